@@ -1,0 +1,104 @@
+"""ctypes binding of libcmdp.so (include/cmdp.h).  Fails loudly when the HIP library is missing:
+there is no CPU fallback anywhere in this package."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcmdp.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_NEEDS_RESET, ERR_UNSUPPORTED, ERR_MAX_ITER, ERR_NO_DEVICE, ERR_MAX_VALUE = (
+    0, -1, -2, -3, -4, -5, -6, -7)
+RNG_MT_COMPAT, RNG_PHILOX = 0, 1
+POLICY_RANDOM, POLICY_HOST_ACTIONS, POLICY_GREEDY_Q = 0, 1, 2
+SCHEME_AUTO, SCHEME_JACOBI, SCHEME_GAUSS_SEIDEL = 0, 1, 2
+LAYOUT_CSR, LAYOUT_DENSE = 0, 1
+
+EXPORTS = [
+    "cmdp_version", "cmdp_last_error", "cmdp_device_count", "cmdp_set_device", "cmdp_create", "cmdp_destroy",
+    "cmdp_stream", "cmdp_reset", "cmdp_step", "cmdp_rollout", "cmdp_rollout_async", "cmdp_synchronize",
+    "cmdp_visits", "cmdp_reset_visits", "cmdp_state", "cmdp_vi_discounted", "cmdp_pe_discounted",
+    "cmdp_vi_episodic", "cmdp_pe_episodic", "cmdp_diameter", "cmdp_value_norm",
+]
+
+
+class CmdpDesc(C.Structure):
+    _fields_ = [
+        ("n_instances", C.c_int32), ("n_actions", C.c_int32), ("horizon", C.c_int32), ("rng_mode", C.c_int32),
+        ("layout", C.c_int32), ("reserved", C.c_int32),
+        ("reward_min", C.c_double), ("reward_max", C.c_double),
+        ("state_off", C.c_void_p),
+        ("sp_ptr", C.c_void_p), ("sp_next", C.c_void_p), ("sp_cum", C.c_void_p), ("sp_reward", C.c_void_p),
+        ("sp_rkind", C.c_void_p), ("sp_seed", C.c_void_p), ("start_off", C.c_void_p), ("start_state", C.c_void_p),
+        ("start_cum", C.c_void_p), ("start_seed", C.c_void_p), ("philox_key", C.c_void_p),
+        ("csr_ptr", C.c_void_p), ("csr_col", C.c_void_p), ("csr_val", C.c_void_p), ("R", C.c_void_p),
+    ]
+
+
+class CmdpError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libcmdp error {code}: {message}")
+        self.code = code
+
+
+class DynamicProgrammingMaxIterationExceeded(Exception):
+    """Same name as the reference's exception (colosseum/dynamic_programming/utils.py:8-9)."""
+
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises if it has not been built (python __graft_entry__.py / build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                f"(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+        L.cmdp_version.restype = C.c_int
+        L.cmdp_last_error.restype = C.c_char_p
+        L.cmdp_device_count.restype = C.c_int
+        L.cmdp_set_device.argtypes = [i32]
+        L.cmdp_create.argtypes = [C.POINTER(vp), C.POINTER(CmdpDesc)]
+        L.cmdp_destroy.argtypes = [vp]
+        L.cmdp_stream.restype = vp
+        L.cmdp_stream.argtypes = [vp]
+        L.cmdp_reset.argtypes = [vp, vp, vp]
+        L.cmdp_step.argtypes = [vp, vp, i32, vp, vp, vp]
+        L.cmdp_rollout.argtypes = [vp, i32, vp, i64, vp, vp, vp, vp, vp]
+        L.cmdp_rollout_async.argtypes = [vp, i32, i64]
+        L.cmdp_synchronize.argtypes = [vp]
+        L.cmdp_visits.argtypes = [vp, vp, vp]
+        L.cmdp_reset_visits.argtypes = [vp]
+        L.cmdp_state.argtypes = [vp, vp, vp, vp]
+        L.cmdp_vi_discounted.argtypes = [vp, f32, f64, i32, i64, f64, vp, vp, vp, vp]
+        L.cmdp_pe_discounted.argtypes = [vp, vp, f32, f64, i32, i64, vp, vp, vp, vp]
+        L.cmdp_vi_episodic.argtypes = [vp, i32, vp, vp, vp]
+        L.cmdp_pe_episodic.argtypes = [vp, i32, vp, vp, vp, vp]
+        L.cmdp_diameter.argtypes = [vp, f64, i32, i64, vp, vp]
+        L.cmdp_value_norm.argtypes = [vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc == OK:
+        return
+    msg = load().cmdp_last_error().decode()
+    if rc == ERR_MAX_ITER:
+        raise DynamicProgrammingMaxIterationExceeded(msg)
+    if rc == ERR_NEEDS_RESET:
+        raise AssertionError(msg)  # the reference raises AssertionError (mdp/base.py:1290)
+    raise CmdpError(rc, msg)
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def carr(a, dtype):
+    return None if a is None else np.ascontiguousarray(a, dtype)

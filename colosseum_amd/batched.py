@@ -1,0 +1,214 @@
+"""BatchedMDP: B independent MDP instances resident on one MI355X, advanced together.
+
+The throughput-side counterpart of the reference's one-environment-per-process fan-out
+(colosseum/experiment/experiment_instances.py:160-166): instances are (parameterisation x seed) pairs,
+laid out back to back in HBM; every method is one call through the C ABI of libcmdp.so."""
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+from .mdp.builder import TabularModel
+
+
+class BatchedMDP:
+    def __init__(self, models: Sequence[TabularModel], rng_mode: int = L.RNG_MT_COMPAT,
+                 philox_keys: Optional[Sequence[int]] = None, with_env: bool = True, with_dp: bool = True):
+        lib = L.load()
+        models = list(models)
+        assert len(models) > 0
+        A, H = models[0].n_actions, models[0].H
+        rr = models[0].rewards_range
+        for m in models:
+            if m.n_actions != A or m.H != H or tuple(m.rewards_range) != tuple(rr):
+                raise ValueError("all instances of a batch share n_actions, the horizon H and the rewards range")
+        self.models = models
+        self.B, self.A, self.H = len(models), A, H
+        self.n_states = np.array([m.n_states for m in models], np.int64)
+        self.state_off = np.concatenate([[0], np.cumsum(self.n_states)]).astype(np.int64)
+        self.row_off = self.state_off * A
+        self.rng_mode = rng_mode
+        keep = {}
+        d = L.CmdpDesc()
+        d.n_instances, d.n_actions, d.horizon, d.rng_mode, d.layout = self.B, A, H, rng_mode, L.LAYOUT_CSR
+        d.reward_min, d.reward_max = float(rr[0]), float(rr[1])
+        keep["state_off"] = self.state_off
+        if with_env:
+            ent = np.array([len(m.sp_next) for m in models], np.int64)
+            ent_off = np.concatenate([[0], np.cumsum(ent)])
+            keep["sp_ptr"] = np.concatenate(
+                [m.sp_ptr[:-1] + ent_off[i] for i, m in enumerate(models)] + [ent_off[-1:]]).astype(np.int64)
+            keep["sp_next"] = np.concatenate([m.sp_next for m in models]).astype(np.int32)
+            keep["sp_cum"] = np.concatenate([m.sp_cum for m in models]).astype(np.float64)
+            keep["sp_reward"] = np.concatenate([m.sp_rp0 for m in models]).astype(np.float64)
+            keep["sp_rkind"] = np.concatenate([m.sp_rkind for m in models]).astype(np.uint8)
+            keep["sp_seed"] = np.concatenate([m.sp_seed for m in models]).astype(np.int32)
+            ns = np.array([len(m.start_states) for m in models], np.int64)
+            keep["start_off"] = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+            keep["start_state"] = np.concatenate([m.start_states for m in models]).astype(np.int32)
+            # itertools.accumulate == sequential float64 adds == np.cumsum
+            keep["start_cum"] = np.concatenate([np.cumsum(m.start_probs) for m in models]).astype(np.float64)
+            keep["start_seed"] = np.array([max(m.start_seed, 0) for m in models], np.int32)
+            if philox_keys is None:
+                philox_keys = np.arange(self.B, dtype=np.uint64)
+            keep["philox_key"] = np.ascontiguousarray(philox_keys, np.uint64)
+            assert len(keep["philox_key"]) == self.B
+        if with_dp:
+            csrs = [m.csr() for m in models]
+            nz = np.array([len(c[1]) for c in csrs], np.int64)
+            nz_off = np.concatenate([[0], np.cumsum(nz)])
+            keep["csr_ptr"] = np.concatenate(
+                [c[0][:-1].astype(np.int64) + nz_off[i] for i, c in enumerate(csrs)] + [nz_off[-1:]]).astype(np.int64)
+            keep["csr_col"] = np.concatenate([c[1] for c in csrs]).astype(np.int32)
+            keep["csr_val"] = np.concatenate([c[2] for c in csrs]).astype(np.float32)
+            keep["R"] = np.concatenate([m.reward_matrix().ravel() for m in models]).astype(np.float32)
+        for k, v in keep.items():
+            keep[k] = np.ascontiguousarray(v)
+            setattr(d, k, L.ptr(keep[k]))
+        self._keep = keep
+        self._h = C.c_void_p()
+        L.check(lib.cmdp_create(C.byref(self._h), C.byref(d)))
+        self._lib = lib
+
+    # -- life cycle --------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.cmdp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- interaction ------------------------------------------------------------------------------------
+    def reset(self, mask=None) -> np.ndarray:
+        obs = np.zeros(self.B, np.int32)
+        m = L.carr(mask, np.uint8)
+        L.check(self._lib.cmdp_reset(self._h, L.ptr(m), L.ptr(obs)))
+        return obs
+
+    def step(self, actions, auto_reset: bool = False):
+        a = L.carr(np.broadcast_to(np.asarray(actions), (self.B,)), np.int32)
+        obs = np.zeros(self.B, np.int32)
+        rew = np.zeros(self.B, np.float64)
+        st = np.zeros(self.B, np.uint8)
+        L.check(self._lib.cmdp_step(self._h, L.ptr(a), int(auto_reset), L.ptr(obs), L.ptr(rew), L.ptr(st)))
+        return obs, rew, st
+
+    def rollout(self, n_steps: int, actions=None, trace: bool = False):
+        """n_steps transitions per instance (episodic terminations are followed by reset()).
+        actions: None -> on-device uniform random policy; else int array [n_steps, B]."""
+        n_steps = int(n_steps)
+        last = np.zeros(self.B, np.int32)
+        rsum = np.zeros(self.B, np.float64)
+        tr_obs = np.zeros((n_steps, self.B), np.int32) if trace else None
+        tr_rew = np.zeros((n_steps, self.B), np.float64) if trace else None
+        tr_ty = np.zeros((n_steps, self.B), np.uint8) if trace else None
+        if actions is None:
+            policy, arg = L.POLICY_RANDOM, None
+        else:
+            arg = L.carr(actions, np.int8)
+            assert arg.shape == (n_steps, self.B), f"actions must be [n_steps, B], got {arg.shape}"
+            policy = L.POLICY_HOST_ACTIONS
+        L.check(self._lib.cmdp_rollout(self._h, policy, L.ptr(arg), n_steps, L.ptr(last), L.ptr(rsum), L.ptr(tr_obs),
+                                       L.ptr(tr_rew), L.ptr(tr_ty)))
+        out = dict(last_obs=last, reward_sum=rsum)
+        if trace:
+            out.update(obs=tr_obs, rew=tr_rew, stype=tr_ty)
+        return out
+
+    def rollout_async(self, n_steps: int):
+        L.check(self._lib.cmdp_rollout_async(self._h, L.POLICY_RANDOM, int(n_steps)))
+
+    def synchronize(self):
+        L.check(self._lib.cmdp_synchronize(self._h))
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.cmdp_stream(self._h) or 0)
+
+    def visits(self):
+        """(state counts [sum S], state-action counts [sum S*A]); split with `split_states`/`split_rows`."""
+        vs = np.zeros(int(self.state_off[-1]), np.int64)
+        vsa = np.zeros(int(self.row_off[-1]), np.int64)
+        L.check(self._lib.cmdp_visits(self._h, L.ptr(vs), L.ptr(vsa)))
+        return vs, vsa
+
+    def reset_visits(self):
+        L.check(self._lib.cmdp_reset_visits(self._h))
+
+    def state(self):
+        cur = np.zeros(self.B, np.int32)
+        h = np.zeros(self.B, np.int32)
+        nr = np.zeros(self.B, np.uint8)
+        L.check(self._lib.cmdp_state(self._h, L.ptr(cur), L.ptr(h), L.ptr(nr)))
+        return cur, h, nr.astype(bool)
+
+    # -- helpers ------------------------------------------------------------------------------------------
+    def split_states(self, flat, lead: int = 1) -> List[np.ndarray]:
+        return [flat[lead * self.state_off[b]: lead * self.state_off[b + 1]] for b in range(self.B)]
+
+    def split_rows(self, flat, lead: int = 1) -> List[np.ndarray]:
+        return [flat[lead * self.row_off[b]: lead * self.row_off[b + 1]] for b in range(self.B)]
+
+    def _flat_rows(self, per_instance, lead: int = 1):
+        if per_instance is None:
+            return None
+        if isinstance(per_instance, np.ndarray) and per_instance.ndim == 1 and per_instance.size == lead * self.row_off[-1]:
+            return L.carr(per_instance, np.float32)
+        return L.carr(np.concatenate([np.asarray(x, np.float32).ravel() for x in per_instance]), np.float32)
+
+    # -- dynamic programming ----------------------------------------------------------------------------------
+    def value_iteration(self, gamma=0.99, epsilon=1e-3, scheme=L.SCHEME_AUTO, max_sweeps=1_000_000,
+                        max_abs_value=None, R=None):
+        Q = np.zeros(int(self.row_off[-1]), np.float32)
+        V = np.zeros(int(self.state_off[-1]), np.float32)
+        sw = np.zeros(self.B, np.int64)
+        Rov = self._flat_rows(R)
+        L.check(self._lib.cmdp_vi_discounted(self._h, gamma, epsilon, scheme, max_sweeps,
+                                             0.0 if max_abs_value is None else float(max_abs_value), L.ptr(Rov),
+                                             L.ptr(Q), L.ptr(V), L.ptr(sw)))
+        return Q, V, sw
+
+    def policy_evaluation(self, pi, gamma=0.99, epsilon=1e-7, scheme=L.SCHEME_AUTO, max_sweeps=1_000_000, R=None):
+        Q = np.zeros(int(self.row_off[-1]), np.float32)
+        V = np.zeros(int(self.state_off[-1]), np.float32)
+        sw = np.zeros(self.B, np.int64)
+        p = self._flat_rows(pi)
+        Rov = self._flat_rows(R)
+        L.check(self._lib.cmdp_pe_discounted(self._h, L.ptr(p), gamma, epsilon, scheme, max_sweeps, L.ptr(Rov),
+                                             L.ptr(Q), L.ptr(V), L.ptr(sw)))
+        return Q, V, sw
+
+    def episodic_value_iteration(self, H=None, R=None):
+        H = self.H if H is None else int(H)
+        Q = np.zeros((H + 1) * int(self.row_off[-1]), np.float32)
+        V = np.zeros((H + 1) * int(self.state_off[-1]), np.float32)
+        Rov = self._flat_rows(R)
+        L.check(self._lib.cmdp_vi_episodic(self._h, H, L.ptr(Rov), L.ptr(Q), L.ptr(V)))
+        return Q, V
+
+    def episodic_policy_evaluation(self, pi, H=None, R=None):
+        H = self.H if H is None else int(H)
+        Q = np.zeros((H + 1) * int(self.row_off[-1]), np.float32)
+        V = np.zeros((H + 1) * int(self.state_off[-1]), np.float32)
+        p = self._flat_rows(pi, lead=H)
+        Rov = self._flat_rows(R)
+        L.check(self._lib.cmdp_pe_episodic(self._h, H, L.ptr(p), L.ptr(Rov), L.ptr(Q), L.ptr(V)))
+        return Q, V
+
+    def diameter(self, epsilon=1e-3, scheme=L.SCHEME_AUTO, max_sweeps=1_000_000):
+        per = np.zeros(int(self.state_off[-1]), np.float32)
+        diam = np.zeros(self.B, np.float32)
+        L.check(self._lib.cmdp_diameter(self._h, epsilon, scheme, max_sweeps, L.ptr(per), L.ptr(diam)))
+        return diam, per
+
+    def value_norm(self, V):
+        v = L.carr(V, np.float32)
+        assert v.size == self.state_off[-1]
+        out = np.zeros(self.B, np.float32)
+        L.check(self._lib.cmdp_value_norm(self._h, L.ptr(v), L.ptr(out)))
+        return out

@@ -1,0 +1,725 @@
+// cmdp.hip -- C ABI (include/cmdp.h) over the HIP kernels of cmdp_kernels.h.  gfx950 only.
+#include "../../include/cmdp.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cmdp_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(CMDP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+constexpr int kLdsBudget = 160 * 1024;  // bytes of LDS one workgroup may claim on gfx950
+constexpr int kDpBlock = 256;
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+  }
+  hipError_t upload(const T* src, size_t count, hipStream_t s) {
+    hipError_t e = alloc(count);
+    if (e != hipSuccess || count == 0) return e;
+    return hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s);
+  }
+  hipError_t zero(hipStream_t s) { return n ? hipMemsetAsync(p, 0, n * sizeof(T), s) : hipSuccess; }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~DevBuf() { release(); }
+};
+
+}  // namespace
+
+struct cmdp {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int B = 0, A = 0, H = 0, rng_mode = 0, layout = 0;
+  double rmin = 0, rmax = 1;
+  int64_t n_states = 0, n_rows = 0, n_entries = 0, n_csr = 0, n_slots = 0;
+  bool has_env = false, has_dp = false;
+  std::vector<int64_t> state_off;  // host copy
+  std::vector<int64_t> csr_nnz;    // per instance
+  int max_S = 0;
+  int64_t max_inst_nnz = 0;
+
+  DevBuf<int64_t> d_state_off, d_entry_base, d_start_off, d_csr_ptr;
+  DevBuf<RowDesc> d_row;
+  DevBuf<int32_t> d_sp_next, d_start_state, d_start_slot, d_mt_pos, d_cur, d_h, d_visits_s, d_visits_sa, d_csr_col,
+      d_flag, d_status, d_i32_scratch;
+  DevBuf<double> d_sp_cum, d_sp_reward, d_start_cum, d_f64_scratch;
+  DevBuf<uint2> d_key;
+  DevBuf<uint32_t> d_mt;
+  DevBuf<uint8_t> d_need_reset, d_u8_scratch;
+  DevBuf<unsigned long long> d_ntrans, d_nreset;
+  DevBuf<float> d_csr_val, d_R, d_Rov, d_pi, d_Q, d_V, d_per_target, d_Ev, d_out;
+  DevBuf<int64_t> d_sweeps;
+  DevBuf<int8_t> d_actions8;
+  DevBuf<int32_t> d_tr_obs, d_last_obs;
+  DevBuf<double> d_tr_rew, d_rsum;
+  DevBuf<uint8_t> d_tr_type, d_mask;
+
+  EnvTables env() {
+    EnvTables t{};
+    t.B = B; t.A = A; t.H = H; t.rng_mode = rng_mode;
+    t.rscale = rmax - rmin; t.rmin = rmin;
+    t.state_off = d_state_off.p; t.entry_base = d_entry_base.p; t.row = d_row.p;
+    t.sp_next = d_sp_next.p; t.sp_cum = d_sp_cum.p; t.sp_reward = d_sp_reward.p;
+    t.start_off = d_start_off.p; t.start_state = d_start_state.p; t.start_cum = d_start_cum.p;
+    t.start_slot = d_start_slot.p; t.philox_key = d_key.p; t.mt = d_mt.p; t.mt_pos = d_mt_pos.p;
+    t.cur = d_cur.p; t.hstep = d_h.p; t.need_reset = d_need_reset.p; t.n_trans = d_ntrans.p; t.n_reset = d_nreset.p;
+    t.visits_s = d_visits_s.p; t.visits_sa = d_visits_sa.p;
+    return t;
+  }
+};
+
+namespace {
+
+int bind(cmdp_t* h) {
+  if (!h) return fail(CMDP_ERR_INVALID, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  return CMDP_OK;
+}
+
+inline int grid_for(int64_t n, int block) { return (int)((n + block - 1) / block); }
+
+}  // namespace
+
+extern "C" {
+
+int cmdp_version(void) { return CMDP_ABI_VERSION; }
+
+const char* cmdp_last_error(void) { return g_err.c_str(); }
+
+int cmdp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int cmdp_set_device(int device) {
+  HIP_TRY(hipSetDevice(device));
+  return CMDP_OK;
+}
+
+void* cmdp_stream(cmdp_t* h) { return h ? (void*)h->stream : nullptr; }
+
+int cmdp_destroy(cmdp_t* h) {
+  if (!h) return CMDP_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) {
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamDestroy(h->stream);
+  }
+  delete h;
+  return CMDP_OK;
+}
+
+int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
+  if (!out || !d) return fail(CMDP_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (d->n_instances < 1 || d->n_actions < 1 || d->n_actions > 64 || d->horizon < 0)
+    return fail(CMDP_ERR_INVALID, "n_instances/n_actions/horizon out of range (1 <= A <= 64)");
+  if (d->rng_mode != CMDP_RNG_MT_COMPAT && d->rng_mode != CMDP_RNG_PHILOX) return fail(CMDP_ERR_INVALID, "rng_mode");
+  if (d->layout != CMDP_LAYOUT_CSR) return fail(CMDP_ERR_UNSUPPORTED, "only CMDP_LAYOUT_CSR is built");
+  if (!d->state_off) return fail(CMDP_ERR_INVALID, "state_off is required");
+  const bool has_env = d->sp_ptr != nullptr;
+  const bool has_dp = d->csr_ptr != nullptr;
+  if (!has_env && !has_dp) return fail(CMDP_ERR_INVALID, "neither the sampler half nor the DP half is present");
+  if (has_env && (!d->sp_next || !d->sp_cum || !d->sp_reward || !d->start_off || !d->start_state || !d->start_cum))
+    return fail(CMDP_ERR_INVALID, "sampler half is incomplete");
+  if (has_env && d->rng_mode == CMDP_RNG_MT_COMPAT && (!d->sp_seed || !d->start_seed))
+    return fail(CMDP_ERR_INVALID, "MT_COMPAT needs sp_seed and start_seed");
+  if (has_dp && (!d->csr_col || !d->csr_val || !d->R)) return fail(CMDP_ERR_INVALID, "DP half is incomplete");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(CMDP_ERR_NO_DEVICE, "no HIP device visible");
+
+  const int B = d->n_instances, A = d->n_actions;
+  if (d->state_off[0] != 0) return fail(CMDP_ERR_INVALID, "state_off[0] != 0");
+  int max_S = 0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t S = d->state_off[b + 1] - d->state_off[b];
+    if (S < 1 || S > (1 << 28)) return fail(CMDP_ERR_INVALID, "instance %d has %lld states", b, (long long)S);
+    max_S = std::max<int>(max_S, (int)S);
+  }
+  const int64_t NS = d->state_off[B], R = NS * A;
+
+  cmdp_t* h = new cmdp;
+  struct Guard {
+    cmdp_t* h;
+    ~Guard() { if (h) cmdp_destroy(h); }
+  } guard{h};
+  HIP_TRY(hipGetDevice(&h->device));
+  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  hipStream_t st = h->stream;
+  h->B = B; h->A = A; h->H = d->horizon; h->rng_mode = d->rng_mode; h->layout = d->layout;
+  h->rmin = d->reward_min; h->rmax = d->reward_max;
+  h->n_states = NS; h->n_rows = R; h->max_S = max_S;
+  h->has_env = has_env; h->has_dp = has_dp;
+  h->state_off.assign(d->state_off, d->state_off + B + 1);
+  HIP_TRY(h->d_state_off.upload(d->state_off, B + 1, st));
+  HIP_TRY(h->d_flag.alloc(1));
+
+  if (has_env) {
+    const int64_t E = d->sp_ptr[R];
+    h->n_entries = E;
+    if (d->sp_ptr[0] != 0) return fail(CMDP_ERR_INVALID, "sp_ptr[0] != 0");
+    if (d->sp_rkind)
+      for (int64_t e = 0; e < E; ++e)
+        if (d->sp_rkind[e] != 0)
+          return fail(CMDP_ERR_UNSUPPORTED, "stochastic reward distributions are not built (entry %lld)", (long long)e);
+    // row descriptors, entry bases, MT slots -- validated on the host so that no kernel can index out of range
+    std::vector<RowDesc> rows((size_t)R);
+    std::vector<int64_t> ebase((size_t)B);
+    std::vector<int32_t> seeds;
+    for (int b = 0; b < B; ++b) {
+      const int64_t s0 = d->state_off[b], S = d->state_off[b + 1] - s0;
+      const int64_t r0 = s0 * A, r1 = (s0 + S) * A;
+      ebase[b] = d->sp_ptr[r0];
+      for (int64_t r = r0; r < r1; ++r) {
+        const int64_t lo = d->sp_ptr[r], n = d->sp_ptr[r + 1] - lo;
+        if (n < 1 || n > 4096 || lo - ebase[b] > 0x7fffffffLL)
+          return fail(CMDP_ERR_INVALID, "row %lld has %lld successors", (long long)r, (long long)n);
+        for (int64_t e = lo; e < lo + n; ++e) {
+          if (d->sp_next[e] < 0 || d->sp_next[e] >= S)
+            return fail(CMDP_ERR_INVALID, "successor index out of range at entry %lld", (long long)e);
+          if (e > lo && d->sp_cum[e] < d->sp_cum[e - 1])
+            return fail(CMDP_ERR_INVALID, "sp_cum not non-decreasing at entry %lld", (long long)e);
+        }
+        RowDesc rd;
+        rd.first = (int32_t)(lo - ebase[b]);
+        rd.n = (int32_t)n;
+        rd.next_if_det = d->sp_next[lo];
+        rd.mt_slot = -1;
+        if (n > 1 && d->rng_mode == CMDP_RNG_MT_COMPAT) {
+          rd.mt_slot = (int32_t)seeds.size();
+          seeds.push_back(d->sp_seed[r]);
+        }
+        rows[(size_t)r] = rd;
+      }
+    }
+    std::vector<int32_t> start_slot((size_t)B, -1);
+    if (d->start_off[0] != 0) return fail(CMDP_ERR_INVALID, "start_off[0] != 0");
+    for (int b = 0; b < B; ++b) {
+      const int64_t lo = d->start_off[b], n = d->start_off[b + 1] - lo;
+      const int64_t S = d->state_off[b + 1] - d->state_off[b];
+      if (n < 1) return fail(CMDP_ERR_INVALID, "instance %d has no starting state", b);
+      for (int64_t i = lo; i < lo + n; ++i)
+        if (d->start_state[i] < 0 || d->start_state[i] >= S)
+          return fail(CMDP_ERR_INVALID, "starting state out of range (instance %d)", b);
+      if (n > 1 && d->rng_mode == CMDP_RNG_MT_COMPAT) {
+        start_slot[b] = (int32_t)seeds.size();
+        seeds.push_back(d->start_seed[b]);
+      }
+    }
+    if (seeds.size() > 0x7fffffffULL / 2) return fail(CMDP_ERR_INVALID, "too many MT19937 sampler streams");
+    h->n_slots = (int64_t)seeds.size();
+    const int64_t NSt = d->start_off[B];
+    HIP_TRY(h->d_row.upload(rows.data(), rows.size(), st));
+    HIP_TRY(h->d_entry_base.upload(ebase.data(), ebase.size(), st));
+    HIP_TRY(h->d_sp_next.upload(d->sp_next, E, st));
+    HIP_TRY(h->d_sp_cum.upload(d->sp_cum, E, st));
+    HIP_TRY(h->d_sp_reward.upload(d->sp_reward, E, st));
+    HIP_TRY(h->d_start_off.upload(d->start_off, B + 1, st));
+    HIP_TRY(h->d_start_state.upload(d->start_state, NSt, st));
+    HIP_TRY(h->d_start_cum.upload(d->start_cum, NSt, st));
+    HIP_TRY(h->d_start_slot.upload(start_slot.data(), B, st));
+    std::vector<uint2> keys((size_t)B);
+    for (int b = 0; b < B; ++b) {
+      const uint64_t k = d->philox_key ? d->philox_key[b] : 0;
+      keys[b] = make_uint2((uint32_t)k, (uint32_t)(k >> 32));
+    }
+    HIP_TRY(h->d_key.upload(keys.data(), B, st));
+    HIP_TRY(h->d_cur.alloc(B));
+    HIP_TRY(h->d_cur.zero(st));
+    HIP_TRY(h->d_h.alloc(B));
+    HIP_TRY(h->d_h.zero(st));
+    HIP_TRY(h->d_need_reset.alloc(B));
+    HIP_TRY(hipMemsetAsync(h->d_need_reset.p, 1, B, st));  // BaseMDP starts with a reset pending
+    HIP_TRY(h->d_ntrans.alloc(B));
+    HIP_TRY(h->d_ntrans.zero(st));
+    HIP_TRY(h->d_nreset.alloc(B));
+    HIP_TRY(h->d_nreset.zero(st));
+    HIP_TRY(h->d_visits_s.alloc(NS));
+    HIP_TRY(h->d_visits_s.zero(st));
+    HIP_TRY(h->d_visits_sa.alloc(R));
+    HIP_TRY(h->d_visits_sa.zero(st));
+    if (h->n_slots) {
+      DevBuf<int32_t> d_seeds;
+      HIP_TRY(d_seeds.upload(seeds.data(), seeds.size(), st));
+      HIP_TRY(h->d_mt.alloc((size_t)h->n_slots * 624));
+      HIP_TRY(h->d_mt_pos.alloc(h->n_slots));
+      hipLaunchKernelGGL(k_mt_seed, dim3(grid_for(h->n_slots, 64)), dim3(64), 0, st, h->d_mt.p, h->d_mt_pos.p,
+                         d_seeds.p, h->n_slots);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(st));  // d_seeds is released at scope exit
+    }
+  }
+
+  if (has_dp) {
+    if (d->csr_ptr[0] != 0) return fail(CMDP_ERR_INVALID, "csr_ptr[0] != 0");
+    const int64_t N = d->csr_ptr[R];
+    h->n_csr = N;
+    h->csr_nnz.resize(B);
+    for (int b = 0; b < B; ++b) {
+      const int64_t s0 = d->state_off[b], S = d->state_off[b + 1] - s0;
+      const int64_t r0 = s0 * A, r1 = (s0 + S) * A;
+      h->csr_nnz[b] = d->csr_ptr[r1] - d->csr_ptr[r0];
+      if (h->csr_nnz[b] > 0x7fffffffLL) return fail(CMDP_ERR_INVALID, "instance %d has too many non-zeros", b);
+      h->max_inst_nnz = std::max(h->max_inst_nnz, h->csr_nnz[b]);
+      for (int64_t r = r0; r < r1; ++r) {
+        if (d->csr_ptr[r + 1] < d->csr_ptr[r]) return fail(CMDP_ERR_INVALID, "csr_ptr decreasing at row %lld", (long long)r);
+        for (int64_t k = d->csr_ptr[r]; k < d->csr_ptr[r + 1]; ++k)
+          if (d->csr_col[k] < 0 || d->csr_col[k] >= S)
+            return fail(CMDP_ERR_INVALID, "csr_col out of range at %lld", (long long)k);
+      }
+    }
+    HIP_TRY(h->d_csr_ptr.upload(d->csr_ptr, R + 1, st));
+    HIP_TRY(h->d_csr_col.upload(d->csr_col, N, st));
+    HIP_TRY(h->d_csr_val.upload(d->csr_val, N, st));
+    HIP_TRY(h->d_R.upload(d->R, R, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));  // host staging vectors go out of scope
+  guard.h = nullptr;
+  *out = h;
+  return CMDP_OK;
+}
+
+// ---- interaction --------------------------------------------------------------------------------------
+int cmdp_reset(cmdp_t* h, const uint8_t* mask, int32_t* obs_out) {
+  if (int rc = bind(h)) return rc;
+  if (!h->has_env) return fail(CMDP_ERR_INVALID, "handle was created without the sampler half");
+  hipStream_t st = h->stream;
+  uint8_t* dmask = nullptr;
+  if (mask) {
+    HIP_TRY(h->d_mask.upload(mask, h->B, st));
+    dmask = h->d_mask.p;
+  }
+  if (obs_out && h->d_last_obs.n < (size_t)h->B) HIP_TRY(h->d_last_obs.alloc(h->B));
+  if (obs_out && mask) HIP_TRY(hipMemcpyAsync(h->d_last_obs.p, obs_out, sizeof(int32_t) * h->B, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_reset, dim3(grid_for(h->B, 256)), dim3(256), 0, st, h->env(), dmask,
+                     obs_out ? h->d_last_obs.p : nullptr);
+  HIP_TRY(hipGetLastError());
+  if (obs_out) HIP_TRY(hipMemcpyAsync(obs_out, h->d_last_obs.p, sizeof(int32_t) * h->B, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return CMDP_OK;
+}
+
+static int any_needs_reset(cmdp_t* h, bool* any) {
+  hipStream_t st = h->stream;
+  HIP_TRY(h->d_flag.zero(st));
+  hipLaunchKernelGGL(k_any_needs_reset, dim3(grid_for(h->B, 256)), dim3(256), 0, st, h->d_need_reset.p, h->B,
+                     h->d_flag.p);
+  HIP_TRY(hipGetLastError());
+  int32_t f = 0;
+  HIP_TRY(hipMemcpyAsync(&f, h->d_flag.p, sizeof f, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  *any = f != 0;
+  return CMDP_OK;
+}
+
+int cmdp_step(cmdp_t* h, const int32_t* actions, int auto_reset, int32_t* obs, double* reward, uint8_t* step_type) {
+  if (int rc = bind(h)) return rc;
+  if (!h->has_env) return fail(CMDP_ERR_INVALID, "handle was created without the sampler half");
+  if (!actions || !obs || !reward || !step_type) return fail(CMDP_ERR_INVALID, "null argument");
+  hipStream_t st = h->stream;
+  const int B = h->B;
+  if (h->d_i32_scratch.n < (size_t)2 * B) HIP_TRY(h->d_i32_scratch.alloc((size_t)2 * B));
+  if (h->d_f64_scratch.n < (size_t)B) HIP_TRY(h->d_f64_scratch.alloc(B));
+  if (h->d_u8_scratch.n < (size_t)B) HIP_TRY(h->d_u8_scratch.alloc(B));
+  int32_t* d_act = h->d_i32_scratch.p;
+  int32_t* d_obs = h->d_i32_scratch.p + B;
+  HIP_TRY(hipMemcpyAsync(d_act, actions, sizeof(int32_t) * B, hipMemcpyHostToDevice, st));
+  HIP_TRY(h->d_flag.zero(st));
+  if (!auto_reset)
+    hipLaunchKernelGGL(k_any_needs_reset, dim3(grid_for(B, 256)), dim3(256), 0, st, h->d_need_reset.p, B, h->d_flag.p);
+  hipLaunchKernelGGL(k_check_actions, dim3(grid_for(B, 256)), dim3(256), 0, st, d_act, B, h->A, h->d_flag.p);
+  HIP_TRY(hipGetLastError());
+  int32_t f = 0;
+  HIP_TRY(hipMemcpyAsync(&f, h->d_flag.p, sizeof f, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (f & 2) return fail(CMDP_ERR_INVALID, "action out of range [0, %d)", h->A);
+  if (f & 1) return fail(CMDP_ERR_NEEDS_RESET, "step() on an instance that needs reset()");
+  hipLaunchKernelGGL(k_step, dim3(grid_for(B, 256)), dim3(256), 0, st, h->env(), d_act, auto_reset, d_obs,
+                     h->d_f64_scratch.p, h->d_u8_scratch.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(obs, d_obs, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(reward, h->d_f64_scratch.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(step_type, h->d_u8_scratch.p, B, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return CMDP_OK;
+}
+
+static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_t n_steps, double* d_rsum,
+                          int32_t* d_last, int32_t* d_tobs, double* d_trew, uint8_t* d_ttype) {
+  hipStream_t st = h->stream;
+  const dim3 grid(grid_for(h->B, 256)), block(256);
+  const bool trace = d_tobs || d_trew || d_ttype;
+  EnvTables t = h->env();
+  if (policy == CMDP_POLICY_RANDOM) {
+    if (trace) hipLaunchKernelGGL((k_rollout<0, true>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype);
+    else hipLaunchKernelGGL((k_rollout<0, false>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype);
+  } else {
+    if (trace) hipLaunchKernelGGL((k_rollout<1, true>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype);
+    else hipLaunchKernelGGL((k_rollout<1, false>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype);
+  }
+  HIP_TRY(hipGetLastError());
+  return CMDP_OK;
+}
+
+int cmdp_rollout(cmdp_t* h, int policy, const void* policy_arg, int64_t n_steps, int32_t* last_obs, double* reward_sum,
+                 int32_t* trace_obs, double* trace_reward, uint8_t* trace_type) {
+  if (int rc = bind(h)) return rc;
+  if (!h->has_env) return fail(CMDP_ERR_INVALID, "handle was created without the sampler half");
+  if (n_steps < 0) return fail(CMDP_ERR_INVALID, "n_steps < 0");
+  if (policy == CMDP_POLICY_GREEDY_Q) return fail(CMDP_ERR_UNSUPPORTED, "CMDP_POLICY_GREEDY_Q is not built yet");
+  if (policy != CMDP_POLICY_RANDOM && policy != CMDP_POLICY_HOST_ACTIONS) return fail(CMDP_ERR_INVALID, "policy");
+  if (policy == CMDP_POLICY_HOST_ACTIONS && !policy_arg && n_steps > 0) return fail(CMDP_ERR_INVALID, "actions missing");
+  bool any = false;
+  if (int rc = any_needs_reset(h, &any)) return rc;
+  if (any) return fail(CMDP_ERR_NEEDS_RESET, "rollout() on an instance that needs reset()");
+  hipStream_t st = h->stream;
+  const int B = h->B;
+  const size_t NB = (size_t)n_steps * B;
+  const int8_t* d_act = nullptr;
+  if (policy == CMDP_POLICY_HOST_ACTIONS) {
+    const int8_t* a = static_cast<const int8_t*>(policy_arg);
+    for (size_t i = 0; i < NB; ++i)
+      if (a[i] < 0 || a[i] >= h->A) return fail(CMDP_ERR_INVALID, "action out of range [0, %d)", h->A);
+    HIP_TRY(h->d_actions8.upload(a, NB, st));
+    d_act = h->d_actions8.p;
+  }
+  if (h->d_rsum.n < (size_t)B) HIP_TRY(h->d_rsum.alloc(B));
+  if (h->d_last_obs.n < (size_t)B) HIP_TRY(h->d_last_obs.alloc(B));
+  if (trace_obs && h->d_tr_obs.n < NB) HIP_TRY(h->d_tr_obs.alloc(NB));
+  if (trace_reward && h->d_tr_rew.n < NB) HIP_TRY(h->d_tr_rew.alloc(NB));
+  if (trace_type && h->d_tr_type.n < NB) HIP_TRY(h->d_tr_type.alloc(NB));
+  if (int rc = launch_rollout(h, policy, d_act, n_steps, h->d_rsum.p, h->d_last_obs.p, trace_obs ? h->d_tr_obs.p : nullptr,
+                              trace_reward ? h->d_tr_rew.p : nullptr, trace_type ? h->d_tr_type.p : nullptr))
+    return rc;
+  if (last_obs) HIP_TRY(hipMemcpyAsync(last_obs, h->d_last_obs.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+  if (reward_sum) HIP_TRY(hipMemcpyAsync(reward_sum, h->d_rsum.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+  if (trace_obs) HIP_TRY(hipMemcpyAsync(trace_obs, h->d_tr_obs.p, sizeof(int32_t) * NB, hipMemcpyDeviceToHost, st));
+  if (trace_reward) HIP_TRY(hipMemcpyAsync(trace_reward, h->d_tr_rew.p, sizeof(double) * NB, hipMemcpyDeviceToHost, st));
+  if (trace_type) HIP_TRY(hipMemcpyAsync(trace_type, h->d_tr_type.p, NB, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return CMDP_OK;
+}
+
+int cmdp_rollout_async(cmdp_t* h, int policy, int64_t n_steps) {
+  if (int rc = bind(h)) return rc;
+  if (!h->has_env) return fail(CMDP_ERR_INVALID, "handle was created without the sampler half");
+  if (policy != CMDP_POLICY_RANDOM) return fail(CMDP_ERR_INVALID, "rollout_async supports CMDP_POLICY_RANDOM only");
+  if (n_steps < 0) return fail(CMDP_ERR_INVALID, "n_steps < 0");
+  if (h->d_rsum.n < (size_t)h->B) HIP_TRY(h->d_rsum.alloc(h->B));
+  if (h->d_last_obs.n < (size_t)h->B) HIP_TRY(h->d_last_obs.alloc(h->B));
+  return launch_rollout(h, policy, nullptr, n_steps, h->d_rsum.p, h->d_last_obs.p, nullptr, nullptr, nullptr);
+}
+
+int cmdp_synchronize(cmdp_t* h) {
+  if (int rc = bind(h)) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CMDP_OK;
+}
+
+int cmdp_visits(cmdp_t* h, int64_t* state_counts, int64_t* sa_counts) {
+  if (int rc = bind(h)) return rc;
+  if (!h->has_env) return fail(CMDP_ERR_INVALID, "handle was created without the sampler half");
+  hipStream_t st = h->stream;
+  std::vector<int32_t> tmp;
+  if (state_counts) {
+    tmp.resize((size_t)h->n_states);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), h->d_visits_s.p, sizeof(int32_t) * tmp.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t i = 0; i < tmp.size(); ++i) state_counts[i] = tmp[i];
+  }
+  if (sa_counts) {
+    tmp.resize((size_t)h->n_rows);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), h->d_visits_sa.p, sizeof(int32_t) * tmp.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t i = 0; i < tmp.size(); ++i) sa_counts[i] = tmp[i];
+  }
+  return CMDP_OK;
+}
+
+int cmdp_reset_visits(cmdp_t* h) {
+  if (int rc = bind(h)) return rc;
+  if (!h->has_env) return fail(CMDP_ERR_INVALID, "handle was created without the sampler half");
+  HIP_TRY(h->d_visits_s.zero(h->stream));
+  HIP_TRY(h->d_visits_sa.zero(h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CMDP_OK;
+}
+
+int cmdp_state(cmdp_t* h, int32_t* cur, int32_t* hstep, uint8_t* needs_reset) {
+  if (int rc = bind(h)) return rc;
+  if (!h->has_env) return fail(CMDP_ERR_INVALID, "handle was created without the sampler half");
+  hipStream_t st = h->stream;
+  if (cur) HIP_TRY(hipMemcpyAsync(cur, h->d_cur.p, sizeof(int32_t) * h->B, hipMemcpyDeviceToHost, st));
+  if (hstep) HIP_TRY(hipMemcpyAsync(hstep, h->d_h.p, sizeof(int32_t) * h->B, hipMemcpyDeviceToHost, st));
+  if (needs_reset) HIP_TRY(hipMemcpyAsync(needs_reset, h->d_need_reset.p, h->B, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return CMDP_OK;
+}
+
+}  // extern "C"
+
+// ---- dynamic programming ---------------------------------------------------------------------------------
+namespace {
+
+// AUTO rules of the reference dispatchers (infinite_horizon.py:28-36 and :60-64), per instance.
+int vi_rule(int64_t S, int A, int64_t nnz) {
+  const double size = (double)S * A * (double)S;
+  return (size > 300.0 * 3 * 300 && (double)nnz / size < 0.2) ? CMDP_SCHEME_JACOBI : CMDP_SCHEME_GAUSS_SEIDEL;
+}
+int pe_rule(int64_t S, int A, int64_t nnz) {
+  const double size = (double)S * A * (double)S;
+  return (S > 200 && (double)nnz / size < 0.2) ? CMDP_SCHEME_JACOBI : CMDP_SCHEME_GAUSS_SEIDEL;
+}
+
+// One scheme per launch: all instances of a batch must agree under AUTO (they do when they come from
+// one parameterisation); otherwise the caller picks the scheme explicitly or splits the batch.
+int resolve_scheme(cmdp_t* h, int scheme, bool pe, bool diam, int* out) {
+  if (scheme == CMDP_SCHEME_JACOBI || scheme == CMDP_SCHEME_GAUSS_SEIDEL) { *out = scheme; return CMDP_OK; }
+  if (scheme != CMDP_SCHEME_AUTO) return fail(CMDP_ERR_INVALID, "scheme");
+  int chosen = 0;
+  for (int b = 0; b < h->B; ++b) {
+    const int64_t S = h->state_off[b + 1] - h->state_off[b];
+    int64_t nnz = h->csr_nnz[b];
+    if (diam) nnz = std::max<int64_t>(nnz, 1);  // T_es differs from T only by the rows of the target
+    const int s = pe ? pe_rule(S, h->A, nnz) : vi_rule(S, h->A, nnz);
+    if (chosen == 0) chosen = s;
+    else if (chosen != s)
+      return fail(CMDP_ERR_INVALID, "CMDP_SCHEME_AUTO selects different schemes inside this batch; pass the scheme "
+                                    "explicitly or split the batch");
+  }
+  *out = chosen;
+  return CMDP_OK;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return CMDP_OK;
+}
+
+// Launches the sweep kernels for `units` work items (instances, or (instance,target) pairs).
+int run_sweeps(cmdp_t* h, int mode, bool diam, int scheme, DpTables t, int64_t units) {
+  hipStream_t st = h->stream;
+  if (units > 0x7fffffffLL) return fail(CMDP_ERR_INVALID, "too many work items");
+  const size_t v_bytes = sizeof(float) * (size_t)h->max_S;
+  if (scheme == CMDP_SCHEME_JACOBI) {
+    const size_t base = 2 * v_bytes + sizeof(float) * 4 * (kDpBlock / 64);
+    const size_t csr = sizeof(int32_t) * ((size_t)h->max_S * h->A + 1) + 8 * (size_t)h->max_inst_nnz +
+                       sizeof(float) * (size_t)h->max_S * h->A;
+    if (base > (size_t)kLdsBudget)
+      return fail(CMDP_ERR_UNSUPPORTED, "instance with %d states does not fit the LDS-resident sweep (2*4*S > 160 KiB)", h->max_S);
+    // CSR in LDS when two workgroups still fit on a CU; otherwise it is streamed from L2/HBM every sweep
+    const bool csr_lds = base + csr <= (size_t)kLdsBudget / 2;
+    const size_t lds = csr_lds ? base + csr : base;
+    const dim3 grid((unsigned)units), block(kDpBlock);
+#define LAUNCH_BLOCK(MODE, DIAM)                                                                         \
+  do {                                                                                                   \
+    if (csr_lds) {                                                                                       \
+      if (int rc = set_lds(k_dp_block<MODE, DIAM, true>, lds)) return rc;                                \
+      hipLaunchKernelGGL((k_dp_block<MODE, DIAM, true>), grid, block, lds, st, t);                        \
+    } else {                                                                                             \
+      if (int rc = set_lds(k_dp_block<MODE, DIAM, false>, lds)) return rc;                               \
+      hipLaunchKernelGGL((k_dp_block<MODE, DIAM, false>), grid, block, lds, st, t);                       \
+    }                                                                                                    \
+  } while (0)
+    if (diam) LAUNCH_BLOCK(DP_VI, true);
+    else if (mode == DP_VI) LAUNCH_BLOCK(DP_VI, false);
+    else LAUNCH_BLOCK(DP_PE, false);
+#undef LAUNCH_BLOCK
+  } else {
+    if (v_bytes > (size_t)kLdsBudget)
+      return fail(CMDP_ERR_UNSUPPORTED, "instance with %d states does not fit the LDS-resident sweep", h->max_S);
+    const dim3 grid((unsigned)units), block(64);
+#define LAUNCH_WAVE(MODE, DIAM)                                                       \
+  do {                                                                                \
+    if (int rc = set_lds(k_dp_wave_gs<MODE, DIAM>, v_bytes)) return rc;               \
+    hipLaunchKernelGGL((k_dp_wave_gs<MODE, DIAM>), grid, block, v_bytes, st, t);       \
+  } while (0)
+    if (diam) LAUNCH_WAVE(DP_VI, true);
+    else if (mode == DP_VI) LAUNCH_WAVE(DP_VI, false);
+    else LAUNCH_WAVE(DP_PE, false);
+#undef LAUNCH_WAVE
+  }
+  HIP_TRY(hipGetLastError());
+  return CMDP_OK;
+}
+
+int check_status(cmdp_t* h, int64_t units) {
+  std::vector<int32_t> status((size_t)units);
+  HIP_TRY(hipMemcpyAsync(status.data(), h->d_status.p, sizeof(int32_t) * units, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int64_t u = 0; u < units; ++u) {
+    if (status[u] == CMDP_ERR_MAX_ITER) return fail(CMDP_ERR_MAX_ITER, "work item %lld did not converge within max_sweeps", (long long)u);
+    if (status[u] == CMDP_ERR_MAX_VALUE) return fail(CMDP_ERR_MAX_VALUE, "work item %lld exceeded max_abs_value", (long long)u);
+  }
+  return CMDP_OK;
+}
+
+int discounted(cmdp_t* h, int mode, const float* pi, float gamma, double eps, int scheme, int64_t max_sweeps,
+               double max_abs, const float* R_override, float* Q, float* V, int64_t* sweeps) {
+  if (int rc = bind(h)) return rc;
+  if (!h->has_dp) return fail(CMDP_ERR_INVALID, "handle was created without the DP half");
+  if (!Q || !V) return fail(CMDP_ERR_INVALID, "null output");
+  if (mode == DP_PE && !pi) return fail(CMDP_ERR_INVALID, "pi is required");
+  if (max_sweeps < 1) return fail(CMDP_ERR_INVALID, "max_sweeps < 1");
+  int sch = 0;
+  if (int rc = resolve_scheme(h, scheme, mode == DP_PE, false, &sch)) return rc;
+  hipStream_t st = h->stream;
+  const int64_t R = h->n_rows, NS = h->n_states;
+  if (R_override) HIP_TRY(h->d_Rov.upload(R_override, R, st));
+  if (pi) HIP_TRY(h->d_pi.upload(pi, R, st));
+  if (h->d_Q.n < (size_t)R) HIP_TRY(h->d_Q.alloc(R));
+  if (h->d_V.n < (size_t)NS) HIP_TRY(h->d_V.alloc(NS));
+  if (h->d_sweeps.n < (size_t)h->B) HIP_TRY(h->d_sweeps.alloc(h->B));
+  if (h->d_status.n < (size_t)h->B) HIP_TRY(h->d_status.alloc(h->B));
+  DpTables t{};
+  t.B = h->B; t.A = h->A; t.state_off = h->d_state_off.p; t.csr_ptr = h->d_csr_ptr.p; t.csr_col = h->d_csr_col.p;
+  t.csr_val = h->d_csr_val.p; t.R = R_override ? h->d_Rov.p : h->d_R.p; t.pi = pi ? h->d_pi.p : nullptr;
+  t.unit_off = nullptr; t.gamma = gamma; t.eps = eps; t.max_abs = max_abs; t.max_sweeps = max_sweeps;
+  t.Q = h->d_Q.p; t.V = h->d_V.p; t.sweeps = h->d_sweeps.p; t.per_target = nullptr; t.status = h->d_status.p;
+  if (int rc = run_sweeps(h, mode, false, sch, t, h->B)) return rc;
+  HIP_TRY(hipMemcpyAsync(Q, h->d_Q.p, sizeof(float) * R, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(V, h->d_V.p, sizeof(float) * NS, hipMemcpyDeviceToHost, st));
+  if (sweeps) HIP_TRY(hipMemcpyAsync(sweeps, h->d_sweeps.p, sizeof(int64_t) * h->B, hipMemcpyDeviceToHost, st));
+  return check_status(h, h->B);
+}
+
+int episodic(cmdp_t* h, int mode, int H, const float* pi, const float* R_override, float* Q, float* V) {
+  if (int rc = bind(h)) return rc;
+  if (!h->has_dp) return fail(CMDP_ERR_INVALID, "handle was created without the DP half");
+  if (!Q || !V || H < 1) return fail(CMDP_ERR_INVALID, "bad argument");
+  if (mode == DP_PE && !pi) return fail(CMDP_ERR_INVALID, "pi is required");
+  hipStream_t st = h->stream;
+  const int64_t R = h->n_rows, NS = h->n_states;
+  const size_t lds = 2 * sizeof(float) * (size_t)h->max_S;
+  if (lds > (size_t)kLdsBudget) return fail(CMDP_ERR_UNSUPPORTED, "instance with %d states does not fit LDS", h->max_S);
+  if (R_override) HIP_TRY(h->d_Rov.upload(R_override, R, st));
+  if (pi) HIP_TRY(h->d_pi.upload(pi, (size_t)H * R, st));
+  const size_t nq = (size_t)(H + 1) * R, nv = (size_t)(H + 1) * NS;
+  if (h->d_Q.n < nq) HIP_TRY(h->d_Q.alloc(nq));
+  if (h->d_V.n < nv) HIP_TRY(h->d_V.alloc(nv));
+  DpTables t{};
+  t.B = h->B; t.A = h->A; t.state_off = h->d_state_off.p; t.csr_ptr = h->d_csr_ptr.p; t.csr_col = h->d_csr_col.p;
+  t.csr_val = h->d_csr_val.p; t.R = R_override ? h->d_Rov.p : h->d_R.p; t.pi = pi ? h->d_pi.p : nullptr;
+  const dim3 grid(h->B), block(kDpBlock);
+  if (mode == DP_VI) {
+    if (int rc = set_lds(k_episodic<DP_VI>, lds)) return rc;
+    hipLaunchKernelGGL((k_episodic<DP_VI>), grid, block, lds, st, t, H, h->d_Q.p, h->d_V.p);
+  } else {
+    if (int rc = set_lds(k_episodic<DP_PE>, lds)) return rc;
+    hipLaunchKernelGGL((k_episodic<DP_PE>), grid, block, lds, st, t, H, h->d_Q.p, h->d_V.p);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(Q, h->d_Q.p, sizeof(float) * nq, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(V, h->d_V.p, sizeof(float) * nv, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return CMDP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cmdp_vi_discounted(cmdp_t* h, float gamma, double epsilon, int scheme, int64_t max_sweeps, double max_abs_value,
+                       const float* R_override, float* Q, float* V, int64_t* sweeps) {
+  return discounted(h, DP_VI, nullptr, gamma, epsilon, scheme, max_sweeps, max_abs_value, R_override, Q, V, sweeps);
+}
+
+int cmdp_pe_discounted(cmdp_t* h, const float* pi, float gamma, double epsilon, int scheme, int64_t max_sweeps,
+                       const float* R_override, float* Q, float* V, int64_t* sweeps) {
+  return discounted(h, DP_PE, pi, gamma, epsilon, scheme, max_sweeps, 0.0, R_override, Q, V, sweeps);
+}
+
+int cmdp_vi_episodic(cmdp_t* h, int H, const float* R_override, float* Q, float* V) {
+  return episodic(h, DP_VI, H, nullptr, R_override, Q, V);
+}
+
+int cmdp_pe_episodic(cmdp_t* h, int H, const float* pi, const float* R_override, float* Q, float* V) {
+  return episodic(h, DP_PE, H, pi, R_override, Q, V);
+}
+
+int cmdp_diameter(cmdp_t* h, double epsilon, int scheme, int64_t max_sweeps, float* per_target, float* diameter) {
+  if (int rc = bind(h)) return rc;
+  if (!h->has_dp) return fail(CMDP_ERR_INVALID, "handle was created without the DP half");
+  if (!diameter) return fail(CMDP_ERR_INVALID, "null output");
+  if (max_sweeps < 1) return fail(CMDP_ERR_INVALID, "max_sweeps < 1");
+  int sch = 0;
+  if (int rc = resolve_scheme(h, scheme, false, true, &sch)) return rc;
+  hipStream_t st = h->stream;
+  const int64_t NS = h->n_states;
+  if (h->d_per_target.n < (size_t)NS) HIP_TRY(h->d_per_target.alloc(NS));
+  if (h->d_status.n < (size_t)NS) HIP_TRY(h->d_status.alloc(NS));
+  DpTables t{};
+  t.B = h->B; t.A = h->A; t.state_off = h->d_state_off.p; t.csr_ptr = h->d_csr_ptr.p; t.csr_col = h->d_csr_col.p;
+  t.csr_val = h->d_csr_val.p; t.R = h->d_R.p; t.pi = nullptr; t.unit_off = h->d_state_off.p;
+  t.gamma = 1.0f; t.eps = epsilon; t.max_abs = 0.0; t.max_sweeps = max_sweeps;
+  t.Q = nullptr; t.V = nullptr; t.sweeps = nullptr; t.per_target = h->d_per_target.p; t.status = h->d_status.p;
+  if (int rc = run_sweeps(h, DP_VI, true, sch, t, NS)) return rc;
+  std::vector<float> per((size_t)NS);
+  HIP_TRY(hipMemcpyAsync(per.data(), h->d_per_target.p, sizeof(float) * NS, hipMemcpyDeviceToHost, st));
+  if (int rc = check_status(h, NS)) return rc;
+  for (int b = 0; b < h->B; ++b) {
+    float dmax = 0.0f;  // `diameter = 0` then max(...), diameter.py:99-105
+    for (int64_t s = h->state_off[b]; s < h->state_off[b + 1]; ++s) dmax = std::max(dmax, per[(size_t)s]);
+    diameter[b] = dmax;
+  }
+  if (per_target) std::memcpy(per_target, per.data(), sizeof(float) * NS);
+  return CMDP_OK;
+}
+
+int cmdp_value_norm(cmdp_t* h, const float* V, float* out) {
+  if (int rc = bind(h)) return rc;
+  if (!h->has_dp) return fail(CMDP_ERR_INVALID, "handle was created without the DP half");
+  if (!V || !out) return fail(CMDP_ERR_INVALID, "null argument");
+  hipStream_t st = h->stream;
+  HIP_TRY(h->d_V.upload(V, h->n_states, st));
+  if (h->d_Ev.n < (size_t)h->n_rows) HIP_TRY(h->d_Ev.alloc(h->n_rows));
+  if (h->d_out.n < (size_t)h->B) HIP_TRY(h->d_out.alloc(h->B));
+  DpTables t{};
+  t.B = h->B; t.A = h->A; t.state_off = h->d_state_off.p; t.csr_ptr = h->d_csr_ptr.p; t.csr_col = h->d_csr_col.p;
+  t.csr_val = h->d_csr_val.p; t.R = h->d_R.p;
+  hipLaunchKernelGGL(k_value_norm, dim3(h->B), dim3(256), 0, st, t, h->d_V.p, h->d_Ev.p, h->d_out.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, h->d_out.p, sizeof(float) * h->B, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return CMDP_OK;
+}
+
+}  // extern "C"

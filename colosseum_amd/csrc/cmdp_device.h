@@ -1,0 +1,94 @@
+// cmdp_device.h -- device-side primitives shared by the kernels of libcmdp (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CMDP_WAVE 64
+
+// ---------------------------------------------------------------------------------------------------
+// Philox-4x32-10.  Counter (n_lo, n_hi, domain, 0), key = the instance's 64-bit key.
+// domain 0: transition n  -> w0,w1 = 53-bit transition uniform, w2 = random-policy action
+// domain 1: reset n       -> w0,w1 = start-state uniform
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&w)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  w[0] = c0; w[1] = c1; w[2] = c2; w[3] = c3;
+}
+
+__device__ __forceinline__ double u53(uint32_t w0, uint32_t w1) {
+  return ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// MT19937, one word at a time (identical output sequence to the block "twist" form): CPython's
+// random.Random stream of one NextStateSampler (reference colosseum/mdp/utils/custom_samplers.py:52).
+// State: 624 words + position, position starts at 0 after seeding.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mt_next_word(uint32_t* __restrict__ mt, int& pos) {
+  const int p = pos;
+  const int p1 = (p == 623) ? 0 : p + 1;
+  const int pm = (p >= 227) ? p - 227 : p + 397;
+  const uint32_t y = (mt[p] & 0x80000000u) | (mt[p1] & 0x7fffffffu);
+  uint32_t v = mt[pm] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  mt[p] = v;
+  pos = p1;
+  v ^= v >> 11;
+  v ^= (v << 7) & 0x9d2c5680u;
+  v ^= (v << 15) & 0xefc60000u;
+  v ^= v >> 18;
+  return v;
+}
+
+__device__ __forceinline__ double mt_random(uint32_t* __restrict__ mt, int32_t* __restrict__ pos_ptr) {
+  int pos = *pos_ptr;
+  const uint32_t a = mt_next_word(mt, pos) >> 5;
+  const uint32_t b = mt_next_word(mt, pos) >> 6;
+  *pos_ptr = pos;
+  return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+}
+
+// random.Random(seed) seeding == init_by_array([seed])
+__device__ inline void mt_seed_python_int(uint32_t* __restrict__ mt, uint32_t seed) {
+  mt[0] = 19650218u;
+  for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+  int i = 1;
+  for (int k = 624; k; --k) {
+    mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + seed;  // + j with j == 0 (key length 1)
+    if (++i >= 624) { mt[0] = mt[623]; i = 1; }
+  }
+  for (int k = 623; k; --k) {
+    mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+    if (++i >= 624) { mt[0] = mt[623]; i = 1; }
+  }
+  mt[0] = 0x80000000u;
+}
+
+// `random.choices` index: bisect_right(cum, u*total, 0, n-1) == #{ i < n-1 : cum[i] <= u*total }.
+// Loads are independent (linear count), n is small (<= 1 + lazy + (A-1)*k successors).
+__device__ __forceinline__ int choose_index(const double* __restrict__ cum, int n, double u01) {
+  const double x = u01 * (cum[n - 1] + 0.0);
+  int idx = 0;
+  for (int i = 0; i < n - 1; ++i) idx += (cum[i] <= x) ? 1 : 0;
+  return idx;
+}
+
+// wave-wide reductions (64 lanes)
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,131 @@
+"""Drop-in for `colosseum.dynamic_programming` (reference colosseum/dynamic_programming/*.py): the same
+free functions on dense float32 `T[S,A,S]`, `R[S,A]`, executed by the HIP sweep kernels of libcmdp.so.
+
+Signatures, defaults, return conventions (`None` when `max_abs_value` is exceeded, the
+`DynamicProgrammingMaxIterationExceeded` exception after 10**6 sweeps) follow the reference."""
+import numpy as np
+
+from .. import _lib as L
+from .._lib import DynamicProgrammingMaxIterationExceeded  # noqa: F401
+from ..dp_handle import DPBatch, csr_from_dense
+
+DP_MAX_ITERATION = int(1e6)
+ARGMAX_SEED = 42
+
+
+def _vi_rule(T_size, nnz, sparse_n_states_threshold, sparse_nnz_per_threshold):
+    """reference infinite_horizon.py:28-36."""
+    if T_size > sparse_n_states_threshold and nnz / T_size < sparse_nnz_per_threshold:
+        return L.SCHEME_JACOBI
+    return L.SCHEME_GAUSS_SEIDEL
+
+
+def discounted_value_iteration(T, R, gamma=0.99, epsilon=1e-3, max_abs_value=None,
+                               sparse_n_states_threshold=300 * 3 * 300, sparse_nnz_per_threshold=0.2):
+    """reference infinite_horizon.py:14-44.  Returns (Q [S,A], V [S]) float32, or None."""
+    S, A, _ = T.shape
+    csr = csr_from_dense(T)
+    scheme = _vi_rule(T.size, len(csr[1]), sparse_n_states_threshold, sparse_nnz_per_threshold)
+    with DPBatch([(S, A, csr, np.asarray(R, np.float32))]) as dp:
+        try:
+            Q, V, _ = dp.value_iteration(gamma, epsilon, scheme, DP_MAX_ITERATION, max_abs_value)
+        except L.CmdpError as e:
+            if e.code == L.ERR_MAX_VALUE:
+                return None
+            raise
+    return Q.reshape(S, A), V
+
+
+def discounted_policy_evaluation(T, R, pi, gamma=0.99, epsilon=1e-7, sparse_n_states_threshold=200,
+                                 sparse_nnz_per_threshold=0.2):
+    """reference infinite_horizon.py:47-64."""
+    S, A, _ = T.shape
+    csr = csr_from_dense(T)
+    scheme = (L.SCHEME_JACOBI if (S > sparse_n_states_threshold and len(csr[1]) / T.size < sparse_nnz_per_threshold)
+              else L.SCHEME_GAUSS_SEIDEL)
+    with DPBatch([(S, A, csr, np.asarray(R, np.float32))]) as dp:
+        Q, V, _ = dp.policy_evaluation(np.asarray(pi, np.float32).ravel(), gamma, epsilon, scheme, DP_MAX_ITERATION)
+    return Q.reshape(S, A), V
+
+
+def episodic_value_iteration(H, T, R, max_value=None):
+    """reference finite_horizon.py:11-26.  Returns (Q [H+1,S,A], V [H+1,S]) or None when a value exceeds
+    `max_value`."""
+    S, A, _ = T.shape
+    with DPBatch([(S, A, csr_from_dense(T), np.asarray(R, np.float32))]) as dp:
+        Q, V = dp.episodic_value_iteration(int(H))
+    Q, V = Q.reshape(H + 1, S, A), V.reshape(H + 1, S)
+    if max_value is not None and (V > max_value).any():
+        return None
+    return Q, V
+
+
+def episodic_policy_evaluation(H, T, R, policy):
+    """reference finite_horizon.py:29-42; policy [H,S,A]."""
+    S, A, _ = T.shape
+    with DPBatch([(S, A, csr_from_dense(T), np.asarray(R, np.float32))]) as dp:
+        Q, V = dp.episodic_policy_evaluation(np.asarray(policy, np.float32).ravel(), int(H))
+    return Q.reshape(H + 1, S, A), V.reshape(H + 1, S)
+
+
+def discounted_policy_iteration(T, R, gamma=0.99, epsilon=1e-7):
+    """reference infinite_horizon.py:208-219 (the initial Q is drawn from the unseeded global numpy RNG
+    there too)."""
+    S, A, _ = T.shape
+    Q = np.random.rand(S, A)
+    pi = argmax_2d(Q)
+    for _ in range(DP_MAX_ITERATION):
+        old_pi = pi.copy()
+        Q, V = discounted_policy_evaluation(T, R, pi, gamma, epsilon)
+        pi = argmax_2d(Q)
+        if (pi != old_pi).sum() == 0:
+            return Q, V, pi
+    raise DynamicProgrammingMaxIterationExceeded()
+
+
+# ---- argmax with uniform random tie-break (reference dynamic_programming/utils.py:12-100) ----------------
+# The reference re-seeds *numba's* generator with 42 on every call; without numba the tie winner cannot be
+# reproduced (SURVEY 8c caveat 1).  Tie-free rows are exact; ties are broken by RandomState(42).choice,
+# which is what the reference computes when its njit decorators are the identity.
+def _pick(rs, row):
+    return rs.choice(np.where(row == row.max())[0])
+
+
+def argmax_2d(A):
+    rs = np.random.RandomState(ARGMAX_SEED)
+    X = np.zeros_like(A, np.float32)
+    for s in range(len(A)):
+        X[s, _pick(rs, A[s])] = 1
+    return X
+
+
+def argmax_3d(A):
+    rs = np.random.RandomState(ARGMAX_SEED)
+    X = np.zeros(A.shape, np.float32)
+    for h in range(len(A)):
+        for s in range(A.shape[1]):
+            X[h, s, _pick(rs, A[h, s])] = 1.0
+    return X
+
+
+def get_deterministic_policy_from_q_values(Q):
+    rs = np.random.RandomState(ARGMAX_SEED)
+    X = np.zeros(Q.shape[:-1], np.int32)
+    for s in range(len(Q)):
+        X[s] = np.int32(_pick(rs, Q[s]))
+    return X
+
+
+def get_deterministic_policy_from_q_values_finite_horizon(Q):
+    rs = np.random.RandomState(ARGMAX_SEED)
+    X = np.zeros(Q.shape[:-1], np.int32)
+    for h in range(len(Q)):
+        for s in range(Q.shape[1]):
+            X[h, s] = np.int32(_pick(rs, Q[h, s]))
+    return X
+
+
+def get_policy_from_q_values(Q, stochastic_form=False):
+    if Q.ndim == 3:
+        return argmax_3d(Q) if stochastic_form else get_deterministic_policy_from_q_values_finite_horizon(Q)
+    return argmax_2d(Q) if stochastic_form else get_deterministic_policy_from_q_values(Q)

@@ -1,0 +1,194 @@
+/* cmdp.h -- C ABI of libcmdp.so, the MI355X-native batched tabular-MDP engine.
+ *
+ * The reference (MichelangeloConserva/Colosseum, pure Python + numba) has no FFI of its own; the
+ * drop-in boundary is its Python call surface.  Every entry point below names the reference
+ * interface it replaces (paths relative to the reference tree).  The library is loaded with
+ * ctypes.CDLL by colosseum_amd/_lib.py; INTEGRATION.md shows the binding a reference maintainer
+ * would add.
+ *
+ * Conventions: plain C types only; every function returns 0 (CMDP_OK) or a negative error code and
+ * never throws; cmdp_last_error() gives the message of the calling thread's last failure; host
+ * buffers are borrowed for the duration of the call; a cmdp_t owns its device memory and one HIP
+ * stream, is bound to the device current at cmdp_create time, and is not thread-safe; calls are
+ * synchronous on return unless stated otherwise.
+ *
+ * Batch layout: B independent MDP instances (environment parameterisation x seed), instance b having
+ * S_b states and the common A actions.  state_off[b] = sum_{i<b} S_i.  "row" r of instance b is
+ * (state_off[b] + s) * A + a for the action a an agent passes to step().  All per-state arrays are
+ * the instances' arrays concatenated ([state_off[B]]), all per-row arrays likewise ([state_off[B]*A]).
+ */
+#ifndef CMDP_H
+#define CMDP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMDP_ABI_VERSION 1
+
+enum {
+  CMDP_OK = 0,
+  CMDP_ERR_INVALID = -1,     /* bad argument (message says which)                                  */
+  CMDP_ERR_HIP = -2,         /* a HIP runtime call failed                                           */
+  CMDP_ERR_NEEDS_RESET = -3, /* step() on an instance whose episode ended: the reference's
+                                `assert not self.necessary_reset`, colosseum/mdp/base.py:1290       */
+  CMDP_ERR_UNSUPPORTED = -4, /* feature outside the built scope                                     */
+  CMDP_ERR_MAX_ITER = -5,    /* DynamicProgrammingMaxIterationExceeded,
+                                colosseum/dynamic_programming/utils.py:8-9                          */
+  CMDP_ERR_NO_DEVICE = -6,   /* no HIP device visible                                               */
+  CMDP_ERR_MAX_VALUE = -7    /* |V| exceeded max_abs_value: the reference returns None,
+                                colosseum/dynamic_programming/infinite_horizon.py:136-138           */
+};
+
+/* Random-number discipline of the transition sampler. */
+enum {
+  /* One CPython MT19937 stream per stochastic (s,a) row and per stochastic start sampler, seeded
+     like random.Random(seed) and consumed one random() per sample: reproduces the reference's
+     NextStateSampler (colosseum/mdp/utils/custom_samplers.py:49-72) draw for draw. */
+  CMDP_RNG_MT_COMPAT = 0,
+  /* Philox-4x32-10 keyed by the instance, counter = the instance's transition count: one call per
+     transition yields the transition uniform, the random-policy action and the start-state uniform. */
+  CMDP_RNG_PHILOX = 1
+};
+
+/* Action source of cmdp_rollout. */
+enum {
+  CMDP_POLICY_RANDOM = 0,       /* uniform over A from the instance's Philox stream (config C2)      */
+  CMDP_POLICY_HOST_ACTIONS = 1, /* policy_arg = const int8_t actions[n_steps][B]                      */
+  CMDP_POLICY_GREEDY_Q = 2      /* policy_arg = const float Q[...]: first maximiser of Q[h? , s, :]   */
+};
+
+/* Sweep scheme of the discounted solvers. */
+enum {
+  CMDP_SCHEME_AUTO = 0,   /* the reference's own size/density rule,
+                             colosseum/dynamic_programming/infinite_horizon.py:25-36,53-64          */
+  CMDP_SCHEME_JACOBI = 1, /* _discounted_value_iteration_sparse / _discounted_policy_evaluation_sparse */
+  CMDP_SCHEME_GAUSS_SEIDEL = 2 /* _discounted_value_iteration / _discounted_policy_evaluation (numba) */
+};
+
+/* Device table layout of the transition sampler. */
+enum {
+  CMDP_LAYOUT_CSR = 0,   /* per-row successor lists (compact; the default)                           */
+  CMDP_LAYOUT_DENSE = 1  /* per-instance dense float32 P[s,a,:] rows streamed from HBM, wavefront
+                            prefix-sum CDF lookup (Philox mode only)                                  */
+};
+
+typedef struct cmdp cmdp_t;
+
+/* Model description handed to cmdp_create.  Either half may be absent (all its pointers NULL):
+ * the sampler half is what reset/step/rollout/visits need, the CSR half what the DP entry points
+ * need.  Replaces the tables the reference builds in BaseMDP.instantiate_MDP
+ * (colosseum/mdp/base.py:463-503) and get_transition_matrix_and_rewards
+ * (colosseum/mdp/utils/mdp_creation.py:41-95). */
+typedef struct cmdp_desc {
+  int32_t n_instances;       /* B >= 1                                                               */
+  int32_t n_actions;         /* A >= 1                                                               */
+  int32_t horizon;           /* H > 0: episodic (EpisodicMDP.H); 0: continuous                       */
+  int32_t rng_mode;          /* CMDP_RNG_*                                                           */
+  int32_t layout;            /* CMDP_LAYOUT_*                                                        */
+  int32_t reserved;
+  double reward_min;         /* BaseMDP.rewards_range, applied as r*(max-min) - min                  */
+  double reward_max;         /*   (sic, colosseum/mdp/base.py:1205-1207)                             */
+  const int64_t* state_off;  /* [B+1]                                                                */
+
+  /* --- sampler half: NextStateSampler tables in creation order, duplicates kept ---------------- */
+  const int64_t* sp_ptr;     /* [R+1] entry offsets, R = state_off[B]*A                              */
+  const int32_t* sp_next;    /* [E]   successor state index, local to the instance                   */
+  const double*  sp_cum;     /* [E]   itertools.accumulate(probs) within the row                     */
+  const double*  sp_reward;  /* [E]   reward of (s,a,s'): the deterministic value (loc)              */
+  const uint8_t* sp_rkind;   /* [E]   0 deterministic; anything else -> CMDP_ERR_UNSUPPORTED; NULL=0 */
+  const int32_t* sp_seed;    /* [R]   seed given to the row's NextStateSampler (MT_COMPAT)           */
+  const int64_t* start_off;  /* [B+1]                                                                */
+  const int32_t* start_state;/* [NS]  starting states, local index                                   */
+  const double*  start_cum;  /* [NS]  accumulated starting probabilities                             */
+  const int32_t* start_seed; /* [B]   seed of the start sampler (MT_COMPAT; ignored if one start)    */
+  const uint64_t* philox_key;/* [B]   per-instance Philox key (PHILOX)                               */
+
+  /* --- DP half: the non-zeros of the reference's dense float32 T[S,A,S], ascending column ------- */
+  const int64_t* csr_ptr;    /* [R+1]                                                                */
+  const int32_t* csr_col;    /* [N]   local successor index                                          */
+  const float*   csr_val;    /* [N]                                                                  */
+  const float*   R;          /* [R]   reward matrix R[s,a]                                           */
+} cmdp_desc;
+
+/* ---- library / device -------------------------------------------------------------------------- */
+int cmdp_version(void);
+const char* cmdp_last_error(void);
+int cmdp_device_count(void);
+int cmdp_set_device(int device);
+
+/* ---- life cycle ------------------------------------------------------------------------------------ */
+/* BaseMDP.__init__/instantiate_MDP (colosseum/mdp/base.py:327-503) for B instances at once. */
+int cmdp_create(cmdp_t** out, const cmdp_desc* desc);
+int cmdp_destroy(cmdp_t* h);
+/* Handle's HIP stream (a hipStream_t) so that a caller can time it with HIP events. */
+void* cmdp_stream(cmdp_t* h);
+
+/* ---- interaction: BaseMDP.reset / BaseMDP.step -------------------------------------------------- */
+/* BaseMDP.reset (colosseum/mdp/base.py:1268-1277) on every instance with mask[b] != 0 (all when mask
+   is NULL): h = 0, start state sampled, its state-visit count bumped.  obs_out[b] = start state index
+   (untouched where masked out); may be NULL. */
+int cmdp_reset(cmdp_t* h, const uint8_t* mask, int32_t* obs_out);
+
+/* BaseMDP.step(action, auto_reset) (colosseum/mdp/base.py:1279-1317) on every instance.
+   obs[b] = new state index, or -1 when the episode ended (h >= H); step_type: 0 FIRST (an auto-reset
+   happened instead of a transition; reward 0), 1 MID, 2 LAST.  With auto_reset == 0 an instance that
+   needs a reset makes the call fail with CMDP_ERR_NEEDS_RESET and nothing is modified. */
+int cmdp_step(cmdp_t* h, const int32_t* actions, int auto_reset,
+              int32_t* obs, double* reward, uint8_t* step_type);
+
+/* The body of MDPLoop.run's loop, env side, fused on the device
+   (colosseum/experiment/agent_mdp_interaction.py:238-298): n_steps transitions per instance, each
+   episodic termination followed at once by reset() (which is not counted as a step).  Instances must
+   have been reset.  last_obs[B], reward_sum[B] (sum of the n_steps rewards) and the three trace
+   arrays ([n_steps][B], obs = -1 on termination) may each be NULL. */
+int cmdp_rollout(cmdp_t* h, int policy, const void* policy_arg, int64_t n_steps,
+                 int32_t* last_obs, double* reward_sum,
+                 int32_t* trace_obs, double* trace_reward, uint8_t* trace_type);
+/* Same launch without the final synchronisation or any copy-back (for back-to-back timing). */
+int cmdp_rollout_async(cmdp_t* h, int policy, int64_t n_steps);
+int cmdp_synchronize(cmdp_t* h);
+
+/* BaseMDP.get_visitation_counts / reset_visitation_counts (colosseum/mdp/base.py:1357-1382).
+   state_counts [state_off[B]], sa_counts [state_off[B]*A]; either may be NULL. */
+int cmdp_visits(cmdp_t* h, int64_t* state_counts, int64_t* sa_counts);
+int cmdp_reset_visits(cmdp_t* h);
+/* Current state index, in-episode step and needs-reset flag of every instance (BaseMDP.cur_node,
+   .h, .necessary_reset); each may be NULL. */
+int cmdp_state(cmdp_t* h, int32_t* cur, int32_t* hstep, uint8_t* needs_reset);
+
+/* ---- dynamic programming ---------------------------------------------------------------------------- */
+/* discounted_value_iteration (colosseum/dynamic_programming/infinite_horizon.py:14-44,121-164).
+   R_override ([R] or NULL) replaces the reward matrix (e.g. -R for the worst policy).  Q [R], V
+   [state_off[B]], sweeps [B] (sweeps executed, including the converging one); sweeps may be NULL.
+   max_abs_value <= 0 disables the bound. */
+int cmdp_vi_discounted(cmdp_t* h, float gamma, double epsilon, int scheme, int64_t max_sweeps,
+                       double max_abs_value, const float* R_override,
+                       float* Q, float* V, int64_t* sweeps);
+/* discounted_policy_evaluation (infinite_horizon.py:47-64,167-205); pi [R] float32. */
+int cmdp_pe_discounted(cmdp_t* h, const float* pi, float gamma, double epsilon, int scheme,
+                       int64_t max_sweeps, const float* R_override,
+                       float* Q, float* V, int64_t* sweeps);
+/* episodic_value_iteration / episodic_policy_evaluation
+   (colosseum/dynamic_programming/finite_horizon.py:11-42).  Q of instance b is [H+1][S_b][A] at
+   offset (H+1)*state_off[b]*A, V is [H+1][S_b] at (H+1)*state_off[b]; pi is [H][S_b][A] at
+   H*state_off[b]*A. */
+int cmdp_vi_episodic(cmdp_t* h, int H, const float* R_override, float* Q, float* V);
+int cmdp_pe_episodic(cmdp_t* h, int H, const float* pi, const float* R_override, float* Q, float* V);
+
+/* ---- hardness measures --------------------------------------------------------------------------- */
+/* get_diameter, continuous setting (colosseum/hardness/measures/diameter.py:76-106): for every
+   target state es the optimal expected hitting time by value iteration with es absorbing, R = -1,
+   gamma = 1; diameter[b] = max over targets and start states.  per_target [state_off[B]] may be
+   NULL.  scheme as in cmdp_vi_discounted (AUTO = the rule applied to the instance's T). */
+int cmdp_diameter(cmdp_t* h, double epsilon, int scheme, int64_t max_sweeps,
+                  float* per_target, float* diameter);
+/* calculate_norm_discounted (colosseum/hardness/measures/value_norm.py:83-87). V [state_off[B]]. */
+int cmdp_value_norm(cmdp_t* h, const float* V, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMDP_H */

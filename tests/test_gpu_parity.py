@@ -1,0 +1,268 @@
+"""GPU parity tests: the HIP path (through the C ABI of libcmdp.so) against the reference's golden
+vectors and against the CPU oracle.  Integer results (states, step types, visit counts, sweep counts)
+bit-exact; float rewards bit-exact (deterministic values); value functions within 1e-6 relative
+(BASELINE.json north_star), and bit-exact against the oracle which shares the accumulation order."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from colosseum_amd import _lib as L
+from colosseum_amd.batched import BatchedMDP
+from colosseum_amd.mdp import make_model
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+VTOL = dict(rtol=1e-6, atol=1e-6)
+
+
+def _models(cases):
+    return [make_model(c["cls"], **c["kwargs"]) for c in cases]
+
+
+@pytest.mark.parametrize("name", ["G1_deepsea8", "G2_deepsea30"])
+def test_trajectories_vs_reference_batched(need_gpu, name):
+    """All golden DeepSea cases as ONE batch, driven by the stored action streams."""
+    z, cases = load_golden(name)
+    models = _models(cases)
+    env = BatchedMDP(models, rng_mode=L.RNG_MT_COMPAT, with_dp=False)
+    first = env.reset()
+    n = len(z["c0_actions"])
+    acts = np.stack([z[f"c{i}_actions"] for i in range(len(cases))], 1)
+    out = env.rollout(n, acts, trace=True)
+    vs, vsa = env.visits()
+    for i in range(len(cases)):
+        k = f"c{i}_"
+        assert first[i] == z[k + "resets"][0]
+        np.testing.assert_array_equal(out["obs"][:, i], z[k + "obs"].astype(np.int32))
+        np.testing.assert_array_equal(out["rew"][:, i], z[k + "rew"])
+        np.testing.assert_array_equal(out["stype"][:, i], z[k + "stype"])
+        np.testing.assert_array_equal(env.split_states(vs)[i], z[k + "visits_s"])
+        np.testing.assert_array_equal(env.split_rows(vsa)[i].reshape(-1, env.A), z[k + "visits_sa"])
+        assert out["reward_sum"][i] == pytest.approx(float(np.sum(z[k + "rew"])), abs=1e-9)
+    env.close()
+
+
+def test_trajectories_stochastic_mt_compat(need_gpu):
+    """Stochastic dynamics: per-(s,a) MT19937 streams on the device reproduce the reference draw for draw
+    (12 000 steps, crossing the reference's 5000-sample refills).  Ragged: one handle per case."""
+    z, cases = load_golden("G3_stochastic")
+    for i, c in enumerate(cases):
+        k = f"c{i}_"
+        m = make_model(c["cls"], **c["kwargs"])
+        env = BatchedMDP([m], rng_mode=L.RNG_MT_COMPAT, with_dp=False)
+        first = env.reset()
+        acts = z[k + "actions"][:, None]
+        out = env.rollout(len(acts), acts, trace=True)
+        vs, vsa = env.visits()
+        assert first[0] == z[k + "resets"][0], c
+        np.testing.assert_array_equal(out["obs"][:, 0], z[k + "obs"], err_msg=str(c))
+        np.testing.assert_array_equal(out["rew"][:, 0], z[k + "rew"])
+        np.testing.assert_array_equal(out["stype"][:, 0], z[k + "stype"])
+        np.testing.assert_array_equal(vs, z[k + "visits_s"])
+        np.testing.assert_array_equal(vsa.reshape(-1, env.A), z[k + "visits_sa"])
+        env.close()
+
+
+def test_step_api_matches_rollout_and_reference(need_gpu):
+    """cmdp_step one call per transition (BaseMDP.step semantics incl. the needs-reset assert)."""
+    z, cases = load_golden("G1_deepsea8")
+    models = _models(cases)
+    env = BatchedMDP(models, with_dp=False)
+    with pytest.raises(AssertionError):
+        env.step(np.zeros(env.B, np.int32))  # reset pending
+    obs = env.reset()
+    n = 300
+    resets = [1] * env.B
+    for t in range(n):
+        a = np.array([z[f"c{i}_actions"][t] for i in range(env.B)], np.int32)
+        o, r, ty = env.step(a)
+        for i in range(env.B):
+            k = f"c{i}_"
+            assert o[i] == z[k + "obs"][t] and r[i] == z[k + "rew"][t] and ty[i] == z[k + "stype"][t]
+        if (ty == 2).any():
+            assert (ty == 2).all()  # same horizon
+            with pytest.raises(AssertionError):
+                env.step(a)
+            o2 = env.reset()
+            for i in range(env.B):
+                assert o2[i] == z[f"c{i}_resets"][resets[i]]
+                resets[i] += 1
+    with pytest.raises(L.CmdpError):
+        env.step(np.full(env.B, 7, np.int32))  # action out of range
+    env.close()
+
+
+def test_step_auto_reset(need_gpu):
+    z, cases = load_golden("G1_deepsea8")
+    m = make_model(cases[0]["cls"], **cases[0]["kwargs"])
+    env = BatchedMDP([m], with_dp=False)
+    o, r, ty = env.step([0], auto_reset=True)  # behaves as reset()
+    assert ty[0] == 0 and r[0] == 0.0 and o[0] == m.start_states[0]
+    for t in range(m.H):
+        o, r, ty = env.step([0], auto_reset=True)
+    assert ty[0] == 2 and o[0] == -1
+    o, r, ty = env.step([1], auto_reset=True)
+    assert ty[0] == 0 and o[0] == m.start_states[0]
+    env.close()
+
+
+def test_philox_rollout_vs_oracle(need_gpu):
+    """Throughput mode: GPU and CPU oracle share the Philox streams -> bit-exact states/visits/rewards,
+    on-device random policy, deterministic (DeepSea) and stochastic (FrozenLake, MiniGrid) dynamics."""
+    specs = [("DeepSeaEpisodic", dict(seed=s, size=30)) for s in range(6)]
+    models = [make_model(c, **k) for c, k in specs]
+    keys = np.array([0x9E3779B97F4A7C15 ^ (i * 0x1000003) for i in range(len(models))], np.uint64)
+    env = BatchedMDP(models, rng_mode=L.RNG_PHILOX, philox_keys=keys, with_dp=False)
+    env.reset()
+    out = env.rollout(5000, None, trace=True)
+    out2 = env.rollout(777, None, trace=False)  # counters persist across launches
+    vs, vsa = env.visits()
+    for i, m in enumerate(models):
+        e = O.OracleEnv(m, rng_mode=1, philox_key=int(keys[i]))
+        e.reset()
+        ref = e.rollout(5000)
+        ref2 = e.rollout(777, trace=False)
+        np.testing.assert_array_equal(out["obs"][:, i], ref["obs"])
+        np.testing.assert_array_equal(out["rew"][:, i], ref["rew"])
+        np.testing.assert_array_equal(out["stype"][:, i], ref["stype"])
+        assert out["reward_sum"][i] == ref["reward_sum"] and out2["reward_sum"][i] == ref2["reward_sum"]
+        assert out2["last_obs"][i] == ref2["last_obs"]
+        rvs, rvsa = e.visits()
+        np.testing.assert_array_equal(env.split_states(vs)[i], rvs)
+        np.testing.assert_array_equal(env.split_rows(vsa)[i].reshape(-1, 2), rvsa)
+    env.close()
+    for cls, kw in [("FrozenLakeContinuous", dict(seed=3, size=12, p_frozen=0.9, p_rand=0.1)),
+                    ("MiniGridEmptyEpisodic", dict(seed=1, size=6, p_rand=0.2, n_starting_states=3)),
+                    ("MiniGridRoomsContinuous", dict(seed=2, room_size=3, n_rooms=4, p_lazy=0.2, n_starting_states=2))]:
+        m = make_model(cls, **kw)
+        env = BatchedMDP([m, m], rng_mode=L.RNG_PHILOX, philox_keys=[11, 12], with_dp=False)
+        env.reset()
+        out = env.rollout(4000, None, trace=True)
+        vs, vsa = env.visits()
+        for i in range(2):
+            e = O.OracleEnv(m, rng_mode=1, philox_key=11 + i)
+            e.reset()
+            ref = e.rollout(4000)
+            np.testing.assert_array_equal(out["obs"][:, i], ref["obs"], err_msg=cls)
+            np.testing.assert_array_equal(out["rew"][:, i], ref["rew"])
+            rvs, rvsa = e.visits()
+            np.testing.assert_array_equal(env.split_states(vs)[i], rvs)
+        assert not np.array_equal(out["obs"][:, 0], out["obs"][:, 1])
+        env.close()
+
+
+def test_vi_frozenlake20_vs_reference(need_gpu):
+    """Config C3 slice: FrozenLake 20x20 discounted VI; Jacobi (the scheme the reference's rule selects)
+    bit-exact incl. sweep counts; Gauss-Seidel within tolerance (the reference's BLAS summation order is
+    not reproducible), bit-exact against the oracle."""
+    z, cases = load_golden("G4_frozenlake20_vi")
+    models = _models(cases)
+    dp = BatchedMDP(models, with_env=False)
+    for eps, tag in ((1e-3, "e3"), (1e-6, "e6")):
+        Q, V, sw = dp.value_iteration(0.99, eps, L.SCHEME_AUTO)
+        Qg, Vg, swg = dp.value_iteration(0.99, eps, L.SCHEME_GAUSS_SEIDEL)
+        for i, c in enumerate(cases):
+            k = f"c{i}_"
+            assert c["reference_rule_selects"] == "jacobi"
+            np.testing.assert_array_equal(dp.split_states(V)[i], z[k + f"jac_{tag}_V"])
+            np.testing.assert_array_equal(dp.split_rows(Q)[i].reshape(-1, 4), z[k + f"jac_{tag}_Q"])
+            np.testing.assert_array_equal(dp.split_states(V)[i], z[k + f"disp_{tag}_V"])
+            assert sw[i] == c[f"jac_{tag}_sweeps"]
+            np.testing.assert_allclose(dp.split_states(Vg)[i], z[k + f"gs_{tag}_V"], rtol=2e-6, atol=2e-6)
+            np.testing.assert_allclose(dp.split_rows(Qg)[i].reshape(-1, 4), z[k + f"gs_{tag}_Q"], rtol=2e-6, atol=2e-6)
+            assert abs(int(swg[i]) - c[f"gs_{tag}_sweeps"]) <= 1
+            m = models[i]
+            oQ, oV, oit, _ = O.vi_discounted(m.n_states, 4, m.csr(), m.reward_matrix(), 0.99, eps, 2)
+            np.testing.assert_array_equal(dp.split_states(Vg)[i], oV)
+            np.testing.assert_array_equal(dp.split_rows(Qg)[i].reshape(-1, 4), oQ)
+            assert swg[i] == oit
+    pis = [np.ones((m.n_states, 4), np.float32) / 4 for m in models]
+    Q, V, sw = dp.policy_evaluation(pis, 0.99, 1e-5, L.SCHEME_JACOBI)
+    Qg, Vg, swg = dp.policy_evaluation(pis, 0.99, 1e-5, L.SCHEME_GAUSS_SEIDEL)
+    for i, c in enumerate(cases):
+        k = f"c{i}_"
+        np.testing.assert_array_equal(dp.split_states(V)[i], z[k + "pe_jac_V"])
+        np.testing.assert_array_equal(dp.split_rows(Q)[i].reshape(-1, 4), z[k + "pe_jac_Q"])
+        assert sw[i] == c["pe_jac_sweeps"]
+        np.testing.assert_allclose(dp.split_states(Vg)[i], z[k + "pe_gs_V"], **VTOL)
+        assert abs(int(swg[i]) - c["pe_gs_sweeps"]) <= 1
+    dp.close()
+
+
+def test_episodic_dp_vs_reference(need_gpu):
+    for name in ("G1_deepsea8", "G3_stochastic"):
+        z, cases = load_golden(name)
+        for i, c in enumerate(cases):
+            k = f"c{i}_"
+            if k + "Q_opt" not in z:
+                continue
+            m = make_model(c["cls"], **c["kwargs"])
+            S, A, H = m.n_states, m.n_actions, m.H
+            dp = BatchedMDP([m, m], with_env=False)
+            Q, V = dp.episodic_value_iteration()
+            Qw, Vw = dp.episodic_value_iteration(R=[-m.reward_matrix()] * 2)
+            pi = np.ones((H, S, A), np.float32) / A
+            Qr, Vr = dp.episodic_policy_evaluation([pi, pi])
+            for b in range(2):
+                np.testing.assert_allclose(dp.split_rows(Q, H + 1)[b].reshape(H + 1, S, A), z[k + "Q_opt"], **VTOL)
+                np.testing.assert_allclose(dp.split_states(V, H + 1)[b].reshape(H + 1, S), z[k + "V_opt"], **VTOL)
+                np.testing.assert_allclose(dp.split_rows(Qw, H + 1)[b].reshape(H + 1, S, A), z[k + "Q_worst"], **VTOL)
+                np.testing.assert_allclose(dp.split_rows(Qr, H + 1)[b].reshape(H + 1, S, A), z[k + "Q_rand"], **VTOL)
+                np.testing.assert_allclose(dp.split_states(Vr, H + 1)[b].reshape(H + 1, S), z[k + "V_rand"], **VTOL)
+            oQ, oV = O.episodic(S, A, H, m.csr(), m.reward_matrix())
+            np.testing.assert_array_equal(dp.split_rows(Q, H + 1)[0].reshape(H + 1, S, A), oQ)
+            oQr, oVr = O.episodic(S, A, H, m.csr(), m.reward_matrix(), pi)
+            np.testing.assert_array_equal(dp.split_states(Vr, H + 1)[1].reshape(H + 1, S), oVr)
+            dp.close()
+
+
+def test_drop_in_dp_functions(need_gpu):
+    """The reference's free-function signatures on dense T, R."""
+    from colosseum_amd import dynamic_programming as dpf
+
+    z, cases = load_golden("G4_frozenlake20_vi")
+    m = make_model(cases[0]["cls"], **cases[0]["kwargs"])
+    T, R = m.dense()
+    Q, V = dpf.discounted_value_iteration(T, R, 0.99, 1e-6)
+    np.testing.assert_array_equal(V, z["c0_disp_e6_V"])
+    assert dpf.discounted_value_iteration(T, R, 0.99, 1e-6, max_abs_value=0.5) is None
+    with pytest.raises(dpf.DynamicProgrammingMaxIterationExceeded):
+        from colosseum_amd.dp_handle import DPBatch, csr_from_dense
+
+        with DPBatch([(m.n_states, 4, csr_from_dense(T), R)]) as h:
+            h.value_iteration(0.99, 1e-9, L.SCHEME_JACOBI, 5)
+    z1, c1 = load_golden("G1_deepsea8")
+    m = make_model(c1[0]["cls"], **c1[0]["kwargs"])
+    T, R = m.dense()
+    Q, V = dpf.episodic_value_iteration(m.H, T, R)
+    np.testing.assert_array_equal(Q, z1["c0_Q_opt"])
+    pol = dpf.get_policy_from_q_values(Q[: m.H], True)
+    Qp, Vp = dpf.episodic_policy_evaluation(m.H, T, R, pol)
+    np.testing.assert_allclose(Vp[0, m.start_states[0]], V[0, m.start_states[0]], **VTOL)
+
+
+def test_diameter_and_value_norm(need_gpu):
+    import json
+    import os
+
+    from conftest import GOLDEN
+
+    rows = json.load(open(os.path.join(GOLDEN, "G6_hardness_ref.json")))
+    for row in rows:
+        if "Episodic" in row["cls"]:
+            continue
+        m = make_model(row["cls"], **row["kwargs"])
+        dp = BatchedMDP([m], with_env=False)
+        diam, per = dp.diameter()
+        od, oper = O.diameter_continuous(m.n_states, m.n_actions, m.csr())
+        np.testing.assert_array_equal(per, oper)
+        assert diam[0] == od
+        # G-S path, eps = 1e-3: the reference's BLAS summation order can move the stopping sweep by one, i.e.
+        # the hitting times by up to ~eps -> absolute tolerance 2*eps; GPU == oracle exactly (above)
+        assert diam[0] == pytest.approx(row["diameter"], abs=2e-3), row
+        Q, V, _ = dp.value_iteration(0.99, 1e-3)
+        vn = dp.value_norm(V)
+        assert vn[0] == pytest.approx(row["value_norm"], rel=5e-6, abs=1e-6), row
+        assert vn[0] == O.value_norm(m.n_states, m.n_actions, m.csr(), V)
+        dp.close()
