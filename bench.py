@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline measurement (BASELINE.json: env steps/s on 65 536 parallel DeepSea(size=30)
+instances, random policy + value-iteration sweeps/s), one rank per GPU.
+
+    python bench.py --gpus 1 --steps 30 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is one fused rollout launch: `--launch-steps` (default 1000) transitions of every instance of the
+rank's shard (default 65 536 instances per GPU -> weak scaling), inputs resident in HBM.  K timed steps are
+bracketed by barrier + device synchronise on both sides, the max over ranks is taken, rank 0 prints ONE JSON
+line.  `value` = transitions of all ranks / that time.
+
+Extra objects on the line (prompt section 4):
+  roofline      dominant kernel (k_rollout): algorithmic bytes per launch / HIP-event launch time vs 8 TB/s
+  cpu_baseline  the CPU oracle (oracle/cmdp_oracle.c, "port") timed on this host, one core, bounded sample
+  vi            config C3: FrozenLake 20x20 discounted value iteration to 1e-6, sweeps/s (secondary metric)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+class HipEvents:
+    """Minimal ctypes view of the HIP event API (libamdhip64 is already mapped by libcmdp.so)."""
+
+    def __init__(self):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        self.hip.hipEventSynchronize.argtypes = [C.c_void_p]
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self.hip.hipEventDestroy.argtypes = [C.c_void_p]
+
+    def create(self):
+        ev = C.c_void_p()
+        assert self.hip.hipEventCreate(C.byref(ev)) == 0
+        return ev
+
+    def record(self, ev, stream):
+        assert self.hip.hipEventRecord(ev, C.c_void_p(stream)) == 0
+
+    def elapsed_ms(self, a, b):
+        assert self.hip.hipEventSynchronize(b) == 0
+        ms = C.c_float()
+        assert self.hip.hipEventElapsedTime(C.byref(ms), a, b) == 0
+        return float(ms.value)
+
+
+def _build_fl(args):
+    from colosseum_amd.mdp import make_model
+
+    seed, size = args
+    m = make_model("FrozenLakeContinuous", seed=seed, size=size, p_frozen=0.9, is_slippery=True, p_rand=0.1)
+    ptr, col, val = m.csr()
+    return m.n_states, ptr, col, val, m.reward_matrix().ravel()
+
+
+def frozenlake_dp_tables(seeds, size, workers):
+    """DP half of the tables for FrozenLakeContinuous(seed, size, p_frozen=0.9, is_slippery=True, p_rand=0.1)
+    (config C3), built by a process pool (the builder is host Python)."""
+    import multiprocessing as mp
+
+    jobs = [(int(s), size) for s in seeds]
+    if workers > 1:
+        with mp.get_context("fork").Pool(workers) as pool:
+            res = pool.map(_build_fl, jobs, chunksize=max(1, len(jobs) // (workers * 8)))
+    else:
+        res = [_build_fl(j) for j in jobs]
+    S = np.array([r[0] for r in res], np.int64)
+    nz = np.array([len(r[2]) for r in res], np.int64)
+    nz_off = np.concatenate([[0], np.cumsum(nz)])
+    return dict(
+        B=len(res), A=4, H=0, rewards_range=(0.0, 1.0),
+        state_off=np.concatenate([[0], np.cumsum(S)]).astype(np.int64),
+        csr_ptr=np.concatenate([r[1][:-1].astype(np.int64) + nz_off[i] for i, r in enumerate(res)] + [nz_off[-1:]]),
+        csr_col=np.concatenate([r[2] for r in res]),
+        csr_val=np.concatenate([r[3] for r in res]),
+        R=np.concatenate([r[4] for r in res]),
+    )
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--instances", type=int, default=65536, help="instances per GPU (weak scaling)")
+    ap.add_argument("--size", type=int, default=30)
+    ap.add_argument("--launch-steps", type=int, default=1000, help="transitions per instance per launch")
+    ap.add_argument("--vi-instances", type=int, default=4096, help="FrozenLake instances per GPU for the VI leg (0: skip)")
+    ap.add_argument("--cpu-instances", type=int, default=16384, help="instances of the CPU-oracle sample (0: skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+
+    from colosseum_amd import _lib as L
+    from colosseum_amd.batched import BatchedMDP
+    from colosseum_amd.mdp.fast_batch import deepsea_episodic_tables
+
+    lib = L.load()
+    assert lib.cmdp_device_count() > 0, "no HIP device visible: the product path has no CPU fallback"
+    L.check(lib.cmdp_set_device(local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # ---- C2 workload: this rank's shard of DeepSeaEpisodic(seed=i, size=30), i in [rank*B, (rank+1)*B) ----
+    B = args.instances
+    seeds = np.arange(rank * B, (rank + 1) * B, dtype=np.int64)
+    t_build = time.time()
+    tables = deepsea_episodic_tables(seeds, args.size)
+    keys = seeds.astype(np.uint64)  # Philox key = global instance id
+    env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX, philox_keys=keys)
+    env.reset()
+    t_build = time.time() - t_build
+    S = int(env.n_states[0])
+
+    ev = HipEvents()
+    stream = env.stream
+    for _ in range(args.warmup):
+        env.rollout_async(args.launch_steps)
+    env.synchronize()
+    marks = [ev.create() for _ in range(args.steps + 1)]
+    barrier()
+    env.synchronize()
+    t0 = time.perf_counter()
+    ev.record(marks[0], stream)
+    for k in range(args.steps):
+        env.rollout_async(args.launch_steps)
+        ev.record(marks[k + 1], stream)
+    env.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    launch_ms = [ev.elapsed_ms(marks[k], marks[k + 1]) for k in range(args.steps)]
+
+    if dist is not None:
+        import torch
+
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- final gather over RCCL (the only collective): per-instance episode counts = visits of the start state ----
+    vs, _ = env.visits(sa=False)
+    start = int(tables["start_state"][0])
+    episodes = vs.reshape(B, S)[:, start].copy()
+    gather_ms = None
+    if dist is not None:
+        import torch
+
+        local = torch.from_numpy(episodes).cuda()
+        allv = torch.empty(world * B, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        dist.all_gather_into_tensor(allv, local)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        assert bool((allv[rank * B:(rank + 1) * B] == local).all())
+
+    total_steps = world * B * args.launch_steps * args.steps
+    value = total_steps / elapsed
+    avg_launch_s = float(np.mean(launch_ms)) * 1e-3
+    # SURVEY 8(d), CSR companion figure: 8 (row pointer pair) + 8*nnz(s,a) + 28 B per transition = 44 B at C2
+    bytes_per_step = 8 + 8 * 1 + 28
+    algo_bytes = bytes_per_step * B * args.launch_steps
+    achieved = algo_bytes / avg_launch_s / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_rollout_pmc.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": "env steps/sec (whole node), DeepSea size=%d x %d instances/GPU, random policy" % (args.size, B),
+        "value": value,
+        "unit": "env steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "i32 state/visit indices, f64 rewards+CDF",
+        "data": "synthetic",
+        "config": {
+            "workload": "C2: DeepSeaEpisodic(seed=i,size=%d), %d instances per GPU, on-device uniform random policy "
+                        "(Philox-4x32-10), %d transitions per instance per step, auto-reset at h>=H" % (args.size, B, args.launch_steps),
+            "instances_per_gpu": B, "states": S, "actions": 2, "horizon": int(env.H),
+            "transitions_per_instance_per_step": args.launch_steps, "layout": "csr", "rng": "philox4x32-10",
+            "build_s": round(t_build, 2),
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "k_rollout<0,false>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes_per_transition": bytes_per_step, "accounting": "SURVEY 8(d) CSR figure (44 B/transition)",
+            "launch_ms_avg": avg_launch_s * 1e3, "launch_ms_min": float(np.min(launch_ms)),
+        },
+    }
+    if gather_ms is not None:
+        line["gather_ms"] = gather_ms
+
+    # ---- VI leg (config C3): FrozenLake 20x20, gamma .99, eps 1e-6, the reference's own scheme rule --------
+    if args.vi_instances > 0:
+        workers = max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
+        tb = time.time()
+        fl = frozenlake_dp_tables(np.arange(rank * args.vi_instances, (rank + 1) * args.vi_instances), 20, workers)
+        dp = BatchedMDP(tables=fl, with_env=False)
+        tb = time.time() - tb
+        dp.value_iteration(0.99, 1e-6)  # warm-up (also sizes the device buffers)
+        barrier()
+        t1 = time.perf_counter()
+        Q, V, sw = dp.value_iteration(0.99, 1e-6)
+        barrier()
+        vi_s = time.perf_counter() - t1
+        sweeps = float(sw.sum())
+        if dist is not None:
+            import torch
+
+            tt = torch.tensor([vi_s, -sweeps], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            vi_s = float(tt[0].item())
+            ts = torch.tensor([sweeps], dtype=torch.float64, device="cuda")
+            dist.all_reduce(ts)
+            sweeps = float(ts.item())
+        line["vi"] = {
+            "workload": "C3: FrozenLakeContinuous(seed=i,size=20,p_frozen=0.9,is_slippery=True,p_rand=0.1), %d instances "
+                        "per GPU, discounted VI gamma=0.99 eps=1e-6, scheme by the reference rule (Jacobi)" % args.vi_instances,
+            "sweeps_per_s": sweeps / vi_s, "instances_per_s": world * args.vi_instances / vi_s, "total_sweeps": sweeps,
+            "wall_ms": vi_s * 1e3, "includes": "H2D of nothing, D2H of Q,V,sweeps", "build_s": round(tb, 2),
+        }
+        dp.close()
+
+    # ---- CPU baseline: the oracle, one core, bounded sample of the same workload (rank 0, N = 1 only) -----
+    if rank == 0 and world == 1 and not args.no_cpu and args.cpu_instances > 0:
+        from oracle import oracle as O
+
+        n = min(args.cpu_instances, B)
+        n_steps = args.launch_steps * (args.steps + args.warmup)  # everything the GPU did since reset()
+        c0 = time.perf_counter()
+        last, rsum, cvs, _ = O.batch_rollout(tables, 0, n, n_steps, rng_mode=1, philox_keys=keys, want_visits=True)
+        cpu_s = time.perf_counter() - c0
+        # the timed GPU work is checked, not just timed: state-visit counts of the sampled instances are bit-equal
+        verified = bool(np.array_equal(cvs, vs[: n * S]))
+        assert verified, "GPU visit counts differ from the CPU oracle"
+        line["verified_against_oracle"] = "state-visit counts of instances 0..%d after %d transitions: bit-equal" % (n - 1, n_steps)
+        line["cpu_baseline"] = {
+            "value": n * n_steps / cpu_s, "unit": "env steps/s", "cores": 1, "kind": "port",
+            "sample": "instances 0..%d of the same batch, %d transitions each (same Philox streams), reset included; "
+                      "%.1f s on 1 of %d host cores" % (n - 1, n_steps, cpu_s, os.cpu_count() or 0),
+        }
+        if "vi" in line and args.vi_instances > 0:
+            nv = min(256, args.vi_instances)
+            c0 = time.perf_counter()
+            _, _, swc = O.batch_vi(fl, 0, nv, 0.99, 1e-6, 0)
+            cv = time.perf_counter() - c0
+            line["vi"]["cpu_baseline"] = {"value": float(swc.sum()) / cv, "unit": "sweeps/s", "cores": 1, "kind": "port",
+                                          "sample": "instances 0..%d, %.1f s" % (nv - 1, cv)}
+    env.close()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,60 +12,85 @@ from . import _lib as L
 from .mdp.builder import TabularModel
 
 
+_ENV_FIELDS = (("sp_ptr", np.int64), ("sp_next", np.int32), ("sp_cum", np.float64), ("sp_reward", np.float64),
+               ("sp_rkind", np.uint8), ("sp_seed", np.int32), ("start_off", np.int64), ("start_state", np.int32),
+               ("start_cum", np.float64), ("start_seed", np.int32))
+_DP_FIELDS = (("csr_ptr", np.int64), ("csr_col", np.int32), ("csr_val", np.float32), ("R", np.float32))
+
+
+def tables_from_models(models: Sequence[TabularModel], with_env: bool = True, with_dp: bool = True) -> dict:
+    """Concatenates per-instance TabularModels into the flat arrays of `cmdp_desc` (include/cmdp.h)."""
+    A, H = models[0].n_actions, models[0].H
+    rr = tuple(models[0].rewards_range)
+    for m in models:
+        if m.n_actions != A or m.H != H or tuple(m.rewards_range) != rr:
+            raise ValueError("all instances of a batch share n_actions, the horizon H and the rewards range")
+    n_states = np.array([m.n_states for m in models], np.int64)
+    t = dict(B=len(models), A=A, H=H, rewards_range=rr,
+             state_off=np.concatenate([[0], np.cumsum(n_states)]).astype(np.int64))
+    if with_env:
+        ent = np.array([len(m.sp_next) for m in models], np.int64)
+        ent_off = np.concatenate([[0], np.cumsum(ent)])
+        t["sp_ptr"] = np.concatenate([m.sp_ptr[:-1] + ent_off[i] for i, m in enumerate(models)] + [ent_off[-1:]])
+        t["sp_next"] = np.concatenate([m.sp_next for m in models])
+        t["sp_cum"] = np.concatenate([m.sp_cum for m in models])
+        t["sp_reward"] = np.concatenate([m.sp_rp0 for m in models])
+        t["sp_rkind"] = np.concatenate([m.sp_rkind for m in models])
+        t["sp_seed"] = np.concatenate([m.sp_seed for m in models])
+        ns = np.array([len(m.start_states) for m in models], np.int64)
+        t["start_off"] = np.concatenate([[0], np.cumsum(ns)])
+        t["start_state"] = np.concatenate([m.start_states for m in models])
+        # itertools.accumulate == sequential float64 adds == np.cumsum
+        t["start_cum"] = np.concatenate([np.cumsum(m.start_probs) for m in models])
+        t["start_seed"] = np.array([max(m.start_seed, 0) for m in models], np.int32)
+    if with_dp:
+        csrs = [m.csr() for m in models]
+        nz = np.array([len(c[1]) for c in csrs], np.int64)
+        nz_off = np.concatenate([[0], np.cumsum(nz)])
+        t["csr_ptr"] = np.concatenate([c[0][:-1].astype(np.int64) + nz_off[i] for i, c in enumerate(csrs)]
+                                      + [nz_off[-1:]])
+        t["csr_col"] = np.concatenate([c[1] for c in csrs])
+        t["csr_val"] = np.concatenate([c[2] for c in csrs])
+        t["R"] = np.concatenate([m.reward_matrix().ravel() for m in models])
+    return t
+
+
 class BatchedMDP:
-    def __init__(self, models: Sequence[TabularModel], rng_mode: int = L.RNG_MT_COMPAT,
-                 philox_keys: Optional[Sequence[int]] = None, with_env: bool = True, with_dp: bool = True):
+    def __init__(self, models: Optional[Sequence[TabularModel]] = None, rng_mode: int = L.RNG_MT_COMPAT,
+                 philox_keys: Optional[Sequence[int]] = None, with_env: bool = True, with_dp: bool = True,
+                 tables: Optional[dict] = None):
+        """Either `models` (TabularModel per instance) or pre-concatenated `tables` (see `tables_from_models`
+        and colosseum_amd.mdp.fast_batch) describe the batch."""
         lib = L.load()
-        models = list(models)
-        assert len(models) > 0
-        A, H = models[0].n_actions, models[0].H
-        rr = models[0].rewards_range
-        for m in models:
-            if m.n_actions != A or m.H != H or tuple(m.rewards_range) != tuple(rr):
-                raise ValueError("all instances of a batch share n_actions, the horizon H and the rewards range")
+        if tables is None:
+            models = list(models)
+            assert len(models) > 0
+            tables = tables_from_models(models, with_env, with_dp)
         self.models = models
-        self.B, self.A, self.H = len(models), A, H
-        self.n_states = np.array([m.n_states for m in models], np.int64)
-        self.state_off = np.concatenate([[0], np.cumsum(self.n_states)]).astype(np.int64)
+        self.B, self.A, self.H = int(tables["B"]), int(tables["A"]), int(tables["H"])
+        A = self.A
+        rr = tables["rewards_range"]
+        self.state_off = np.ascontiguousarray(tables["state_off"], np.int64)
+        self.n_states = np.diff(self.state_off)
         self.row_off = self.state_off * A
         self.rng_mode = rng_mode
         keep = {}
         d = L.CmdpDesc()
-        d.n_instances, d.n_actions, d.horizon, d.rng_mode, d.layout = self.B, A, H, rng_mode, L.LAYOUT_CSR
+        d.n_instances, d.n_actions, d.horizon, d.rng_mode, d.layout = self.B, A, self.H, rng_mode, L.LAYOUT_CSR
         d.reward_min, d.reward_max = float(rr[0]), float(rr[1])
         keep["state_off"] = self.state_off
-        if with_env:
-            ent = np.array([len(m.sp_next) for m in models], np.int64)
-            ent_off = np.concatenate([[0], np.cumsum(ent)])
-            keep["sp_ptr"] = np.concatenate(
-                [m.sp_ptr[:-1] + ent_off[i] for i, m in enumerate(models)] + [ent_off[-1:]]).astype(np.int64)
-            keep["sp_next"] = np.concatenate([m.sp_next for m in models]).astype(np.int32)
-            keep["sp_cum"] = np.concatenate([m.sp_cum for m in models]).astype(np.float64)
-            keep["sp_reward"] = np.concatenate([m.sp_rp0 for m in models]).astype(np.float64)
-            keep["sp_rkind"] = np.concatenate([m.sp_rkind for m in models]).astype(np.uint8)
-            keep["sp_seed"] = np.concatenate([m.sp_seed for m in models]).astype(np.int32)
-            ns = np.array([len(m.start_states) for m in models], np.int64)
-            keep["start_off"] = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
-            keep["start_state"] = np.concatenate([m.start_states for m in models]).astype(np.int32)
-            # itertools.accumulate == sequential float64 adds == np.cumsum
-            keep["start_cum"] = np.concatenate([np.cumsum(m.start_probs) for m in models]).astype(np.float64)
-            keep["start_seed"] = np.array([max(m.start_seed, 0) for m in models], np.int32)
+        if "sp_ptr" in tables:
+            for k, dt in _ENV_FIELDS:
+                keep[k] = np.ascontiguousarray(tables[k], dt)
             if philox_keys is None:
                 philox_keys = np.arange(self.B, dtype=np.uint64)
             keep["philox_key"] = np.ascontiguousarray(philox_keys, np.uint64)
             assert len(keep["philox_key"]) == self.B
-        if with_dp:
-            csrs = [m.csr() for m in models]
-            nz = np.array([len(c[1]) for c in csrs], np.int64)
-            nz_off = np.concatenate([[0], np.cumsum(nz)])
-            keep["csr_ptr"] = np.concatenate(
-                [c[0][:-1].astype(np.int64) + nz_off[i] for i, c in enumerate(csrs)] + [nz_off[-1:]]).astype(np.int64)
-            keep["csr_col"] = np.concatenate([c[1] for c in csrs]).astype(np.int32)
-            keep["csr_val"] = np.concatenate([c[2] for c in csrs]).astype(np.float32)
-            keep["R"] = np.concatenate([m.reward_matrix().ravel() for m in models]).astype(np.float32)
+        if "csr_ptr" in tables:
+            for k, dt in _DP_FIELDS:
+                keep[k] = np.ascontiguousarray(tables[k], dt)
         for k, v in keep.items():
-            keep[k] = np.ascontiguousarray(v)
-            setattr(d, k, L.ptr(keep[k]))
+            setattr(d, k, L.ptr(v))
         self._keep = keep
         self._h = C.c_void_p()
         L.check(lib.cmdp_create(C.byref(self._h), C.byref(d)))
@@ -130,10 +155,10 @@ class BatchedMDP:
     def stream(self) -> int:
         return int(self._lib.cmdp_stream(self._h) or 0)
 
-    def visits(self):
+    def visits(self, state: bool = True, sa: bool = True):
         """(state counts [sum S], state-action counts [sum S*A]); split with `split_states`/`split_rows`."""
-        vs = np.zeros(int(self.state_off[-1]), np.int64)
-        vsa = np.zeros(int(self.row_off[-1]), np.int64)
+        vs = np.zeros(int(self.state_off[-1]), np.int64) if state else None
+        vsa = np.zeros(int(self.row_off[-1]), np.int64) if sa else None
         L.check(self._lib.cmdp_visits(self._h, L.ptr(vs), L.ptr(vsa)))
         return vs, vsa
 

@@ -58,6 +58,12 @@ def lib():
                                                  C.c_int64, C.c_void_p, C.c_void_p]
         L.oracle_value_norm.restype = C.c_float
         L.oracle_value_norm.argtypes = [C.c_int, C.c_int, _i64p, _i32p, _f32p, _f32p]
+        L.oracle_batch_rollout.restype = C.c_int
+        L.oracle_batch_rollout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double] + \
+            [C.c_void_p] * 11 + [C.c_int64] + [C.c_void_p] * 4
+        L.oracle_batch_vi.restype = C.c_int64
+        L.oracle_batch_vi.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5 + \
+            [C.c_float, C.c_double, C.c_int, C.c_int64] + [C.c_void_p] * 3
         _LIB = L
     return _LIB
 
@@ -202,3 +208,49 @@ def philox(c, k):
     out = np.zeros(4, np.uint32)
     lib().oracle_philox(*[int(x) for x in c], *[int(x) for x in k], _ptr(out))
     return out
+
+
+def batch_rollout(tables, b0, b1, n_steps, rng_mode=1, philox_keys=None, want_visits=False):
+    """Instances [b0, b1) of concatenated tables (colosseum_amd.batched.tables_from_models layout): reset, then
+    n_steps transitions under the Philox random policy.  Returns last_obs, reward_sum[, visits_s, visits_sa]."""
+    L = lib()
+    t = tables
+    A, H = int(t["A"]), int(t["H"])
+    f = {k: np.ascontiguousarray(t[k], dt) for k, dt in (
+        ("state_off", np.int64), ("sp_ptr", np.int64), ("sp_next", np.int32), ("sp_cum", np.float64),
+        ("sp_reward", np.float64), ("sp_seed", np.int32), ("start_off", np.int64), ("start_state", np.int32),
+        ("start_cum", np.float64), ("start_seed", np.int32))}
+    keys = np.ascontiguousarray(philox_keys if philox_keys is not None else np.arange(int(t["B"])), np.uint64)
+    n = b1 - b0
+    last = np.zeros(n, np.int32)
+    rsum = np.zeros(n, np.float64)
+    ns = int(f["state_off"][b1] - f["state_off"][b0])
+    vs = np.zeros(ns, np.int64) if want_visits else None
+    vsa = np.zeros(ns * A, np.int64) if want_visits else None
+    rc = L.oracle_batch_rollout(b0, b1, A, H, rng_mode, float(t["rewards_range"][0]), float(t["rewards_range"][1]),
+                                _ptr(f["state_off"]), _ptr(f["sp_ptr"]), _ptr(f["sp_next"]), _ptr(f["sp_cum"]),
+                                _ptr(f["sp_reward"]), _ptr(f["sp_seed"]), _ptr(f["start_off"]), _ptr(f["start_state"]),
+                                _ptr(f["start_cum"]), _ptr(f["start_seed"]), _ptr(keys), int(n_steps), _ptr(last),
+                                _ptr(rsum), _ptr(vs), _ptr(vsa))
+    if rc != 0:
+        raise RuntimeError(f"oracle batch rollout failed ({rc})")
+    return (last, rsum, vs, vsa) if want_visits else (last, rsum)
+
+
+def batch_vi(tables, b0, b1, gamma=0.99, eps=1e-6, scheme=0, max_sweeps=1_000_000):
+    L = lib()
+    t = tables
+    A = int(t["A"])
+    so = np.ascontiguousarray(t["state_off"], np.int64)
+    ptr = np.ascontiguousarray(t["csr_ptr"], np.int64)
+    col = np.ascontiguousarray(t["csr_col"], np.int32)
+    val = np.ascontiguousarray(t["csr_val"], np.float32)
+    R = np.ascontiguousarray(t["R"], np.float32)
+    Q = np.zeros(int(so[-1]) * A, np.float32)
+    V = np.zeros(int(so[-1]), np.float32)
+    sw = np.zeros(b1 - b0, np.int64)
+    tot = L.oracle_batch_vi(b0, b1, A, _ptr(so), _ptr(ptr), _ptr(col), _ptr(val), _ptr(R), gamma, eps, scheme,
+                            max_sweeps, _ptr(Q), _ptr(V), _ptr(sw))
+    if tot < 0:
+        raise RuntimeError(f"oracle batch VI failed ({tot})")
+    return Q, V, sw
