@@ -1,0 +1,81 @@
+"""Host model builder vs the reference's own structures (golden fixtures G1-G4): state order, action
+permutation, successor lists, probabilities, reward means, start distribution, dense T and R -- all exact."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from colosseum_amd.batched import tables_from_models
+from colosseum_amd.mdp import make_model
+from colosseum_amd.mdp.fast_batch import deepsea_episodic_tables
+
+
+@pytest.mark.parametrize("name", ["G1_deepsea8", "G2_deepsea30", "G3_stochastic", "G4_frozenlake20_vi"])
+def test_structure_matches_reference(name):
+    z, cases = load_golden(name)
+    for i, c in enumerate(cases):
+        m = make_model(c["cls"], **c["kwargs"])
+        k = f"c{i}_"
+        S, A, H = z[k + "SAH"]
+        assert (m.n_states, m.n_actions, m.H) == (S, A, H), c
+        np.testing.assert_array_equal(m.nodes, z[k + "nodes"])
+        np.testing.assert_array_equal(m.sp_ptr, z[k + "sp_ptr"])
+        np.testing.assert_array_equal(m.sp_next, z[k + "sp_next"])
+        np.testing.assert_array_equal(m.sp_prob, z[k + "sp_prob"])
+        np.testing.assert_array_equal(m.sp_rmean, z[k + "sp_rmean"])
+        if k + "start_states" in z:
+            np.testing.assert_array_equal(m.start_states, z[k + "start_states"])
+            np.testing.assert_array_equal(m.start_probs, z[k + "start_probs"])
+        T, R = m.dense()
+        np.testing.assert_array_equal(R, z[k + "R"])
+        if k + "T_idx" in z:
+            nz = np.nonzero(T)
+            np.testing.assert_array_equal(np.stack(nz), z[k + "T_idx"])
+            np.testing.assert_array_equal(T[nz], z[k + "T_val"])
+        extra = c.get("extra", {})
+        fam = m.extra["family"]
+        if "lake" in extra:
+            assert ["".join(r) for r in fam.lake] == extra["lake"]
+        if "goal_position" in extra:
+            assert list(fam.goal_position) == extra["goal_position"]
+
+
+def test_first_samples_of_every_sampler_match_reference():
+    """The per-(s,a) sampler seeds are right: the first 8 draws of random.Random(seed).choices(...) equal the
+    reference's cached_states (custom_samplers.py:55-57)."""
+    import random
+
+    z, cases = load_golden("G3_stochastic")
+    for i, c in enumerate(cases):
+        m = make_model(c["cls"], **c["kwargs"])
+        first = z[f"c{i}_sp_first"]
+        for r in range(m.n_states * m.n_actions):
+            lo, hi = m.sp_ptr[r], m.sp_ptr[r + 1]
+            if hi - lo == 1:
+                assert first[r, 0] == -1
+                continue
+            got = random.Random(int(m.sp_seed[r])).choices(m.sp_next[lo:hi].tolist(), weights=m.sp_prob[lo:hi].tolist(), k=8)
+            assert got == first[r].tolist(), (c, r)
+        sf = z[f"c{i}_start_first"]
+        if len(sf):
+            got = random.Random(m.start_seed).choices(m.start_states.tolist(), weights=m.start_probs.tolist(), k=len(sf))
+            assert got == sf.tolist()
+
+
+def test_deepsea_fast_batch_equals_generic_builder():
+    seeds = [0, 1, 5, 123, 40000]
+    for size in (5, 12):
+        fast = deepsea_episodic_tables(seeds, size, with_dp=True)
+        ref = tables_from_models([make_model("DeepSeaEpisodic", seed=s, size=size) for s in seeds])
+        for k in ref:
+            if k == "sp_seed":  # never read for deterministic rows
+                continue
+            np.testing.assert_array_equal(np.asarray(ref[k]), np.asarray(fast[k]), err_msg=k)
+
+
+def test_constructor_checks():
+    with pytest.raises(AssertionError):
+        make_model("DeepSeaEpisodic", seed=0, size=5, p_lazy=0.1)  # no lazy mechanic for DeepSea
+    with pytest.raises(KeyError):
+        make_model("TaxiEpisodic", seed=0, size=5)
+    with pytest.raises(NotImplementedError):
+        make_model("DeepSeaEpisodic", seed=0)
