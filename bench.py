@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--vi-instances", type=int, default=4096, help="FrozenLake instances per GPU for the VI leg (0: skip)")
     ap.add_argument("--cpu-instances", type=int, default=16384, help="instances of the CPU-oracle sample (0: skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--lds-groups", type=int, default=0, help="LDS rollout workgroups per CU (0: library default)")
+    ap.add_argument("--rollout-kernel", type=int, default=0, help="0 auto, 1 HBM tables, 2 LDS-resident")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,6 +138,10 @@ def main():
     keys = seeds.astype(np.uint64)  # Philox key = global instance id
     env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX, philox_keys=keys)
     env.reset()
+    if args.rollout_kernel:
+        env.set_rollout_kernel(args.rollout_kernel)
+    if args.lds_groups:
+        env.set_option(L.OPT_LDS_GROUPS_PER_CU, args.lds_groups)
     t_build = time.time() - t_build
     S = int(env.n_states[0])
 

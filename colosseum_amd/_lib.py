@@ -14,10 +14,15 @@ RNG_MT_COMPAT, RNG_PHILOX = 0, 1
 POLICY_RANDOM, POLICY_HOST_ACTIONS, POLICY_GREEDY_Q = 0, 1, 2
 SCHEME_AUTO, SCHEME_JACOBI, SCHEME_GAUSS_SEIDEL = 0, 1, 2
 LAYOUT_CSR, LAYOUT_DENSE = 0, 1
+OPT_ROLLOUT_KERNEL = 1
+OPT_DP_KERNEL = 2
+OPT_LDS_GROUPS_PER_CU = 3
+DP_AUTO, DP_WORKGROUP, DP_REGISTER = 0, 1, 2
+ROLLOUT_AUTO, ROLLOUT_GLOBAL, ROLLOUT_LDS = 0, 1, 2
 
 EXPORTS = [
     "cmdp_version", "cmdp_last_error", "cmdp_device_count", "cmdp_set_device", "cmdp_create", "cmdp_destroy",
-    "cmdp_stream", "cmdp_reset", "cmdp_step", "cmdp_rollout", "cmdp_rollout_async", "cmdp_synchronize",
+    "cmdp_stream", "cmdp_reset", "cmdp_step", "cmdp_rollout", "cmdp_rollout_async", "cmdp_synchronize", "cmdp_set_option",
     "cmdp_visits", "cmdp_reset_visits", "cmdp_state", "cmdp_vi_discounted", "cmdp_pe_discounted",
     "cmdp_vi_episodic", "cmdp_pe_episodic", "cmdp_diameter", "cmdp_value_norm",
 ]
@@ -72,6 +77,7 @@ def load():
         L.cmdp_rollout.argtypes = [vp, i32, vp, i64, vp, vp, vp, vp, vp]
         L.cmdp_rollout_async.argtypes = [vp, i32, i64]
         L.cmdp_synchronize.argtypes = [vp]
+        L.cmdp_set_option.argtypes = [vp, i32, i64]
         L.cmdp_visits.argtypes = [vp, vp, vp]
         L.cmdp_reset_visits.argtypes = [vp]
         L.cmdp_state.argtypes = [vp, vp, vp, vp]

@@ -148,6 +148,17 @@ class BatchedMDP:
     def rollout_async(self, n_steps: int):
         L.check(self._lib.cmdp_rollout_async(self._h, L.POLICY_RANDOM, int(n_steps)))
 
+    def set_rollout_kernel(self, which: int):
+        """L.ROLLOUT_AUTO | L.ROLLOUT_GLOBAL | L.ROLLOUT_LDS (tuning only; results are identical)."""
+        L.check(self._lib.cmdp_set_option(self._h, L.OPT_ROLLOUT_KERNEL, int(which)))
+
+    def set_option(self, option: int, value: int):
+        L.check(self._lib.cmdp_set_option(self._h, int(option), int(value)))
+
+    def set_dp_kernel(self, which: int):
+        """L.DP_AUTO | L.DP_WORKGROUP | L.DP_REGISTER for the Jacobi sweeps (tuning only)."""
+        L.check(self._lib.cmdp_set_option(self._h, L.OPT_DP_KERNEL, int(which)))
+
     def synchronize(self):
         L.check(self._lib.cmdp_synchronize(self._h))
 

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "cmdp_kernels.h"
@@ -72,6 +73,8 @@ struct cmdp {
   std::vector<int64_t> csr_nnz;    // per instance
   int max_S = 0;
   int64_t max_inst_nnz = 0;
+  int max_row_nnz = 0;
+  int dp_kernel = 0;  // 0 auto, 1 LDS/global-CSR workgroup kernel, 2 register-resident kernel
 
   DevBuf<int64_t> d_state_off, d_entry_base, d_start_off, d_csr_ptr;
   DevBuf<RowDesc> d_row;
@@ -88,6 +91,15 @@ struct cmdp {
   DevBuf<int32_t> d_tr_obs, d_last_obs;
   DevBuf<double> d_tr_rew, d_rsum;
   DevBuf<uint8_t> d_tr_type, d_mask;
+  // LDS-resident rollout (K1L)
+  bool lds_ok = false;
+  int lds_G1 = 0, lds_G2 = 0;  // instances per workgroup at one / two workgroups per CU
+  int rollout_kernel = 0;  // CMDP_OPT_ROLLOUT_KERNEL
+  LdsPlan lds_plan{};
+  size_t lds_bytes = 0;
+  DevBuf<uint16_t> d_next16;
+  DevBuf<uint8_t> d_rcode;
+  DevBuf<double> d_rvals;
 
   EnvTables env() {
     EnvTables t{};
@@ -220,6 +232,8 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
         rd.first = (int32_t)(lo - ebase[b]);
         rd.n = (int32_t)n;
         rd.next_if_det = d->sp_next[lo];
+        rd.reward_if_det = d->sp_reward[lo];
+        rd.pad = 0.0;
         rd.mt_slot = -1;
         if (n > 1 && d->rng_mode == CMDP_RNG_MT_COMPAT) {
           rd.mt_slot = (int32_t)seeds.size();
@@ -274,6 +288,67 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
     HIP_TRY(h->d_visits_s.zero(st));
     HIP_TRY(h->d_visits_sa.alloc(R));
     HIP_TRY(h->d_visits_sa.zero(st));
+    // ---- eligibility of the LDS-resident rollout kernel --------------------------------------------------
+    {
+      bool ok = max_S <= 65535 && h->n_slots == 0;
+      for (int b = 0; ok && b < B; ++b) ok = (d->state_off[b + 1] - d->state_off[b]) == max_S;  // uniform S
+      for (int64_t r = 0; ok && r < R; ++r) ok = rows[(size_t)r].n == 1;
+      for (int b = 0; ok && b < B; ++b) ok = (d->start_off[b + 1] - d->start_off[b]) == 1;
+      std::vector<double> vals;
+      std::unordered_map<uint64_t, int> code_of;
+      std::vector<uint8_t> codes;
+      std::vector<uint16_t> next16;
+      if (ok) {
+        codes.resize((size_t)R);
+        next16.resize((size_t)R);
+        for (int64_t r = 0; ok && r < R; ++r) {
+          const double v = rows[(size_t)r].reward_if_det;
+          uint64_t bits;
+          std::memcpy(&bits, &v, sizeof bits);
+          auto it = code_of.find(bits);
+          if (it == code_of.end()) {
+            if (vals.size() == 256) { ok = false; break; }
+            it = code_of.emplace(bits, (int)vals.size()).first;
+            vals.push_back(v);
+          }
+          codes[(size_t)r] = (uint8_t)it->second;
+          next16[(size_t)r] = (uint16_t)rows[(size_t)r].next_if_det;
+        }
+      }
+      if (ok) {
+        const int rows_max = max_S * A;
+        LdsPlan p{};
+        p.rows_max = rows_max;
+        p.off_rcode = (rows_max * 2 + 3) & ~3;
+        p.off_cnt = p.off_rcode + ((rows_max + 3) & ~3);
+        p.slot_bytes = p.off_cnt + (((rows_max + 1) / 2) * 4);
+        const int fixed = 256 * 8 + 64 * 4;
+        // two workgroups per CU when that keeps >= 12 instances each: one group's staging / flush streams
+        // overlap the other group's walk
+        p.G = std::min<int>(64, (kLdsBudget - fixed) / p.slot_bytes);
+        const int g2 = std::min<int>(64, (kLdsBudget / 2 - fixed) / p.slot_bytes);
+        if (g2 >= 12) p.G = g2;
+        h->lds_G1 = std::min<int>(64, (kLdsBudget - fixed) / p.slot_bytes);
+        h->lds_G2 = g2;
+        p.n_codes = (int)vals.size();
+        if (p.G >= 8) {
+          // 16 bytes of slack in front of and behind both element arrays: the staging loads are 16-byte wide
+          // from the aligned-down address of a group's first element
+          next16.insert(next16.begin(), 8, 0);
+          next16.insert(next16.end(), 8, 0);
+          codes.insert(codes.begin(), 16, 0);
+          codes.insert(codes.end(), 16, 0);
+          HIP_TRY(h->d_next16.upload(next16.data(), next16.size(), st));
+          HIP_TRY(h->d_rcode.upload(codes.data(), codes.size(), st));
+          HIP_TRY(h->d_rvals.upload(vals.data(), vals.size(), st));
+          p.next16 = h->d_next16.p + 8; p.rcode = h->d_rcode.p + 16; p.rvals = h->d_rvals.p;
+          h->lds_plan = p;
+          h->lds_bytes = (size_t)fixed + (size_t)p.G * p.slot_bytes;
+          h->lds_ok = true;
+          HIP_TRY(hipStreamSynchronize(st));  // staging vectors die with this scope
+        }
+      }
+    }
     if (h->n_slots) {
       DevBuf<int32_t> d_seeds;
       HIP_TRY(d_seeds.upload(seeds.data(), seeds.size(), st));
@@ -299,6 +374,7 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
       h->max_inst_nnz = std::max(h->max_inst_nnz, h->csr_nnz[b]);
       for (int64_t r = r0; r < r1; ++r) {
         if (d->csr_ptr[r + 1] < d->csr_ptr[r]) return fail(CMDP_ERR_INVALID, "csr_ptr decreasing at row %lld", (long long)r);
+        h->max_row_nnz = std::max<int>(h->max_row_nnz, (int)std::min<int64_t>(d->csr_ptr[r + 1] - d->csr_ptr[r], 1 << 30));
         for (int64_t k = d->csr_ptr[r]; k < d->csr_ptr[r + 1]; ++k)
           if (d->csr_col[k] < 0 || d->csr_col[k] >= S)
             return fail(CMDP_ERR_INVALID, "csr_col out of range at %lld", (long long)k);
@@ -386,6 +462,20 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
   const dim3 grid(grid_for(h->B, 256)), block(256);
   const bool trace = d_tobs || d_trew || d_ttype;
   EnvTables t = h->env();
+  const bool lds_eligible = h->lds_ok && policy == CMDP_POLICY_RANDOM && !trace;
+  if (h->rollout_kernel == 2 && !lds_eligible)
+    return fail(CMDP_ERR_UNSUPPORTED, "LDS-resident rollout needs deterministic dynamics, one start state, <= 65535 "
+                                      "states, <= 256 distinct rewards, the random policy and no trace");
+  // the LDS kernel pays a fixed staging + flush cost per launch: worth it from a few dozen transitions on
+  if (lds_eligible && (h->rollout_kernel == 2 || (h->rollout_kernel == 0 && n_steps >= 64))) {
+    if (h->lds_bytes > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)h->lds_bytes));
+    hipLaunchKernelGGL(k_rollout_lds, dim3(grid_for(h->B, h->lds_plan.G)), dim3(K1L_THREADS), h->lds_bytes, st, t, h->lds_plan,
+                       n_steps, d_rsum, d_last);
+    HIP_TRY(hipGetLastError());
+    return CMDP_OK;
+  }
   if (policy == CMDP_POLICY_RANDOM) {
     if (trace) hipLaunchKernelGGL((k_rollout<0, true>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype);
     else hipLaunchKernelGGL((k_rollout<0, false>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype);
@@ -444,6 +534,26 @@ int cmdp_rollout_async(cmdp_t* h, int policy, int64_t n_steps) {
   if (h->d_rsum.n < (size_t)h->B) HIP_TRY(h->d_rsum.alloc(h->B));
   if (h->d_last_obs.n < (size_t)h->B) HIP_TRY(h->d_last_obs.alloc(h->B));
   return launch_rollout(h, policy, nullptr, n_steps, h->d_rsum.p, h->d_last_obs.p, nullptr, nullptr, nullptr);
+}
+
+int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
+  if (!h) return fail(CMDP_ERR_INVALID, "null handle");
+  if (option == CMDP_OPT_ROLLOUT_KERNEL && value >= 0 && value <= 2) {
+    h->rollout_kernel = (int)value;
+    return CMDP_OK;
+  }
+  if (option == CMDP_OPT_LDS_GROUPS_PER_CU && (value == 1 || value == 2) && h->lds_ok) {
+    const int g = value == 1 ? h->lds_G1 : h->lds_G2;
+    if (g < 1) return fail(CMDP_ERR_INVALID, "no room for %lld workgroups per CU", (long long)value);
+    h->lds_plan.G = g;
+    h->lds_bytes = (size_t)(256 * 8 + 64 * 4) + (size_t)g * h->lds_plan.slot_bytes;
+    return CMDP_OK;
+  }
+  if (option == CMDP_OPT_DP_KERNEL && value >= 0 && value <= 2) {
+    h->dp_kernel = (int)value;
+    return CMDP_OK;
+  }
+  return fail(CMDP_ERR_INVALID, "unknown option %d / value %lld", option, (long long)value);
 }
 
 int cmdp_synchronize(cmdp_t* h) {
@@ -539,6 +649,32 @@ int run_sweeps(cmdp_t* h, int mode, bool diam, int scheme, DpTables t, int64_t u
   hipStream_t st = h->stream;
   if (units > 0x7fffffffLL) return fail(CMDP_ERR_INVALID, "too many work items");
   const size_t v_bytes = sizeof(float) * (size_t)h->max_S;
+  if (scheme == CMDP_SCHEME_JACOBI && !diam && h->dp_kernel != 1) {
+    // register-resident CSR (K2R) when the shapes fit one of the compiled instantiations
+    const int A = h->A, K = h->max_row_nnz <= 4 ? 4 : (h->max_row_nnz <= 8 ? 8 : 0);
+    const int spt = h->max_S <= 256 ? 1 : (h->max_S <= 512 ? 2 : (h->max_S <= 1024 ? 4 : 0));
+    const size_t lds = 2 * v_bytes + sizeof(float) * 16;
+    bool launched = true;
+    const dim3 grid((unsigned)units), block(256);
+#define REG_CASE(AT, KT, ST)                                                                                  \
+  if (A == AT && K == KT && spt == ST) {                                                                      \
+    if (mode == DP_VI) hipLaunchKernelGGL((k_dp_reg<DP_VI, AT, KT, ST>), grid, block, lds, st, t);             \
+    else hipLaunchKernelGGL((k_dp_reg<DP_PE, AT, KT, ST>), grid, block, lds, st, t);                           \
+  } else
+    REG_CASE(2, 4, 1) REG_CASE(2, 4, 2) REG_CASE(2, 4, 4)
+    REG_CASE(3, 4, 1) REG_CASE(3, 4, 2) REG_CASE(3, 4, 4)
+    REG_CASE(4, 4, 1) REG_CASE(4, 4, 2) REG_CASE(4, 4, 4)
+    REG_CASE(2, 8, 1) REG_CASE(2, 8, 2)
+    REG_CASE(3, 8, 1) REG_CASE(3, 8, 2)
+    REG_CASE(4, 8, 1) REG_CASE(4, 8, 2)
+    { launched = false; }
+#undef REG_CASE
+    if (launched) {
+      HIP_TRY(hipGetLastError());
+      return CMDP_OK;
+    }
+    if (h->dp_kernel == 2) return fail(CMDP_ERR_UNSUPPORTED, "no register-resident instantiation for A=%d, %d non-zeros/row, %d states", A, h->max_row_nnz, h->max_S);
+  }
   if (scheme == CMDP_SCHEME_JACOBI) {
     const size_t base = 2 * v_bytes + sizeof(float) * 4 * (kDpBlock / 64);
     const size_t csr = sizeof(int32_t) * ((size_t)h->max_S * h->A + 1) + 8 * (size_t)h->max_inst_nnz +

@@ -7,8 +7,9 @@
 
 // ---------------------------------------------------------------------------------------------------
 // Philox-4x32-10.  Counter (n_lo, n_hi, domain, 0), key = the instance's 64-bit key.
-// domain 0: transition n  -> w0,w1 = 53-bit transition uniform, w2 = random-policy action
-// domain 1: reset n       -> w0,w1 = start-state uniform
+// domain 0, n = transition index      : w0,w1 = 53-bit transition uniform (stochastic rows only)
+// domain 1, n = reset index           : w0,w1 = start-state uniform (several start states only)
+// domain 2, n = transition index >> 2 : word (index & 3) = random-policy action, a = (word * A) >> 32
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t (&w)[4]) {

@@ -13,12 +13,20 @@
 #pragma once
 #include "cmdp_device.h"
 
-struct RowDesc {       // 16 B, one per (instance, state, action)
-  int32_t first;       // first entry of the row, relative to the instance's entry base
-  int32_t n;           // number of successors (1 = deterministic shortcut, no draw)
-  int32_t next_if_det; // successor when n == 1
-  int32_t mt_slot;     // MT19937 slot of the row's sampler (MT_COMPAT, n > 1), else -1
+struct __attribute__((aligned(32))) RowDesc {  // 32 B, one per (instance, state, action): ONE load per transition
+  int32_t first;         // first entry of the row, relative to the instance's entry base
+  int32_t n;             // number of successors (1 = deterministic shortcut, no draw)
+  int32_t next_if_det;   // successor when n == 1
+  int32_t mt_slot;       // MT19937 slot of the row's sampler (MT_COMPAT, n > 1), else -1
+  double reward_if_det;  // reward of the only successor when n == 1 (saves the dependent entry load)
+  double pad;
 };
+
+// Visit counters belong to exactly one lane; the add is issued as a no-return atomic so that the wave never
+// waits for a counter load (fire and forget; the increments are off the state's dependency chain).
+__device__ __forceinline__ void bump(int32_t* p) {
+  (void)__hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 struct EnvTables {
   int32_t B, A, H, rng_mode;
@@ -55,6 +63,15 @@ __global__ void k_mt_seed(uint32_t* __restrict__ mt, int32_t* __restrict__ mt_po
   mt_pos[i] = 0;
 }
 
+// random-policy action of transition n: word (n & 3) of the domain-2 Philox block n >> 2
+__device__ __forceinline__ int philox_action(unsigned long long n, uint2 key, int A) {
+  uint32_t w[4];
+  philox4x32_10((uint32_t)(n >> 2), (uint32_t)(n >> 34), 2u, 0u, key.x, key.y, w);
+  const int j = (int)(n & 3);
+  const uint32_t word = (j == 0) ? w[0] : (j == 1) ? w[1] : (j == 2) ? w[2] : w[3];
+  return (int)(((uint64_t)word * (uint64_t)A) >> 32);
+}
+
 // BaseMDP.reset (reference colosseum/mdp/base.py:1268-1277) for one instance
 __device__ __forceinline__ int32_t env_reset(const EnvTables& t, int b, int64_t soff, uint2 key,
                                              unsigned long long& n_reset) {
@@ -75,7 +92,7 @@ __device__ __forceinline__ int32_t env_reset(const EnvTables& t, int b, int64_t 
   }
   n_reset++;
   const int32_t s = t.start_state[lo + idx];
-  t.visits_s[soff + s] += 1;
+  bump(t.visits_s + soff + s);
   return s;
 }
 
@@ -84,28 +101,32 @@ __device__ __forceinline__ int32_t env_reset(const EnvTables& t, int b, int64_t 
 __device__ __forceinline__ int env_step(const EnvTables& t, int64_t soff, int64_t ebase, uint2 key, int32_t& cur,
                                         int32_t& h, unsigned long long& n_trans, int action, int32_t& obs,
                                         double& reward) {
-  uint32_t w[4] = {0u, 0u, 0u, 0u};
-  if (t.rng_mode == 1 || action < 0) {
-    philox4x32_10((uint32_t)n_trans, (uint32_t)(n_trans >> 32), 0u, 0u, key.x, key.y, w);
-  }
-  if (action < 0) action = (int)(((uint64_t)w[2] * (uint64_t)t.A) >> 32);
+  const unsigned long long n = n_trans;
+  if (action < 0) action = philox_action(n, key, t.A);
   n_trans++;
   h += 1;
   const int64_t r = (soff + cur) * t.A + action;
   const RowDesc d = t.row[r];
-  int64_t e = ebase + d.first;
   int32_t nxt = d.next_if_det;
+  double rraw = d.reward_if_det;
   if (d.n > 1) {  // NextStateSampler.sample (custom_samplers.py:59-72)
     double u;
-    if (t.rng_mode == 0) u = mt_random(t.mt + (int64_t)d.mt_slot * 624, t.mt_pos + d.mt_slot);
-    else u = u53(w[0], w[1]);
-    e += choose_index(t.sp_cum + e, d.n, u);
+    if (t.rng_mode == 0) {
+      u = mt_random(t.mt + (int64_t)d.mt_slot * 624, t.mt_pos + d.mt_slot);
+    } else {
+      uint32_t w[4];
+      philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 0u, 0u, key.x, key.y, w);
+      u = u53(w[0], w[1]);
+    }
+    const int64_t e0 = ebase + d.first;
+    const int64_t e = e0 + choose_index(t.sp_cum + e0, d.n, u);
     nxt = t.sp_next[e];
+    rraw = t.sp_reward[e];
   }
   // visit counts on the arrival node with the action taken at the departure node (base.py:1302-1303)
-  t.visits_s[soff + nxt] += 1;
-  t.visits_sa[(soff + nxt) * t.A + action] += 1;
-  reward = t.sp_reward[e] * t.rscale - t.rmin;  // `r * (max - min) - min`, base.py:1205-1207
+  bump(t.visits_s + soff + nxt);
+  bump(t.visits_sa + (soff + nxt) * t.A + action);
+  reward = rraw * t.rscale - t.rmin;  // `r * (max - min) - min`, base.py:1205-1207
   cur = nxt;
   if (t.H > 0 && h >= t.H) {
     obs = -1;
@@ -206,6 +227,250 @@ __global__ void __launch_bounds__(256) k_rollout(EnvTables t, const int8_t* __re
   t.n_reset[b] = nr;
   if (reward_sum) reward_sum[b] = sum;
   if (last_obs) last_obs[b] = obs;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1L: LDS-resident rollout for batches of small deterministic-dynamics instances (config C2).
+//
+// The lane-per-instance kernel above moves a whole HBM sector for every 4..32-byte table access
+// (measured ~640 B of traffic per 44-byte transition), so it is bound by HBM sector throughput.  Here a
+// one-wavefront workgroup stages the tables of G instances into LDS with coalesced loads ONCE per launch
+// -- per instance: successor table uint16[S*A], reward-code table uint8[S*A] and 16-bit visit-count
+// deltas [S*A] -- walks them for n_steps entirely on chip (one LDS read on the dependency chain per
+// transition), then adds the deltas into the HBM counters with coalesced read-modify-writes.
+// HBM traffic per launch ~ (3 + 12) bytes per table row, independent of n_steps.
+// G = floor(160 KiB / bytes per instance) (33 for DeepSea-30), one workgroup per CU at a time.
+// ---------------------------------------------------------------------------------------------------
+struct LdsPlan {
+  int32_t G;               // instances per workgroup (<= 64)
+  int32_t rows_max;        // max S*A over the batch
+  int32_t slot_bytes;      // LDS bytes per instance slot
+  int32_t off_rcode;       // byte offsets inside a slot
+  int32_t off_cnt;
+  int32_t n_codes;         // distinct reward values (<= 256)
+  const uint16_t* next16;  // [R] successor of every (deterministic) row
+  const uint8_t* rcode;    // [R] index into rvals
+  const double* rvals;     // [n_codes]
+};
+
+struct LdsPlan;
+// dst[j] += delta(j) for j in [0, total): ROWS: delta = 16-bit count of row j; else delta = sum over the A
+// counts of state j (+ the resets of its instance when j is the start state).  `per` = rows or states per slot.
+template <bool ROWS>
+__device__ __forceinline__ void flush_counts(int32_t* __restrict__ dst, int total, int per, int A, unsigned char* slots,
+                                             const LdsPlan& p, const int32_t* resets, const int32_t* start_states,
+                                             int tid);
+// `K` independent global loads in flight per thread before any is consumed (memory-level parallelism:
+// the staging / flush phases are pure streaming and must not serialise on HBM latency).
+#define K1L_UNROLL 8
+#define K1L_THREADS 256
+
+__global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPlan p, int64_t n_steps,
+                                                            double* __restrict__ reward_sum,
+                                                            int32_t* __restrict__ last_obs) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int g0 = blockIdx.x * p.G;
+  const int nb = min(p.G, t.B - g0);
+  double* rvals = reinterpret_cast<double*>(smem);                       // [256]
+  int32_t* resets = reinterpret_cast<int32_t*>(smem + 256 * 8);          // [64]
+  unsigned char* slots = smem + 256 * 8 + 64 * 4;
+  const int A = t.A, H = t.H;
+  // all instances of the batch have the same S (eligibility): the group's rows are one contiguous range
+  const int64_t so0 = t.state_off[g0];
+  const int S = (int)(t.state_off[g0 + 1] - so0);
+  const int rows = S * A;
+  const int64_t row00 = so0 * A;
+  const int total_rows = nb * rows, total_states = nb * S;
+  for (int i = tid; i < p.n_codes; i += K1L_THREADS) rvals[i] = p.rvals[i];
+  // ---- stage the tables: 16-byte loads from the aligned-down address, K1L_UNROLL of them in flight per
+  //      thread (the element arrays carry 16 bytes of slack at both ends, see cmdp_create) -----------------
+  {
+    const uint16_t* src = p.next16 + row00;
+    const int head = (int)((reinterpret_cast<uintptr_t>(src) & 15) >> 1);
+    const uint4* vsrc = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(src) - 2 * head);
+    const int nchunks = (head + total_rows + 7) >> 3;
+    for (int c0 = 0; c0 < nchunks; c0 += K1L_THREADS * K1L_UNROLL) {
+      uint4 v[K1L_UNROLL];
+#pragma unroll
+      for (int k = 0; k < K1L_UNROLL; ++k) {
+        const int c = c0 + k * K1L_THREADS + tid;
+        if (c < nchunks) v[k] = vsrc[c];
+      }
+#pragma unroll
+      for (int k = 0; k < K1L_UNROLL; ++k) {
+        const int c = c0 + k * K1L_THREADS + tid;
+        if (c < nchunks) {
+          const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+          int j = c * 8 - head;
+          int slot = (j > 0) ? j / rows : 0, off = j - slot * rows;
+#pragma unroll
+          for (int e = 0; e < 8; ++e, ++j, ++off) {
+            if (off == rows) { off = 0; ++slot; }
+            if (j >= 0 && j < total_rows)
+              reinterpret_cast<uint16_t*>(slots + (size_t)slot * p.slot_bytes)[off] = (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
+          }
+        }
+      }
+    }
+  }
+  {
+    const uint8_t* src = p.rcode + row00;
+    const int head = (int)(reinterpret_cast<uintptr_t>(src) & 15);
+    const uint4* vsrc = reinterpret_cast<const uint4*>(src - head);
+    const int nchunks = (head + total_rows + 15) >> 4;
+    for (int c0 = 0; c0 < nchunks; c0 += K1L_THREADS * K1L_UNROLL) {
+      uint4 v[K1L_UNROLL];
+#pragma unroll
+      for (int k = 0; k < K1L_UNROLL; ++k) {
+        const int c = c0 + k * K1L_THREADS + tid;
+        if (c < nchunks) v[k] = vsrc[c];
+      }
+#pragma unroll
+      for (int k = 0; k < K1L_UNROLL; ++k) {
+        const int c = c0 + k * K1L_THREADS + tid;
+        if (c < nchunks) {
+          const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+          int j = c * 16 - head;
+          int slot = (j > 0) ? j / rows : 0, off = j - slot * rows;
+#pragma unroll
+          for (int e = 0; e < 16; ++e, ++j, ++off) {
+            if (off == rows) { off = 0; ++slot; }
+            if (j >= 0 && j < total_rows)
+              (slots + (size_t)slot * p.slot_bytes + p.off_rcode)[off] = (uint8_t)(w[e >> 2] >> (8 * (e & 3)));
+          }
+        }
+      }
+    }
+  }
+  for (int j = tid; j < nb * ((rows + 1) / 2); j += K1L_THREADS) {
+    const int slot = j / ((rows + 1) / 2), off = j - slot * ((rows + 1) / 2);
+    reinterpret_cast<uint32_t*>(slots + (size_t)slot * p.slot_bytes + p.off_cnt)[off] = 0u;
+  }
+  const bool walker = tid < nb;
+  const int b = g0 + (walker ? tid : 0);
+  const uint2 key = t.philox_key[b];
+  const int32_t start = t.start_state[t.start_off[b]];
+  int32_t cur = t.cur[b], h = t.hstep[b], obs = cur;
+  unsigned long long nt = t.n_trans[b], nr = t.n_reset[b];
+  double sum = 0.0;
+  const unsigned char* base = slots + (size_t)(walker ? tid : 0) * p.slot_bytes;
+  const uint16_t* nx = reinterpret_cast<const uint16_t*>(base);
+  const uint8_t* rc = base + p.off_rcode;
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(const_cast<unsigned char*>(base) + p.off_cnt);
+  // 16-bit deltas: at most 32768 transitions between two flushes
+  for (int64_t done = 0; done < n_steps;) {
+    const int64_t chunk = min((int64_t)32768, n_steps - done);
+    __syncthreads();
+    if (walker) {  // lanes of wavefront 0; the other wavefronts wait at the barrier below
+      int32_t n_resets = 0;
+      uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+      bool have = false;
+      for (int64_t s = 0; s < chunk; ++s) {
+        const int j = (int)(nt & 3);
+        if (!have || j == 0) {
+          uint32_t w[4];
+          philox4x32_10((uint32_t)(nt >> 2), (uint32_t)(nt >> 34), 2u, 0u, key.x, key.y, w);
+          w0 = w[0]; w1 = w[1]; w2 = w[2]; w3 = w[3];
+          have = true;
+        }
+        const uint32_t word = (j == 0) ? w0 : (j == 1) ? w1 : (j == 2) ? w2 : w3;
+        const int a = (int)(((uint64_t)word * (uint64_t)A) >> 32);
+        const int row = cur * A + a;
+        const int nxt = nx[row];
+        const double r = rvals[rc[row]] * t.rscale - t.rmin;  // `r * (max - min) - min`, base.py:1205-1207
+        sum += r;
+        // visit count of the ARRIVAL node under the action taken (base.py:1302-1303), 16-bit halves of a dword
+        const int crow = nxt * A + a;
+        atomicAdd(cnt + (crow >> 1), (crow & 1) ? 0x10000u : 1u);
+        ++nt;
+        ++h;
+        cur = nxt;
+        obs = nxt;
+        if (H > 0 && h >= H) {  // episodic termination followed at once by reset()
+          cur = start;
+          obs = start;
+          h = 0;
+          ++nr;
+          ++n_resets;
+        }
+      }
+      resets[tid] = n_resets;
+    }
+    __syncthreads();
+    // ---- flush the deltas into the HBM counters: 16-byte read-modify-writes (every counter has exactly one
+    //      owner; the partial chunks at the two ends of the group's range go element by element) ---------------
+    flush_counts<true>(t.visits_sa + row00, total_rows, rows, A, slots, p, resets, nullptr, tid);
+    flush_counts<false>(t.visits_s + so0, total_states, S, A, slots, p, resets, t.start_state + t.start_off[g0], tid);
+    __syncthreads();
+    for (int j = tid; j < nb * ((rows + 1) / 2); j += K1L_THREADS) {
+      const int slot = j / ((rows + 1) / 2), off = j - slot * ((rows + 1) / 2);
+      reinterpret_cast<uint32_t*>(slots + (size_t)slot * p.slot_bytes + p.off_cnt)[off] = 0u;
+    }
+    done += chunk;
+  }
+  if (walker) {
+    t.cur[b] = cur;
+    t.hstep[b] = h;
+    t.n_trans[b] = nt;
+    t.n_reset[b] = nr;
+    if (reward_sum) reward_sum[b] = sum;
+    if (last_obs) last_obs[b] = obs;
+  }
+}
+
+
+template <bool ROWS>
+__device__ __forceinline__ void flush_counts(int32_t* __restrict__ dst, int total, int per, int A, unsigned char* slots,
+                                             const LdsPlan& p, const int32_t* resets, const int32_t* start_states,
+                                             int tid) {
+  auto delta = [&](int slot, int off) -> int {
+    const uint16_t* c16 = reinterpret_cast<const uint16_t*>(slots + (size_t)slot * p.slot_bytes + p.off_cnt);
+    if (ROWS) return c16[off];
+    int acc = (off == start_states[slot]) ? resets[slot] : 0;
+    for (int a = 0; a < A; ++a) acc += c16[off * A + a];
+    return acc;
+  };
+  const int head = (int)((reinterpret_cast<uintptr_t>(dst) & 15) >> 2);  // counters before the first aligned chunk
+  const int lead = head ? min(4 - head, total) : 0;
+  const int nfull = (total - lead) >> 2;
+  const int tail0 = lead + 4 * nfull;
+  if (tid < lead) {
+    const int d = delta(tid / per, tid % per);
+    if (d) dst[tid] += d;
+  }
+  if (tid >= 64 && tid - 64 < total - tail0) {
+    const int j = tail0 + tid - 64;
+    const int d = delta(j / per, j % per);
+    if (d) dst[j] += d;
+  }
+  int4* vdst = reinterpret_cast<int4*>(dst + lead);
+  for (int c0 = 0; c0 < nfull; c0 += K1L_THREADS * K1L_UNROLL) {
+    int4 old[K1L_UNROLL];
+#pragma unroll
+    for (int k = 0; k < K1L_UNROLL; ++k) {
+      const int c = c0 + k * K1L_THREADS + tid;
+      if (c < nfull) old[k] = vdst[c];
+    }
+#pragma unroll
+    for (int k = 0; k < K1L_UNROLL; ++k) {
+      const int c = c0 + k * K1L_THREADS + tid;
+      if (c < nfull) {
+        int j = lead + 4 * c;
+        int slot = j / per, off = j - slot * per;
+        int d[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e, ++off) {
+          if (off == per) { off = 0; ++slot; }
+          d[e] = delta(slot, off);
+        }
+        if (d[0] | d[1] | d[2] | d[3]) {
+          old[k].x += d[0]; old[k].y += d[1]; old[k].z += d[2]; old[k].w += d[3];
+          vdst[c] = old[k];
+        }
+      }
+    }
+  }
 }
 
 // ===================================================================================================
@@ -385,6 +650,117 @@ __global__ void __launch_bounds__(256) k_dp_block(DpTables t) {
           backup_state<MODE, true, false, true>(s, A, -1, gp, t.csr_col + nz0, t.csr_val + nz0, t.R + row0, pi, Vnew,
                                                 t.gamma, t.Q + row0);
         }
+      }
+    }
+  }
+}
+
+// K2R: Jacobi sweeps with the instance's CSR held in REGISTERS.  One 256-thread workgroup per instance,
+// thread t owns states t, t+256, ... (SPT of them) and keeps the (column, coefficient) pairs of all their
+// A x KMAX row entries plus R in VGPRs for the whole solve: a sweep touches LDS only for the V gathers and the
+// V write (no CSR traffic at all, no bank-conflicting table walks), one barrier per sweep.  Rows shorter than
+// KMAX are padded with (col 0, coefficient +0.0): acc + 0*V[0] == acc exactly, so the padded sum is bit-equal
+// to the reference's in-order accumulation.  HBM traffic: the CSR once per solve, Q/V once at the end.
+template <int MODE, int A_T, int KMAX, int SPT>
+__global__ void __launch_bounds__(256) k_dp_reg(DpTables t) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int b = blockIdx.x;
+  const int64_t soff = t.state_off[b];
+  const int S = (int)(t.state_off[b + 1] - soff);
+  const int64_t row0 = soff * A_T;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  constexpr int NW = 4;
+  float* Va = reinterpret_cast<float*>(smem);
+  float* Vb = Va + S;
+  float* red = Vb + S;  // [2][NW][2]
+
+  int32_t col[SPT][A_T][KMAX];
+  float cf[SPT][A_T][KMAX];
+  float Rr[SPT][A_T], Pi[SPT][A_T];
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {
+    const int s = tid + j * 256;
+#pragma unroll
+    for (int a = 0; a < A_T; ++a) {
+      const int64_t r = row0 + (int64_t)s * A_T + a;
+      int64_t lo = 0, hi = 0;
+      if (s < S) { lo = t.csr_ptr[r]; hi = t.csr_ptr[r + 1]; }
+      Rr[j][a] = (s < S) ? t.R[r] : 0.0f;
+      Pi[j][a] = (MODE == DP_PE && s < S) ? t.pi[r] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        const bool in = lo + k < hi;
+        col[j][a][k] = in ? t.csr_col[lo + k] : 0;
+        const float v = in ? t.csr_val[lo + k] : 0.0f;
+        // PE (and every non-Jacobi-VI form) multiplies the coefficient by gamma first: `(gamma * T) @ V`
+        cf[j][a][k] = (MODE == DP_PE) ? __fmul_rn(t.gamma, v) : v;
+      }
+    }
+  }
+  for (int i = tid; i < S; i += 256) { Va[i] = 0.0f; Vb[i] = 0.0f; }
+  __syncthreads();
+
+  float* Vold = Va;
+  float* Vnew = Vb;
+  int64_t it = 0;
+  int status = -5;
+  while (it < t.max_sweeps) {
+    ++it;
+    float dmax = 0.0f, vabs = 0.0f;
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+      const int s = tid + j * 256;
+      if (s < S) {
+        float v = 0.0f;
+#pragma unroll
+        for (int a = 0; a < A_T; ++a) {
+          float acc = 0.0f;
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) acc = __fadd_rn(acc, __fmul_rn(cf[j][a][k], Vold[col[j][a][k]]));
+          float q;
+          if (MODE == DP_VI) {
+            q = __fadd_rn(Rr[j][a], __fmul_rn(t.gamma, acc));
+            v = (a == 0) ? q : fmaxf(v, q);
+          } else {
+            q = __fadd_rn(Rr[j][a], acc);
+            const float qp = __fmul_rn(q, Pi[j][a]);
+            v = (a == 0) ? qp : __fadd_rn(v, qp);
+          }
+        }
+        Vnew[s] = v;
+        dmax = fmaxf(dmax, fabsf(Vold[s] - v));
+        vabs = fmaxf(vabs, fabsf(v));
+      }
+    }
+    dmax = wave_max(dmax);
+    vabs = wave_max(vabs);
+    float* rbuf = red + (it & 1) * 2 * NW;
+    if (lane == 0) { rbuf[2 * wave] = dmax; rbuf[2 * wave + 1] = vabs; }
+    __syncthreads();
+    float diff = 0.0f, vmax = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { diff = fmaxf(diff, rbuf[2 * w]); vmax = fmaxf(vmax, rbuf[2 * w + 1]); }
+    float* tmp = Vold; Vold = Vnew; Vnew = tmp;
+    if (t.max_abs > 0.0 && (double)vmax > t.max_abs) { status = -7; break; }
+    if ((double)diff < t.eps) { status = 0; break; }
+  }
+  if (tid == 0) {
+    t.status[b] = status;
+    if (t.sweeps) t.sweeps[b] = it;
+  }
+  // Q of the last sweep = the same arithmetic on the vector that sweep read (now in Vnew)
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {
+    const int s = tid + j * 256;
+    if (s < S) {
+      t.V[soff + s] = Vold[s];
+#pragma unroll
+      for (int a = 0; a < A_T; ++a) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) acc = __fadd_rn(acc, __fmul_rn(cf[j][a][k], Vnew[col[j][a][k]]));
+        const float q = (MODE == DP_VI) ? __fadd_rn(Rr[j][a], __fmul_rn(t.gamma, acc)) : __fadd_rn(Rr[j][a], acc);
+        t.Q[row0 + (int64_t)s * A_T + a] = q;
       }
     }
   }

@@ -48,8 +48,10 @@ enum {
      like random.Random(seed) and consumed one random() per sample: reproduces the reference's
      NextStateSampler (colosseum/mdp/utils/custom_samplers.py:49-72) draw for draw. */
   CMDP_RNG_MT_COMPAT = 0,
-  /* Philox-4x32-10 keyed by the instance, counter = the instance's transition count: one call per
-     transition yields the transition uniform, the random-policy action and the start-state uniform. */
+  /* Philox-4x32-10 keyed by the instance (counter-based, nothing stored per sampler):
+     counter (n, domain): domain 0, n = transition index -> 53-bit transition uniform (stochastic rows);
+     domain 1, n = reset index -> start-state uniform; domain 2, n = transition index >> 2 -> word
+     (index & 3) gives the random-policy action (word * A) >> 32. */
   CMDP_RNG_PHILOX = 1
 };
 
@@ -150,6 +152,18 @@ int cmdp_rollout(cmdp_t* h, int policy, const void* policy_arg, int64_t n_steps,
 /* Same launch without the final synchronisation or any copy-back (for back-to-back timing). */
 int cmdp_rollout_async(cmdp_t* h, int policy, int64_t n_steps);
 int cmdp_synchronize(cmdp_t* h);
+
+/* Tuning knobs (never change results).  CMDP_OPT_ROLLOUT_KERNEL: 0 = automatic, 1 = lane-per-instance
+   kernel with the tables in HBM, 2 = LDS-resident kernel (fails with CMDP_ERR_UNSUPPORTED when the batch is
+   not eligible: deterministic dynamics, one start state, equal state counts <= 65535, <= 256 distinct reward
+   values, at least 8 instances per 160 KiB of LDS).
+   CMDP_OPT_DP_KERNEL (Jacobi sweeps): 0 = automatic, 1 = workgroup kernel with the CSR in LDS or HBM,
+   2 = register-resident CSR kernel (CMDP_ERR_UNSUPPORTED when no compiled shape fits: A in 2..4, <= 8
+   non-zeros per row, <= 1024 states).
+   CMDP_OPT_LDS_GROUPS_PER_CU: 1 or 2 workgroups of the LDS-resident rollout kernel per CU (default 2 when
+   each still holds >= 12 instances). */
+enum { CMDP_OPT_ROLLOUT_KERNEL = 1, CMDP_OPT_DP_KERNEL = 2, CMDP_OPT_LDS_GROUPS_PER_CU = 3 };
+int cmdp_set_option(cmdp_t* h, int option, int64_t value);
 
 /* BaseMDP.get_visitation_counts / reset_visitation_counts (colosseum/mdp/base.py:1357-1382).
    state_counts [state_off[B]], sa_counts [state_off[B]*A]; either may be NULL. */

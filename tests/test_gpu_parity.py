@@ -152,6 +152,52 @@ def test_philox_rollout_vs_oracle(need_gpu):
         env.close()
 
 
+def test_lds_resident_rollout_equals_global_kernel_and_oracle(need_gpu):
+    """K1L (tables + 16-bit count deltas in LDS) vs the lane-per-instance kernel vs the oracle: 70 000
+    transitions (crosses the 32 768-step flush of the 16-bit deltas), ragged batch sizes (B not a multiple of the
+    instances-per-workgroup), visits / last observation / reward sums bit-equal."""
+    from colosseum_amd.mdp.fast_batch import deepsea_episodic_tables
+
+    B, size, n1, n2 = 75, 12, 50, 70_000
+    seeds = np.arange(1000, 1000 + B)
+    tables = deepsea_episodic_tables(seeds, size)
+    keys = (seeds * 7919).astype(np.uint64)
+    res = {}
+    for which in (L.ROLLOUT_GLOBAL, L.ROLLOUT_LDS):
+        env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX, philox_keys=keys)
+        env.set_rollout_kernel(which)
+        env.reset()
+        a = env.rollout(n1)  # odd transition count: the next launch starts mid Philox block and mid episode
+        b = env.rollout(n2)
+        vs, vsa = env.visits()
+        res[which] = (a["last_obs"], a["reward_sum"], b["last_obs"], b["reward_sum"], vs, vsa, env.state())
+        env.close()
+    g, l = res[L.ROLLOUT_GLOBAL], res[L.ROLLOUT_LDS]
+    for x, y in zip(g[:6], l[:6]):
+        np.testing.assert_array_equal(x, y)
+    for x, y in zip(g[6], l[6]):
+        np.testing.assert_array_equal(x, y)
+    last, rsum, ovs, ovsa = O.batch_rollout(tables, 0, B, n1 + n2, rng_mode=1, philox_keys=keys, want_visits=True)
+    np.testing.assert_array_equal(l[2], last)
+    np.testing.assert_array_equal(l[4], ovs)
+    np.testing.assert_array_equal(l[5], ovsa)
+    # the oracle sums all n1+n2 rewards in one go; the two launches' sums are separate partial sums
+    np.testing.assert_allclose(l[1] + l[3], rsum, rtol=1e-12)
+
+
+def test_lds_kernel_refused_when_not_eligible(need_gpu):
+    m = make_model("FrozenLakeContinuous", seed=0, size=5, p_frozen=0.9)
+    env = BatchedMDP([m], rng_mode=L.RNG_PHILOX, with_dp=False)
+    env.set_rollout_kernel(L.ROLLOUT_LDS)
+    env.reset()
+    with pytest.raises(L.CmdpError) as ei:
+        env.rollout(100)
+    assert ei.value.code == L.ERR_UNSUPPORTED
+    env.set_rollout_kernel(L.ROLLOUT_AUTO)
+    env.rollout(100)
+    env.close()
+
+
 def test_vi_frozenlake20_vs_reference(need_gpu):
     """Config C3 slice: FrozenLake 20x20 discounted VI; Jacobi (the scheme the reference's rule selects)
     bit-exact incl. sweep counts; Gauss-Seidel within tolerance (the reference's BLAS summation order is
@@ -188,6 +234,37 @@ def test_vi_frozenlake20_vs_reference(need_gpu):
         np.testing.assert_allclose(dp.split_states(Vg)[i], z[k + "pe_gs_V"], **VTOL)
         assert abs(int(swg[i]) - c["pe_gs_sweeps"]) <= 1
     dp.close()
+
+
+def test_register_resident_sweeps_equal_workgroup_kernel_and_oracle(need_gpu):
+    """K2R (CSR in registers) vs K2 (CSR in LDS/HBM) vs the oracle on A = 2, 3, 4, ragged batches, VI and PE."""
+    batches = [
+        [make_model("DeepSeaContinuous", seed=s, size=sz, p_rand=0.2) for s, sz in ((0, 9), (1, 14), (2, 23))],
+        [make_model("MiniGridEmptyContinuous", seed=s, size=sz, p_rand=0.1, p_lazy=0.05) for s, sz in ((0, 4), (1, 7), (2, 9))],
+        [make_model("FrozenLakeContinuous", seed=s, size=sz, p_frozen=0.9, p_rand=0.1) for s, sz in ((0, 6), (1, 17), (2, 30))],
+        [make_model("MiniGridRoomsContinuous", seed=s, room_size=3, n_rooms=4, p_rand=0.3, p_lazy=0.1) for s in (0, 1)],
+    ]
+    for models in batches:
+        A = models[0].n_actions
+        dp = BatchedMDP(models, with_env=False)
+        outs = {}
+        for which in (L.DP_WORKGROUP, L.DP_REGISTER):
+            dp.set_dp_kernel(which)
+            pis = [np.random.RandomState(5 + i).dirichlet(np.ones(A), m.n_states).astype(np.float32) for i, m in enumerate(models)]
+            outs[which] = (dp.value_iteration(0.99, 1e-5, L.SCHEME_JACOBI), dp.policy_evaluation(pis, 0.95, 1e-6, L.SCHEME_JACOBI))
+        for x, y in zip(outs[L.DP_WORKGROUP], outs[L.DP_REGISTER]):
+            for u, v in zip(x, y):
+                np.testing.assert_array_equal(u, v)
+        (Q, V, sw), (Qp, Vp, swp) = outs[L.DP_REGISTER]
+        for i, m in enumerate(models):
+            oQ, oV, oit, _ = O.vi_discounted(m.n_states, A, m.csr(), m.reward_matrix(), 0.99, 1e-5, 1)
+            np.testing.assert_array_equal(dp.split_states(V)[i], oV)
+            np.testing.assert_array_equal(dp.split_rows(Q)[i].reshape(-1, A), oQ)
+            assert sw[i] == oit
+            oQ, oV, oit, _ = O.pe_discounted(m.n_states, A, m.csr(), m.reward_matrix(), pis[i], 0.95, 1e-6, 1)
+            np.testing.assert_array_equal(dp.split_states(Vp)[i], oV)
+            assert swp[i] == oit
+        dp.close()
 
 
 def test_episodic_dp_vs_reference(need_gpu):
