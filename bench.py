@@ -194,11 +194,16 @@ def main():
     bytes_per_step = 8 + 8 * 1 + 28
     algo_bytes = bytes_per_step * B * args.launch_steps
     achieved = algo_bytes / avg_launch_s / 1e9
+    # HBM bytes per launch from the PMC counters: they need their own rocprofv3 passes (--pmc FETCH_SIZE,
+    # --pmc WRITE_SIZE), so the figure is read from the committed summary of those passes when the workload
+    # is the one they were collected on; null otherwise.
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r01_rollout_pmc.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            j = json.load(open(pmc))
+            if j.get("transitions_per_launch") == B * args.launch_steps and args.size == 30:
+                traffic = j.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -223,7 +228,7 @@ def main():
             "build_s": round(t_build, 2),
         },
         "roofline": {
-            "bound": "hbm", "kernel": "k_rollout<0,false>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": "k_rollout_lds" if args.rollout_kernel != 1 else "k_rollout<0,false>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_transition": bytes_per_step, "accounting": "SURVEY 8(d) CSR figure (44 B/transition)",
             "launch_ms_avg": avg_launch_s * 1e3, "launch_ms_min": float(np.min(launch_ms)),
