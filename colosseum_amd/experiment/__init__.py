@@ -1,0 +1,1 @@
+from .mdp_loop import InMemoryLogger, MDPLoop, MDPSpec, make_mdp_spec  # noqa: F401

@@ -1,0 +1,256 @@
+"""GpuMDP: one MDP instance behind the reference's `BaseMDP` call surface.
+
+What agents, `MDPLoop`, `make_mdp_spec` and `random_loop` touch in the reference
+(colosseum/experiment/agent_mdp_interaction.py:140-147,219,224,243-245,295-297,326-386,519-575;
+colosseum/utils/acme/specs.py:29-40) exists here with the same names, argument meaning and error behaviour; every
+`reset`/`step` is one call through the C ABI (`cmdp_reset`, `cmdp_step`) and every value function comes from the HIP
+dynamic-programming kernels.  The per-(s,a) MT19937 sampler streams of the reference live on the device
+(`CMDP_RNG_MT_COMPAT`), so trajectories are bit-identical to the reference for the same constructor arguments.
+
+Class factories with the reference's class names are generated at the bottom (`DeepSeaEpisodic`, ...)."""
+from typing import Dict, Tuple
+
+import numpy as np
+
+from .. import _lib as L
+from .. import timestep as ts_
+from ..batched import BatchedMDP
+from ..dynamic_programming import get_policy_from_q_values
+from .registry import make_model, split_class_name
+
+
+class GpuMDP:
+    _cls_name = None
+
+    def __init__(self, cls_name: str = None, **kwargs):
+        cls_name = cls_name or self._cls_name
+        self._model = make_model(cls_name, **kwargs)
+        self._family_name, self._episodic = split_class_name(cls_name)
+        m = self._model
+        self._env = BatchedMDP([m], rng_mode=L.RNG_MT_COMPAT)
+        self.n_states, self.n_actions = m.n_states, m.n_actions
+        self.rewards_range = self._rewards_range = tuple(m.rewards_range)
+        self.r_min, self.r_max = self.rewards_range
+        self.emission_map = None
+        self.is_tabular = True
+        self._seed = kwargs.get("seed")
+        self.parameters = dict(kwargs)
+        nodes = [tuple(int(x) for x in n) for n in m.nodes]
+        self.index_to_node = dict(enumerate(nodes))
+        self.node_to_index = {n: i for i, n in enumerate(nodes)}
+        self.starting_nodes = [self.index_to_node[int(s)] for s in m.start_states]
+        self.starting_states = [int(s) for s in m.start_states]
+        self.starting_state_distribution = np.zeros(self.n_states)
+        self.starting_state_distribution[m.start_states] = m.start_probs
+        self.starting_states_and_probs = list(zip(self.starting_states, m.start_probs.tolist()))
+        self.h = 0
+        self.cur_node = None
+        self.last_starting_node = None
+        self.last_edge = None
+        self._cache: Dict[str, object] = {}
+        if not self._episodic:
+            self.random_policy = np.ones((self.n_states, self.n_actions), np.float32) / self.n_actions
+        # `necessary_reset` is created by the first reset(), exactly like the reference (mdp/base.py:1272): step()
+        # before reset() raises AttributeError there and here
+
+    # -- static facts ---------------------------------------------------------------------------------------
+    def is_episodic(self) -> bool:
+        return self._episodic
+
+    @property
+    def H(self) -> int:
+        if not self._episodic:
+            raise AttributeError("H is defined for episodic MDPs only")
+        return self._model.H
+
+    def action_spec(self):
+        return ts_.DiscreteArray(self.n_actions, name="action")
+
+    def observation_spec(self):
+        return ts_.DiscreteArray(self.n_states, name="observation")
+
+    def reward_spec(self):
+        return ts_.Array(shape=(), dtype=float, name="reward")
+
+    def discount_spec(self):
+        return ts_.BoundedArray(shape=(), dtype=float, minimum=0.0, maximum=1.0, name="discount")
+
+    # -- interaction (colosseum/mdp/base.py:1268-1355) -----------------------------------------------------------
+    def reset(self):
+        obs = int(self._env.reset()[0])
+        self.necessary_reset = False
+        self.h = 0
+        self.cur_node = self.last_starting_node = self.index_to_node[obs]
+        return ts_.restart(obs)
+
+    def step(self, action, auto_reset=False):
+        if auto_reset and self.necessary_reset:
+            return self.reset()
+        assert not self.necessary_reset  # AttributeError before the first reset(), as in the reference
+        action = int(action)
+        obs, rew, st = self._env.step([action], False)
+        self.h += 1
+        cur, _, _ = self._env.state()
+        old = self.cur_node
+        self.cur_node = self.index_to_node[int(cur[0])]
+        self.last_edge = old, self.cur_node
+        reward = float(rew[0])
+        if st[0] == 2:
+            self.necessary_reset = True
+            return ts_.termination(reward=reward, observation=-1)
+        return ts_.transition(reward=reward, observation=int(obs[0]))
+
+    def random_step(self, auto_reset=False):
+        """mdp/base.py:1341-1355 draws the action from the MDP's own numpy stream, which the construction also
+        consumed; a stream positioned after construction is not kept on the host, so this draws from a generator
+        seeded like the reference's but is NOT draw-for-draw identical (documented deviation)."""
+        if "rand" not in self._cache:
+            self._cache["rand"] = np.random.RandomState(self._seed)
+        action = int(self._cache["rand"].randint(self.n_actions))
+        return self.step(action, auto_reset), action
+
+    def get_visitation_counts(self, state_only=True):
+        vs, vsa = self._env.visits()
+        if state_only:
+            return {self.index_to_node[i]: int(vs[i]) for i in range(self.n_states)}
+        vsa = vsa.reshape(self.n_states, self.n_actions)
+        return {(self.index_to_node[i], a): int(vsa[i, a]) for i in range(self.n_states) for a in range(self.n_actions)}
+
+    def reset_visitation_counts(self):
+        self._env.reset_visits()
+
+    # -- tables and value functions ------------------------------------------------------------------------------
+    @property
+    def transition_matrix_and_rewards(self) -> Tuple[np.ndarray, np.ndarray]:
+        return self._model.dense()
+
+    @property
+    def T(self):
+        return self._model.dense()[0]
+
+    @property
+    def R(self):
+        return self._model.dense()[1]
+
+    def _memo(self, key, fn):
+        if key not in self._cache:
+            self._cache[key] = fn()
+        return self._cache[key]
+
+    def _vi(self, R=None):
+        if self._episodic:
+            H, S, A = self.H, self.n_states, self.n_actions
+            Q, V = self._env.episodic_value_iteration(R=None if R is None else [R])
+            return Q.reshape(H + 1, S, A), V.reshape(H + 1, S)
+        Q, V, _ = self._env.value_iteration(R=None if R is None else [R])  # gamma .99, eps 1e-3: reference defaults
+        return Q.reshape(self.n_states, self.n_actions), V
+
+    def _pe(self, policy):
+        if self._episodic:
+            H, S, A = self.H, self.n_states, self.n_actions
+            Q, V = self._env.episodic_policy_evaluation([np.asarray(policy, np.float32)])
+            return Q.reshape(H + 1, S, A), V.reshape(H + 1, S)
+        Q, V, _ = self._env.policy_evaluation([np.asarray(policy, np.float32)])
+        return Q.reshape(self.n_states, self.n_actions), V
+
+    def get_value_functions(self, policy):
+        return self._pe(policy)
+
+    @property
+    def optimal_value_functions(self):
+        return self._memo("opt", self._vi)
+
+    def get_optimal_policy(self, stochastic_form: bool):
+        return self._memo(("opt_pi", stochastic_form),
+                          lambda: get_policy_from_q_values(self.optimal_value_functions[0], stochastic_form))
+
+    def get_worst_policy(self, stochastic_form: bool):
+        return self._memo(("worst_pi", stochastic_form),
+                          lambda: get_policy_from_q_values(self._vi(-self.R)[0], stochastic_form))
+
+    @property
+    def worst_value_functions(self):
+        def f():
+            pol = self.get_worst_policy(True)
+            return self._pe(pol[: self.H] if self._episodic else pol)
+
+        return self._memo("worst", f)
+
+    @property
+    def random_value_functions(self):
+        def f():
+            if self._episodic:
+                pol = np.ones((self.H, self.n_states, self.n_actions), np.float32) / self.n_actions
+            else:
+                pol = self.random_policy
+            return self._pe(pol)
+
+        return self._memo("rand", f)
+
+    # -- episodic baselines (colosseum/mdp/base_finite.py:210-253,339-375) ------------------------------------------
+    def get_optimal_policy_starting_value(self, node):
+        return self.optimal_value_functions[1][0, self.node_to_index[node]]
+
+    def get_worst_policy_starting_value(self, node):
+        return self.worst_value_functions[1][0, self.node_to_index[node]]
+
+    def get_random_policy_starting_value(self, node):
+        return self.random_value_functions[1][0, self.node_to_index[node]]
+
+    def get_minimal_regret_for_starting_node(self, node):
+        return self.get_optimal_policy_starting_value(node) - self.get_worst_policy_starting_value(node)
+
+    def _episodic_average(self, getter):
+        acc = 0.0
+        for sn, p in zip(self.starting_nodes, self._model.start_probs.tolist()):
+            acc += p * getter(sn)
+        return acc / self.H
+
+    @property
+    def episodic_optimal_average_reward(self):
+        return self._memo("eoar", lambda: self._episodic_average(self.get_optimal_policy_starting_value))
+
+    @property
+    def episodic_worst_average_reward(self):
+        return self._memo("ewar", lambda: self._episodic_average(self.get_worst_policy_starting_value))
+
+    @property
+    def episodic_random_average_reward(self):
+        return self._memo("erar", lambda: self._episodic_average(self.get_random_policy_starting_value))
+
+    # -- hardness (continuous setting; colosseum/mdp/base.py:996-1016,1060-1081) -----------------------------------
+    @property
+    def diameter(self):
+        if self._episodic:
+            raise NotImplementedError("episodic diameter (hardness/measures/diameter.py:193-318) is not built yet")
+        return self._memo("diam", lambda: float(self._env.diameter()[0][0]))
+
+    @property
+    def value_norm(self):
+        if self._episodic:
+            raise NotImplementedError("continuous-form value norm of episodic MDPs is not built yet")
+
+        def f():
+            m = self._model
+            if (np.diff(m.sp_ptr) == 1).all() and m.deterministic_rewards:
+                return 0.0  # mdp/base.py:1070-1074
+            return float(self._env.value_norm(self.optimal_value_functions[1])[0])
+
+        return self._memo("vnorm", f)
+
+    def close(self):
+        self._env.close()
+
+
+def _make_class(name):
+    return type(name, (GpuMDP,), {"_cls_name": name, "__doc__": f"`{name}` with the reference's constructor keywords."})
+
+
+DeepSeaEpisodic = _make_class("DeepSeaEpisodic")
+DeepSeaContinuous = _make_class("DeepSeaContinuous")
+FrozenLakeEpisodic = _make_class("FrozenLakeEpisodic")
+FrozenLakeContinuous = _make_class("FrozenLakeContinuous")
+MiniGridEmptyEpisodic = _make_class("MiniGridEmptyEpisodic")
+MiniGridEmptyContinuous = _make_class("MiniGridEmptyContinuous")
+MiniGridRoomsEpisodic = _make_class("MiniGridRoomsEpisodic")
+MiniGridRoomsContinuous = _make_class("MiniGridRoomsContinuous")

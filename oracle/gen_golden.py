@@ -20,6 +20,7 @@ Fixture groups:
   G4  FrozenLakeContinuous 20x20 discounted VI / PE: V, Q, sweep counts under both schemes
   G5  hardness known-answer table lifted from benchmark/cached_hardness_measures/*.txt
   G6  episodic/continuous diameter + value-norm recomputed by the reference here (small cases)
+  G7  MDPLoop + QLearningEpisodic logger rows and action stream (config C1, plumbing)
 """
 import json
 import os
@@ -459,7 +460,65 @@ def g6():
         json.dump(rows, f, indent=0)
 
 
-GROUPS = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6)
+def _import_reference_qlearning():
+    """colosseum.agent.agents.episodic's package __init__ imports TensorFlow / sonnet / bsuite agents; register
+    bare package modules with the real __path__ and import the tabular agent's module directly."""
+    import importlib
+    import types
+
+    base = os.path.join(ref_env.REFERENCE, "colosseum", "agent")
+    import colosseum.agent  # noqa: F401
+
+    for sub in ("agents", "agents.episodic"):
+        name = "colosseum.agent." + sub
+        if name not in sys.modules:
+            try:
+                importlib.import_module(name)
+            except Exception:
+                m = types.ModuleType(name)
+                m.__path__ = [os.path.join(base, *sub.split("."))]
+                sys.modules[name] = m
+    from colosseum.agent.agents.episodic.q_learning import QLearningEpisodic
+
+    return QLearningEpisodic
+
+
+def g7():
+    """Config C1 (plumbing): the reference's MDPLoop driving its QLearningEpisodic (tuned hyper-parameters of
+    benchmark/cached_hyperparameters/agent_configs/QLearningEpisodic.gin) on DeepSeaEpisodic; the logger rows
+    (18 indicators, rounded to 5 decimals by the loop) and the action stream are the golden outputs."""
+    from colosseum.experiment.agent_mdp_interaction import MDPLoop
+    from colosseum.utils.acme.specs import make_mdp_spec
+
+    QLearningEpisodic = _import_reference_qlearning()
+    hp = dict(p=0.05, UCB_type="bernstein", c_1=0.9415278732894797, c_2=0.013873778519317169,
+              min_at=0.07263563483119442)
+    cases = []
+    for mdp_kw, T, log_every in ((dict(seed=0, size=8), 20_000, 1_000), (dict(seed=3, size=5, p_rand=0.2), 6_000, 500)):
+        mdp = DeepSeaEpisodic(**mdp_kw)
+        agent = QLearningEpisodic(seed=mdp_kw["seed"], mdp_specs=make_mdp_spec(mdp), optimization_horizon=T, **hp)
+        actions = []
+        sel = agent.select_action
+
+        def select_action(ts, h, _sel=sel, _log=actions):
+            a = _sel(ts, h)
+            _log.append(int(a))
+            return a
+
+        agent.select_action = select_action
+        loop = MDPLoop(mdp, agent)
+        last_training_step, last_logs = loop.run(T=T, log_every=log_every)
+        rows = [{k: float(v) for k, v in r.items() if k != "steps_per_second"} for r in loop.logger.data]
+        cases.append(dict(mdp_cls="DeepSeaEpisodic", mdp_kwargs=mdp_kw, agent="QLearningEpisodic",
+                          agent_kwargs=dict(seed=mdp_kw["seed"], optimization_horizon=T, **hp), T=T, log_every=log_every,
+                          last_training_step=int(last_training_step), rows=rows, actions=actions,
+                          Q_final=np.asarray(agent._mdp_model.Q, np.float64).round(7).tolist()))
+        print("   ", mdp_kw, "rows", len(rows), "cumulative_regret", rows[-1]["cumulative_regret"])
+    with open(os.path.join(OUT, "G7_mdploop_qlearning.json"), "w") as f:
+        json.dump(cases, f)
+
+
+GROUPS = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

@@ -1,3 +1,7 @@
+"""No-op stand-in for ray.tune (absent): only the names the reference's agent classes mention in annotations and
+hyper-parameter search-space helpers."""
+
+
 class _S:
     def __init__(self, *a, **k):
         pass
@@ -10,8 +14,16 @@ def uniform(*a, **k):
 choice = randint = loguniform = quniform = uniform
 
 
-class sample:
+class _Sample:
     Domain = _S
     Float = _S
     Integer = _S
     Categorical = _S
+
+
+class _Search:
+    sample = _Sample
+
+
+search = _Search
+sample = _Sample
