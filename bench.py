@@ -6,7 +6,7 @@ instances, random policy + value-iteration sweeps/s), one rank per GPU.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-A "step" is one fused rollout launch: `--launch-steps` (default 1000) transitions of every instance of the
+A "step" is one fused rollout launch: `--launch-steps` (default 5000) transitions of every instance of the
 rank's shard (default 65 536 instances per GPU -> weak scaling), inputs resident in HBM.  K timed steps are
 bracketed by barrier + device synchronise on both sides, the max over ranks is taken, rank 0 prints ONE JSON
 line.  `value` = transitions of all ranks / that time.
@@ -97,9 +97,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--instances", type=int, default=65536, help="instances per GPU (weak scaling)")
     ap.add_argument("--size", type=int, default=30)
-    ap.add_argument("--launch-steps", type=int, default=1000, help="transitions per instance per launch")
+    ap.add_argument("--launch-steps", type=int, default=5000, help="transitions per instance per launch (one bench step)")
     ap.add_argument("--vi-instances", type=int, default=4096, help="FrozenLake instances per GPU for the VI leg (0: skip)")
-    ap.add_argument("--cpu-instances", type=int, default=16384, help="instances of the CPU-oracle sample (0: skip)")
+    ap.add_argument("--cpu-instances", type=int, default=4096, help="instances of the CPU-oracle sample (0: skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--lds-groups", type=int, default=0, help="LDS rollout workgroups per CU (0: library default)")
     ap.add_argument("--rollout-kernel", type=int, default=0, help="0 auto, 1 HBM tables, 2 LDS-resident")

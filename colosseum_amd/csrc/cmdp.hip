@@ -321,14 +321,15 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
         p.rows_max = rows_max;
         p.off_rcode = (rows_max * 2 + 3) & ~3;
         p.off_cnt = p.off_rcode + ((rows_max + 3) & ~3);
-        p.slot_bytes = p.off_cnt + (((rows_max + 1) / 2) * 4);
-        const int fixed = 256 * 8 + 64 * 4;
+        p.slot_bytes = p.off_cnt + (((rows_max + 1) / 2) * 4) + 4;  // + the walker's dummy count dword
+        const int fixed = K1L_FIXED;
+        const int per_inst = p.slot_bytes + 2 * K1L_CH;  // tables + count deltas + two action-ring chunks
         // two workgroups per CU when that keeps >= 12 instances each: one group's staging / flush streams
         // overlap the other group's walk
-        p.G = std::min<int>(64, (kLdsBudget - fixed) / p.slot_bytes);
-        const int g2 = std::min<int>(64, (kLdsBudget / 2 - fixed) / p.slot_bytes);
+        p.G = std::min<int>(64, (kLdsBudget - fixed) / per_inst);
+        const int g2 = std::min<int>(64, (kLdsBudget / 2 - fixed) / per_inst);
         if (g2 >= 12) p.G = g2;
-        h->lds_G1 = std::min<int>(64, (kLdsBudget - fixed) / p.slot_bytes);
+        h->lds_G1 = std::min<int>(64, (kLdsBudget - fixed) / per_inst);
         h->lds_G2 = g2;
         p.n_codes = (int)vals.size();
         if (p.G >= 8) {
@@ -343,7 +344,7 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
           HIP_TRY(h->d_rvals.upload(vals.data(), vals.size(), st));
           p.next16 = h->d_next16.p + 8; p.rcode = h->d_rcode.p + 16; p.rvals = h->d_rvals.p;
           h->lds_plan = p;
-          h->lds_bytes = (size_t)fixed + (size_t)p.G * p.slot_bytes;
+          h->lds_bytes = (size_t)fixed + (size_t)p.G * per_inst;
           h->lds_ok = true;
           HIP_TRY(hipStreamSynchronize(st));  // staging vectors die with this scope
         }
@@ -546,7 +547,7 @@ int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
     const int g = value == 1 ? h->lds_G1 : h->lds_G2;
     if (g < 1) return fail(CMDP_ERR_INVALID, "no room for %lld workgroups per CU", (long long)value);
     h->lds_plan.G = g;
-    h->lds_bytes = (size_t)(256 * 8 + 64 * 4) + (size_t)g * h->lds_plan.slot_bytes;
+    h->lds_bytes = (size_t)K1L_FIXED + (size_t)g * (h->lds_plan.slot_bytes + 2 * K1L_CH);
     return CMDP_OK;
   }
   if (option == CMDP_OPT_DP_KERNEL && value >= 0 && value <= 2) {

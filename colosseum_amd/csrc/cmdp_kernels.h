@@ -264,7 +264,16 @@ __device__ __forceinline__ void flush_counts(int32_t* __restrict__ dst, int tota
 // the staging / flush phases are pure streaming and must not serialise on HBM latency).
 #define K1L_UNROLL 8
 #define K1L_THREADS 256
+#define K1L_CH 256                      // transitions per action-ring chunk
+#define K1L_NRV 264                      // reward table entries in LDS: 256 codes + a zero entry (index 256) + pad
+#define K1L_FIXED (K1L_NRV * 8 + 64 * 4 + 64 * 8)   // rv2[K1L_NRV] f64, resets[64] i32, keys[64] uint2
 
+// Wavefront specialisation: lanes of wavefront 0 walk one instance each; wavefronts 1-3 are the random-policy
+// PRODUCERS -- they compute the Philox blocks of the NEXT chunk of K1L_CH transitions for all G instances into a
+// double-buffered LDS ring of action bytes while the walkers consume the current chunk, so the walker's
+// instruction stream is only: action byte, successor read (the one LDS load on the dependency chain), 16-bit count
+// add, reward add.  The walker is software-pipelined by hand: the bookkeeping of transition s-1 (count add, reward
+// table read) and the reward add of transition s-2 are issued while the successor read of transition s is in flight.
 __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPlan p, int64_t n_steps,
                                                             double* __restrict__ reward_sum,
                                                             int32_t* __restrict__ last_obs) {
@@ -272,9 +281,11 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
   const int tid = threadIdx.x;
   const int g0 = blockIdx.x * p.G;
   const int nb = min(p.G, t.B - g0);
-  double* rvals = reinterpret_cast<double*>(smem);                       // [256]
-  int32_t* resets = reinterpret_cast<int32_t*>(smem + 256 * 8);          // [64]
-  unsigned char* slots = smem + 256 * 8 + 64 * 4;
+  double* rv2 = reinterpret_cast<double*>(smem);                          // [256] reward value AFTER the range rescale
+  int32_t* resets = reinterpret_cast<int32_t*>(smem + K1L_NRV * 8);       // [64]
+  uint2* keys = reinterpret_cast<uint2*>(smem + K1L_NRV * 8 + 64 * 4);    // [64]
+  unsigned char* ring = smem + K1L_FIXED;                                 // [2][G][K1L_CH] action bytes
+  unsigned char* slots = ring + 2 * p.G * K1L_CH;
   const int A = t.A, H = t.H;
   // all instances of the batch have the same S (eligibility): the group's rows are one contiguous range
   const int64_t so0 = t.state_off[g0];
@@ -282,7 +293,10 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
   const int rows = S * A;
   const int64_t row00 = so0 * A;
   const int total_rows = nb * rows, total_states = nb * S;
-  for (int i = tid; i < p.n_codes; i += K1L_THREADS) rvals[i] = p.rvals[i];
+  // `r * (max - min) - min` (base.py:1205-1207) applied once per distinct value: the same two float64 operations
+  for (int i = tid; i < p.n_codes; i += K1L_THREADS) rv2[i] = p.rvals[i] * t.rscale - t.rmin;
+  if (tid == 0) rv2[256] = 0.0;  // what the walker's software pipeline adds before it holds a real reward
+  if (tid < nb) keys[tid] = t.philox_key[g0 + tid];
   // ---- stage the tables: 16-byte loads from the aligned-down address, K1L_UNROLL of them in flight per
   //      thread (the element arrays carry 16 bytes of slack at both ends, see cmdp_create) -----------------
   {
@@ -349,76 +363,122 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
   }
   const bool walker = tid < nb;
   const int b = g0 + (walker ? tid : 0);
-  const uint2 key = t.philox_key[b];
   const int32_t start = t.start_state[t.start_off[b]];
-  int32_t cur = t.cur[b], h = t.hstep[b], obs = cur;
-  unsigned long long nt = t.n_trans[b], nr = t.n_reset[b];
+  int32_t cur = t.cur[b], h = t.hstep[b];
+  // every instance of the group has its own transition counter; the producers need all of them
+  const unsigned long long nt0 = t.n_trans[b];
+  unsigned long long nr = t.n_reset[b];
   double sum = 0.0;
   const unsigned char* base = slots + (size_t)(walker ? tid : 0) * p.slot_bytes;
   const uint16_t* nx = reinterpret_cast<const uint16_t*>(base);
   const uint8_t* rc = base + p.off_rcode;
   uint32_t* cnt = reinterpret_cast<uint32_t*>(const_cast<unsigned char*>(base) + p.off_cnt);
-  // 16-bit deltas: at most 32768 transitions between two flushes
-  for (int64_t done = 0; done < n_steps;) {
-    const int64_t chunk = min((int64_t)32768, n_steps - done);
-    __syncthreads();
-    if (walker) {  // lanes of wavefront 0; the other wavefronts wait at the barrier below
-      int32_t n_resets = 0;
-      uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-      bool have = false;
-      for (int64_t s = 0; s < chunk; ++s) {
-        const int j = (int)(nt & 3);
-        if (!have || j == 0) {
-          uint32_t w[4];
-          philox4x32_10((uint32_t)(nt >> 2), (uint32_t)(nt >> 34), 2u, 0u, key.x, key.y, w);
-          w0 = w[0]; w1 = w[1]; w2 = w[2]; w3 = w[3];
-          have = true;
-        }
-        const uint32_t word = (j == 0) ? w0 : (j == 1) ? w1 : (j == 2) ? w2 : w3;
-        const int a = (int)(((uint64_t)word * (uint64_t)A) >> 32);
-        const int row = cur * A + a;
-        const int nxt = nx[row];
-        const double r = rvals[rc[row]] * t.rscale - t.rmin;  // `r * (max - min) - min`, base.py:1205-1207
-        sum += r;
-        // visit count of the ARRIVAL node under the action taken (base.py:1302-1303), 16-bit halves of a dword
-        const int crow = nxt * A + a;
-        atomicAdd(cnt + (crow >> 1), (crow & 1) ? 0x10000u : 1u);
-        ++nt;
-        ++h;
-        cur = nxt;
-        obs = nxt;
-        if (H > 0 && h >= H) {  // episodic termination followed at once by reset()
-          cur = start;
-          obs = start;
-          h = 0;
-          ++nr;
-          ++n_resets;
+  __syncthreads();
+
+  // producer: fills ring buffer `buf` with the actions of transitions [first, first + len) of every instance
+  auto produce = [&](int buf, int64_t first, int len) {
+    const int ptid = tid - 64;  // 0..191
+    const int per_slot = K1L_CH / 4 + 1;  // Philox blocks that can overlap a chunk window (unaligned start)
+    for (int item = ptid; item < nb * per_slot; item += K1L_THREADS - 64) {
+      const int slot = item / per_slot, qi = item - slot * per_slot;
+      const unsigned long long n0 = t.n_trans[g0 + slot] + (unsigned long long)first;  // first transition of the window
+      const unsigned long long q = (n0 >> 2) + (unsigned long long)qi;
+      const uint2 key = keys[slot];
+      uint32_t w[4];
+      philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), 2u, 0u, key.x, key.y, w);
+      unsigned char* dst = ring + ((size_t)buf * p.G + slot) * K1L_CH;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long long pos = (long long)(4 * q + j) - (long long)n0;
+        if (pos >= 0 && pos < len) dst[pos] = (unsigned char)(((uint64_t)w[j] * (uint64_t)A) >> 32);
+      }
+    }
+  };
+
+  int64_t done = 0;
+  int buf = 0;
+  if (n_steps > 0 && tid >= 64) produce(0, 0, (int)min((int64_t)K1L_CH, n_steps));
+  __syncthreads();
+  int since_flush = 0;
+  int32_t n_resets = 0, n_resets_total = 0;
+  // Software pipeline registers of the walker.  They start at neutral elements so that the steady-state body needs
+  // no predicates: +0.0 (x + 0.0 == x), the zero entry of the reward table, and a dummy count dword behind the
+  // slot's real counters (never flushed).
+  const int dummy_crow = 2 * ((p.rows_max + 1) / 2);
+  int pend_crow = dummy_crow, pend_code = 256;
+  double pend_val = 0.0;
+  const bool episodic = H > 0;
+  while (done < n_steps) {
+    const int len = (int)min((int64_t)K1L_CH, n_steps - done);
+    if (tid >= 64) {
+      const int64_t nfirst = done + len;
+      if (nfirst < n_steps) produce(buf ^ 1, nfirst, (int)min((int64_t)K1L_CH, n_steps - nfirst));
+    } else if (walker) {
+      const unsigned char* acts = ring + ((size_t)buf * p.G + tid) * K1L_CH;
+      for (int s0 = 0; s0 < len; s0 += 8) {
+        const uint2 aw = *reinterpret_cast<const uint2*>(acts + s0);  // eight action bytes, one LDS read
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (s0 + j < len) {  // wave-uniform; false only in the last group of a ragged chunk
+            const int a = (int)(((j < 4 ? aw.x : aw.y) >> (8 * (j & 3))) & 0xffu);
+            const int row = cur * A + a;
+            const int nxt = nx[row];  // the one load on the dependency chain
+            const int code = rc[row];
+            // bookkeeping of the two previous transitions while the successor read is in flight
+            sum += pend_val;             // rewards are added in transition order: bit-equal to the sequential sum
+            pend_val = rv2[pend_code];
+            // visit count of the ARRIVAL node under the action taken (base.py:1302-1303), 16-bit halves of a dword
+            atomicAdd(cnt + (pend_crow >> 1), (pend_crow & 1) ? 0x10000u : 1u);
+            pend_crow = nxt * A + a;
+            pend_code = code;
+            ++h;
+            const bool term = episodic && h >= H;  // episodic termination followed at once by reset()
+            cur = term ? start : nxt;
+            h = term ? 0 : h;
+            n_resets += term ? 1 : 0;
+          }
         }
       }
-      resets[tid] = n_resets;
+    }
+    done += len;
+    since_flush += len;
+    buf ^= 1;
+    const bool flush_now = (since_flush + K1L_CH > 32768) || done >= n_steps;  // 16-bit deltas
+    if (flush_now && tid < 64) {
+      if (walker) {  // drain the software pipeline before the counters are read
+        sum += pend_val;
+        sum += rv2[pend_code];
+        atomicAdd(cnt + (pend_crow >> 1), (pend_crow & 1) ? 0x10000u : 1u);
+        pend_crow = dummy_crow; pend_code = 256; pend_val = 0.0;
+        resets[tid] = n_resets;
+        n_resets_total += n_resets;
+        n_resets = 0;
+      }
     }
     __syncthreads();
-    // ---- flush the deltas into the HBM counters: 16-byte read-modify-writes (every counter has exactly one
-    //      owner; the partial chunks at the two ends of the group's range go element by element) ---------------
-    flush_counts<true>(t.visits_sa + row00, total_rows, rows, A, slots, p, resets, nullptr, tid);
-    flush_counts<false>(t.visits_s + so0, total_states, S, A, slots, p, resets, t.start_state + t.start_off[g0], tid);
-    __syncthreads();
-    for (int j = tid; j < nb * ((rows + 1) / 2); j += K1L_THREADS) {
-      const int slot = j / ((rows + 1) / 2), off = j - slot * ((rows + 1) / 2);
-      reinterpret_cast<uint32_t*>(slots + (size_t)slot * p.slot_bytes + p.off_cnt)[off] = 0u;
+    if (flush_now) {
+      // ---- flush the deltas into the HBM counters: 16-byte read-modify-writes (every counter has exactly one
+      //      owner; the partial chunks at the two ends of the group's range go element by element) -----------
+      flush_counts<true>(t.visits_sa + row00, total_rows, rows, A, slots, p, resets, nullptr, tid);
+      flush_counts<false>(t.visits_s + so0, total_states, S, A, slots, p, resets, t.start_state + t.start_off[g0], tid);
+      __syncthreads();
+      for (int j = tid; j < nb * ((rows + 1) / 2); j += K1L_THREADS) {
+        const int slot = j / ((rows + 1) / 2), off = j - slot * ((rows + 1) / 2);
+        reinterpret_cast<uint32_t*>(slots + (size_t)slot * p.slot_bytes + p.off_cnt)[off] = 0u;
+      }
+      since_flush = 0;
+      __syncthreads();
     }
-    done += chunk;
   }
   if (walker) {
     t.cur[b] = cur;
     t.hstep[b] = h;
-    t.n_trans[b] = nt;
-    t.n_reset[b] = nr;
+    t.n_trans[b] = nt0 + (unsigned long long)n_steps;
+    t.n_reset[b] = nr + (unsigned long long)n_resets_total;
     if (reward_sum) reward_sum[b] = sum;
-    if (last_obs) last_obs[b] = obs;
+    if (last_obs) last_obs[b] = cur;  // the state after the last transition (the start state after a termination)
   }
 }
-
 
 template <bool ROWS>
 __device__ __forceinline__ void flush_counts(int32_t* __restrict__ dst, int total, int per, int A, unsigned char* slots,
