@@ -242,6 +242,32 @@ class BatchedMDP:
         L.check(self._lib.cmdp_diameter(self._h, epsilon, scheme, max_sweeps, L.ptr(per), L.ptr(diam)))
         return diam, per
 
+    def diameter_episodic(self, epsilon=1e-3, max_sweeps=1_000_000):
+        """Episodic diameter of every instance (needs the batch to have been built from TabularModels or tables
+        that carry the starting states)."""
+        k = self._keep
+        if "start_off" in k:
+            soff, sst = k["start_off"], k["start_state"]
+            cum = k["start_cum"]
+            prob = np.diff(np.concatenate([[0.0], cum]))
+            prob[soff[:-1]] = cum[soff[:-1]]  # first entry of every instance
+        else:
+            models = self.models
+            ns = np.array([len(m.start_states) for m in models], np.int64)
+            soff = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+            sst = np.concatenate([m.start_states for m in models]).astype(np.int32)
+            prob = np.concatenate([m.start_probs for m in models])
+        if self.models is not None:  # exact probabilities rather than differences of accumulated ones
+            prob = np.concatenate([m.start_probs for m in self.models])
+        soff = np.ascontiguousarray(soff, np.int64)
+        sst = np.ascontiguousarray(sst, np.int32)
+        prob = np.ascontiguousarray(prob, np.float32)
+        per = np.zeros(int(self.state_off[-1]), np.float32)
+        diam = np.zeros(self.B, np.float32)
+        L.check(self._lib.cmdp_diameter_episodic(self._h, self.H, L.ptr(soff), L.ptr(sst), L.ptr(prob), epsilon,
+                                                 max_sweeps, L.ptr(per), L.ptr(diam)))
+        return diam, per
+
     def value_norm(self, V):
         v = L.carr(V, np.float32)
         assert v.size == self.state_off[-1]

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -834,6 +835,75 @@ int cmdp_diameter(cmdp_t* h, double epsilon, int scheme, int64_t max_sweeps, flo
   if (int rc = check_status(h, NS)) return rc;
   for (int b = 0; b < h->B; ++b) {
     float dmax = 0.0f;  // `diameter = 0` then max(...), diameter.py:99-105
+    for (int64_t s = h->state_off[b]; s < h->state_off[b + 1]; ++s) dmax = std::max(dmax, per[(size_t)s]);
+    diameter[b] = dmax;
+  }
+  if (per_target) std::memcpy(per_target, per.data(), sizeof(float) * NS);
+  return CMDP_OK;
+}
+
+int cmdp_diameter_episodic(cmdp_t* h, int H, const int64_t* start_off, const int32_t* start_state,
+                           const float* start_prob, double epsilon, int64_t max_sweeps, float* per_target,
+                           float* diameter) {
+  if (int rc = bind(h)) return rc;
+  if (!h->has_dp) return fail(CMDP_ERR_INVALID, "handle was created without the DP half");
+  if (!diameter || !start_off || !start_state || !start_prob) return fail(CMDP_ERR_INVALID, "null argument");
+  if (H < 2 || max_sweeps < 1) return fail(CMDP_ERR_INVALID, "H < 2 or max_sweeps < 1");
+  const int B = h->B, A = h->A;
+  const int64_t NS = h->n_states;
+  const size_t lds = sizeof(float) * (size_t)H * h->max_S;
+  if (lds > (size_t)kLdsBudget - 1024)
+    return fail(CMDP_ERR_UNSUPPORTED, "H*S = %d*%d floats do not fit the LDS-resident episodic sweep", H, h->max_S);
+  if (start_off[0] != 0) return fail(CMDP_ERR_INVALID, "start_off[0] != 0");
+  // rows of T_epi that are filled (mdp_creation.py:118-125): layer 0 = starting states, layer h = states with
+  // incoming mass in layer h-1, for h <= H-2; layer H-1 is the return to the starting states
+  std::vector<int64_t> ptr((size_t)h->n_rows + 1);
+  std::vector<int32_t> col((size_t)h->n_csr);
+  hipStream_t st = h->stream;
+  HIP_TRY(hipMemcpyAsync(ptr.data(), h->d_csr_ptr.p, sizeof(int64_t) * ptr.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(col.data(), h->d_csr_col.p, sizeof(int32_t) * col.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  std::vector<uint8_t> reach((size_t)H * NS, 0);
+  for (int b = 0; b < B; ++b) {
+    const int64_t so = h->state_off[b], S = h->state_off[b + 1] - so;
+    uint8_t* rb = reach.data() + (size_t)H * so;
+    if (start_off[b + 1] <= start_off[b]) return fail(CMDP_ERR_INVALID, "instance %d has no starting state", b);
+    for (int64_t i = start_off[b]; i < start_off[b + 1]; ++i) {
+      if (start_state[i] < 0 || start_state[i] >= S) return fail(CMDP_ERR_INVALID, "starting state out of range");
+      rb[start_state[i]] = 1;
+    }
+    for (int hh = 1; hh <= H - 2; ++hh)
+      for (int64_t s = 0; s < S; ++s)
+        if (rb[(size_t)(hh - 1) * S + s])
+          for (int a = 0; a < A; ++a) {
+            const int64_t r = (so + s) * A + a;
+            for (int64_t k = ptr[r]; k < ptr[r + 1]; ++k) rb[(size_t)hh * S + col[k]] = 1;
+          }
+  }
+  DevBuf<uint8_t> d_reach;
+  DevBuf<int64_t> d_soff;
+  DevBuf<int32_t> d_sstate;
+  DevBuf<float> d_sprob;
+  HIP_TRY(d_reach.upload(reach.data(), reach.size(), st));
+  HIP_TRY(d_soff.upload(start_off, B + 1, st));
+  HIP_TRY(d_sstate.upload(start_state, start_off[B], st));
+  HIP_TRY(d_sprob.upload(start_prob, start_off[B], st));
+  if (h->d_per_target.n < (size_t)NS) HIP_TRY(h->d_per_target.alloc(NS));
+  if (h->d_status.n < (size_t)NS) HIP_TRY(h->d_status.alloc(NS));
+  DpTables t{};
+  t.B = B; t.A = A; t.state_off = h->d_state_off.p; t.csr_ptr = h->d_csr_ptr.p; t.csr_col = h->d_csr_col.p;
+  t.csr_val = h->d_csr_val.p; t.R = h->d_R.p; t.unit_off = h->d_state_off.p; t.eps = epsilon; t.max_sweeps = max_sweeps;
+  t.per_target = h->d_per_target.p; t.status = h->d_status.p;
+  EpiDiamArgs e{H, d_soff.p, d_sstate.p, d_sprob.p, d_reach.p};
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_diam_episodic), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_diam_episodic, dim3((unsigned)NS), dim3(256), lds, st, t, e);
+  HIP_TRY(hipGetLastError());
+  std::vector<float> per((size_t)NS);
+  HIP_TRY(hipMemcpyAsync(per.data(), h->d_per_target.p, sizeof(float) * NS, hipMemcpyDeviceToHost, st));
+  if (int rc = check_status(h, NS)) return rc;  // synchronises; the upload buffers above die after this
+  for (int b = 0; b < B; ++b) {
+    float dmax = -INFINITY;  // `diameter = -np.inf`, diameter.py:203
     for (int64_t s = h->state_off[b]; s < h->state_off[b + 1]; ++s) dmax = std::max(dmax, per[(size_t)s]);
     diameter[b] = dmax;
   }

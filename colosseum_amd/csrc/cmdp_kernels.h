@@ -940,6 +940,109 @@ __global__ void __launch_bounds__(256) k_episodic(DpTables t, int H, float* __re
   }
 }
 
+// K5E: episodic diameter on the time-augmented state space (reference colosseum/hardness/measures/diameter.py:
+// 285-318 over the T_epi of colosseum/mdp/utils/mdp_creation.py:98-128).  One workgroup per (instance, target);
+// ETs[H][S] lives in LDS and is updated in place layer by layer (h = H-1 .. 1, one barrier per layer) exactly in
+// the reference's order; every target runs to diff < eps (the reference's second, running-maximum stopping rule
+// depends on the order in which targets are visited and is not reproduced -- SURVEY 8e).
+struct EpiDiamArgs {
+  int32_t H;
+  const int64_t* start_off;   // [B+1]
+  const int32_t* start_state; // [NS]
+  const float* start_prob;    // [NS] float32, as stored in T_epi[H-1]
+  const uint8_t* reach;       // per instance [H][S_b] at offset H*state_off[b]: row (h, s) of T_epi is filled
+};
+
+__global__ void __launch_bounds__(256) k_diam_episodic(DpTables t, EpiDiamArgs e) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ float red[2][4];
+  __shared__ float last_val;
+  int b, es;
+  unit_to_instance(t, blockIdx.x, b, es);
+  const int A = t.A, H = e.H;
+  const int64_t soff = t.state_off[b];
+  const int S = (int)(t.state_off[b + 1] - soff);
+  const int64_t row0 = soff * A;
+  const int64_t* ptr = t.csr_ptr + row0;
+  const uint8_t* reach = e.reach + (int64_t)H * soff;
+  const int64_t s0 = e.start_off[b];
+  const int n_start = (int)(e.start_off[b + 1] - s0);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float* ETs = reinterpret_cast<float*>(smem);  // [H][S]
+  for (int i = tid; i < H * S; i += 256) ETs[i] = 0.0f;
+  __syncthreads();
+  int64_t it = 0;
+  int status = -5;
+  while (it < t.max_sweeps) {
+    ++it;
+    float dmax = 0.0f;
+    if (tid == 0) {  // ETs[-1] = T[-1, 0, 0] @ (1 + ETs[0]): the start distribution row
+      float last = 0.0f;
+      for (int i = 0; i < n_start; ++i)
+        last = __fadd_rn(last, __fmul_rn(e.start_prob[s0 + i], __fadd_rn(1.0f, ETs[e.start_state[s0 + i]])));
+      last_val = last;
+    }
+    __syncthreads();
+    {
+      const float last = last_val;
+      float* El = ETs + (size_t)(H - 1) * S;
+      for (int s = tid; s < S; s += 256) {
+        dmax = fmaxf(dmax, fabsf(El[s] - last));
+        El[s] = last;
+      }
+    }
+    __syncthreads();
+    for (int h = H - 1; h >= 1; --h) {
+      const float* En = ETs + (size_t)h * S;
+      float* Ec = ETs + (size_t)(h - 1) * S;
+      for (int j = tid; j < S; j += 256) {
+        if (j == es) continue;
+        float best = 0.0f;
+        if (reach[(size_t)(h - 1) * S + j]) {
+          for (int a = 0; a < A; ++a) {
+            const int r = j * A + a;
+            float acc = 0.0f, p_es = 0.0f;
+            for (int64_t k = ptr[r]; k < ptr[r + 1]; ++k) {
+              const int c = t.csr_col[k];
+              const float v = t.csr_val[k];
+              if (c == es) { p_es = v; continue; }
+              acc = __fadd_rn(acc, __fmul_rn(v, __fadd_rn(1.0f, En[c])));
+            }
+            const float cand = __fadd_rn(p_es, acc);
+            best = (a == 0) ? cand : fminf(best, cand);
+          }
+        }
+        dmax = fmaxf(dmax, fabsf(Ec[j] - best));
+        Ec[j] = best;
+      }
+      __syncthreads();
+    }
+    dmax = wave_max(dmax);
+    if (lane == 0) red[it & 1][wave] = dmax;
+    __syncthreads();
+    const float diff = fmaxf(fmaxf(red[it & 1][0], red[it & 1][1]), fmaxf(red[it & 1][2], red[it & 1][3]));
+    if ((double)diff < t.eps) { status = 0; break; }
+  }
+  // cur_diam = max_s min_{h : ETs[h][s] > 0} ETs[h][s]
+  float cur = 0.0f;
+  for (int s = tid; s < S; s += 256) {
+    float mn = 3.0e38f;
+    for (int h = 0; h < H; ++h) {
+      const float v = ETs[(size_t)h * S + s];
+      if (v > 0.0f && v < mn) mn = v;
+    }
+    cur = fmaxf(cur, mn);
+  }
+  cur = wave_max(cur);
+  __syncthreads();
+  if (lane == 0) red[0][wave] = cur;
+  __syncthreads();
+  if (tid == 0) {
+    t.per_target[soff + es] = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    t.status[blockIdx.x] = status;
+  }
+}
+
 // K6: calculate_norm_discounted (reference colosseum/hardness/measures/value_norm.py:83-87):
 //   Ev[j,a] = sum_k T[j,a,k] V[k];  out = max_{i,a} sqrt( sum_j T[i,a,j] (V[j] - Ev[j,a])^2 )
 __global__ void __launch_bounds__(256) k_value_norm(DpTables t, const float* __restrict__ V, float* __restrict__ Ev,

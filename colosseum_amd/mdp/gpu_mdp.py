@@ -222,7 +222,7 @@ class GpuMDP:
     @property
     def diameter(self):
         if self._episodic:
-            raise NotImplementedError("episodic diameter (hardness/measures/diameter.py:193-318) is not built yet")
+            return self._memo("diam", lambda: float(self._env.diameter_episodic()[0][0]))
         return self._memo("diam", lambda: float(self._env.diameter()[0][0]))
 
     @property

@@ -199,6 +199,15 @@ int cmdp_pe_episodic(cmdp_t* h, int H, const float* pi, const float* R_override,
    NULL.  scheme as in cmdp_vi_discounted (AUTO = the rule applied to the instance's T). */
 int cmdp_diameter(cmdp_t* h, double epsilon, int scheme, int64_t max_sweeps,
                   float* per_target, float* diameter);
+/* get_diameter, episodic setting (colosseum/hardness/measures/diameter.py:193-234,285-318) on the
+   time-augmented transition array of get_episodic_transition_matrix_and_rewards
+   (colosseum/mdp/utils/mdp_creation.py:98-128), which is never materialised: H, the starting states
+   (start_off [B+1], start_state [NS], start_prob [NS] as float32) and the CSR define it.  Every target
+   runs to diff < epsilon; the reference's running-maximum early exit (order dependent) is not applied.
+   per_target [state_off[B]] may be NULL. */
+int cmdp_diameter_episodic(cmdp_t* h, int H, const int64_t* start_off, const int32_t* start_state,
+                           const float* start_prob, double epsilon, int64_t max_sweeps,
+                           float* per_target, float* diameter);
 /* calculate_norm_discounted (colosseum/hardness/measures/value_norm.py:83-87). V [state_off[B]]. */
 int cmdp_value_norm(cmdp_t* h, const float* V, float* out);
 

@@ -58,6 +58,9 @@ def lib():
                                                  C.c_int64, C.c_void_p, C.c_void_p]
         L.oracle_value_norm.restype = C.c_float
         L.oracle_value_norm.argtypes = [C.c_int, C.c_int, _i64p, _i32p, _f32p, _f32p]
+        L.oracle_diameter_episodic.restype = C.c_int
+        L.oracle_diameter_episodic.argtypes = [C.c_int, C.c_int, C.c_int, _i64p, _i32p, _f32p, C.c_int, _i32p, _f32p,
+                                               C.c_double, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
         L.oracle_batch_rollout.restype = C.c_int
         L.oracle_batch_rollout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double] + \
             [C.c_void_p] * 11 + [C.c_int64] + [C.c_void_p] * 4
@@ -190,6 +193,22 @@ def diameter_continuous(S, A, csr, eps=1e-3, scheme=0, max_sweeps=1_000_000):
     rc = L.oracle_diameter_continuous(S, A, ptr, col, val, eps, scheme, max_sweeps, _ptr(per), C.byref(d))
     if rc != 0:
         raise RuntimeError(f"oracle diameter failed ({rc})")
+    return float(d.value), per
+
+
+def diameter_episodic(model, eps=1e-3, use_running_max=True, max_sweeps=1_000_000):
+    """Episodic diameter of a TabularModel: (diameter, per-target values), single-thread reference order."""
+    L = lib()
+    ptr, col, val = _csr64(model.csr())
+    S, A, H = model.n_states, model.n_actions, model.H
+    per = np.zeros(S, np.float32)
+    d = C.c_double()
+    st = np.ascontiguousarray(model.start_states, np.int32)
+    sp = np.ascontiguousarray(model.start_probs, np.float32)  # `T_epi[H - 1, :, :, sn] = p` stores float32
+    rc = L.oracle_diameter_episodic(S, A, H, ptr, col, val, len(st), st, sp, eps, int(use_running_max), max_sweeps,
+                                    _ptr(per), C.byref(d))
+    if rc != 0:
+        raise RuntimeError(f"oracle episodic diameter failed ({rc})")
     return float(d.value), per
 
 

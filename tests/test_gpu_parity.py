@@ -343,3 +343,40 @@ def test_diameter_and_value_norm(need_gpu):
         assert vn[0] == pytest.approx(row["value_norm"], rel=5e-6, abs=1e-6), row
         assert vn[0] == O.value_norm(m.n_states, m.n_actions, m.csr(), V)
         dp.close()
+
+
+def test_episodic_diameter(need_gpu):
+    """Episodic diameter (time-augmented state space): GPU (every target to diff < eps) vs the oracle's two
+    variants (the reference's single-thread order with the running-max early exit, and pure convergence), vs the
+    values the reference recomputed here (G6) and the reference's cached values (G5)."""
+    import json
+    import os
+
+    from conftest import GOLDEN
+
+    rows = [r for r in json.load(open(os.path.join(GOLDEN, "G6_hardness_ref.json"))) if "Episodic" in r["cls"]]
+    kat = [r for r in json.load(open(os.path.join(GOLDEN, "G5_hardness_kat.json")))
+           if "Episodic" in r["cls"] and r["measure"] == "diameter"]
+    seen = set()
+    for r in kat:
+        key = (r["cls"], json.dumps({k: v for k, v in r["kwargs"].items() if k != "seed"}, sort_keys=True))
+        if key not in seen:
+            seen.add(key)
+            rows.append(dict(cls=r["cls"], kwargs=r["kwargs"], diameter=r["value"], cached=True))
+    checked = 0
+    for r in rows:
+        m = make_model(r["cls"], **r["kwargs"])
+        if m.n_states * m.H > 6000:
+            continue
+        dp = BatchedMDP([m, m], with_env=False)
+        diam, per = dp.diameter_episodic()
+        od, oper = O.diameter_episodic(m, use_running_max=False)
+        np.testing.assert_array_equal(dp.split_states(per)[0], oper)  # GPU == oracle, target by target
+        np.testing.assert_array_equal(dp.split_states(per)[1], oper)
+        assert diam[0] == np.float32(od) and diam[1] == diam[0]
+        od_ref, _ = O.diameter_episodic(m, use_running_max=True)
+        assert abs(od_ref - od) <= 0.01 + 1e-6  # the early exit stops at diff < 0.01
+        assert diam[0] == pytest.approx(r["diameter"], rel=5e-6, abs=1e-3 if r.get("cached") else 1e-5), r
+        checked += 1
+        dp.close()
+    assert checked >= 12

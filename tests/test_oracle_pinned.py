@@ -152,3 +152,28 @@ def test_cached_hardness_known_answers():
         checked[row["cls"]] = checked.get(row["cls"], 0) + 1
     assert set(checked) == {"DeepSeaContinuous", "FrozenLakeContinuous", "MiniGridEmptyContinuous", "MiniGridRoomsContinuous"}
     assert sum(checked.values()) >= 30
+
+
+def test_episodic_diameter_vs_reference_and_cached_values():
+    """Episodic diameter restatement (single-thread reference order, running-max early exit) against the values the
+    reference recomputed in the development container (G6, bit-equal) and its authors' cached files (G5)."""
+    rows = [r for r in json.load(open(os.path.join(GOLDEN, "G6_hardness_ref.json"))) if "Episodic" in r["cls"]]
+    for r in rows:
+        m = make_model(r["cls"], **r["kwargs"])
+        d, _ = O.diameter_episodic(m)
+        assert d == r["diameter"], r
+    kat = [r for r in json.load(open(os.path.join(GOLDEN, "G5_hardness_kat.json")))
+           if "Episodic" in r["cls"] and r["measure"] == "diameter"]
+    seen, classes = set(), set()
+    for r in kat:
+        key = (r["cls"], json.dumps({k: v for k, v in r["kwargs"].items() if k != "seed"}, sort_keys=True))
+        if key in seen:
+            continue
+        seen.add(key)
+        m = make_model(r["cls"], **r["kwargs"])
+        if m.n_states * m.H > 6000:
+            continue
+        d, _ = O.diameter_episodic(m)
+        assert d == pytest.approx(r["value"], rel=5e-6, abs=1e-3), r  # cached by the multi-process path: other order
+        classes.add(r["cls"])
+    assert classes == {"DeepSeaEpisodic", "FrozenLakeEpisodic", "MiniGridEmptyEpisodic", "MiniGridRoomsEpisodic"}
