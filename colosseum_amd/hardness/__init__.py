@@ -1,0 +1,63 @@
+"""Hardness measures of batches of MDPs on the GPU (reference colosseum/hardness/measures/*, called through
+`BaseMDP.diameter` / `.value_norm`, colosseum/mdp/base.py:996-1016,1042-1081).
+
+`diameter(models)` and `value_norm(models)` take TabularModels (colosseum_amd.mdp.make_model) and return one float
+per model.  Episodic MDPs use the time-augmented diameter and the value norm of their continuous form, as the
+reference does."""
+from typing import List, Sequence
+
+import numpy as np
+
+from .. import _lib as L
+from ..batched import BatchedMDP
+from ..dp_handle import DPBatch
+from ..mdp.builder import TabularModel
+from ..mdp.episodic import continuous_form
+
+
+def _vi_rule(S, A, nnz):
+    size = float(S) * A * S
+    return L.SCHEME_JACOBI if (size > 300 * 3 * 300 and nnz / size < 0.2) else L.SCHEME_GAUSS_SEIDEL
+
+
+def diameter(models: Sequence[TabularModel], epsilon: float = 1e-3) -> np.ndarray:
+    """`get_diameter` per model.  Models are grouped by (episodic?, H, A, scheme) into batches."""
+    out = np.zeros(len(models), np.float64)
+    groups = {}
+    for i, m in enumerate(models):
+        key = (m.H, m.n_actions, 0 if m.is_episodic else _vi_rule(m.n_states, m.n_actions, len(m.csr()[1])))
+        groups.setdefault(key, []).append(i)
+    for (H, A, scheme), idx in groups.items():
+        dp = BatchedMDP([models[i] for i in idx], with_env=False)
+        d = dp.diameter_episodic(epsilon)[0] if H > 0 else dp.diameter(epsilon, scheme)[0]
+        out[idx] = d
+        dp.close()
+    return out
+
+
+def value_norm(models: Sequence[TabularModel]) -> np.ndarray:
+    """`BaseMDP.discounted_value_norm`: 0 for fully deterministic MDPs, else
+    `calculate_norm_discounted(T, V*)` with V* = discounted_value_iteration(T, R) (gamma 0.99, eps 1e-3, the
+    reference's scheme rule) -- on (T_cf, R_cf) for episodic MDPs."""
+    out = np.zeros(len(models), np.float64)
+    problems: List = []
+    owner: List[int] = []
+    for i, m in enumerate(models):
+        if (np.diff(m.sp_ptr) == 1).all() and m.deterministic_rewards:
+            continue  # mdp/base.py:1070-1074
+        if m.is_episodic:
+            N, A, csr, R = continuous_form(m)
+        else:
+            N, A, csr, R = m.n_states, m.n_actions, m.csr(), m.reward_matrix()
+        problems.append((N, A, csr, R))
+        owner.append(i)
+    groups = {}
+    for j, (N, A, csr, R) in enumerate(problems):
+        groups.setdefault((A, _vi_rule(N, A, len(csr[1]))), []).append(j)
+    for (A, scheme), js in groups.items():
+        with DPBatch([problems[j] for j in js]) as dp:
+            Q, V, _ = dp.value_iteration(0.99, 1e-3, scheme, 1_000_000)
+            vn = dp.value_norm(V)
+        for j, v in zip(js, vn):
+            out[owner[j]] = v
+    return out

@@ -143,6 +143,7 @@ def build_model(
 
     order: Dict[Node, int] = {}  # G.nodes insertion order
     has_succ = set()  # nodes with at least one outgoing edge
+    adjacency: Dict[Node, Dict[Node, None]] = {}  # G.successors(node) order = order of first add_edge(node, .)
     action_map: Dict[Node, List[int]] = {}
     rdist_cache: Dict[Tuple[Node, int, Node], Tuple] = {}
     rows: Dict[Node, Dict[int, _Row]] = {}
@@ -173,6 +174,7 @@ def build_model(
         if next_node not in order:
             order[next_node] = len(order)
         has_succ.add(node)
+        adjacency.setdefault(node, {}).setdefault(next_node, None)
 
     def individual_transition(node, action) -> _Row:
         next_nodes, probs = [], []
@@ -280,6 +282,7 @@ def build_model(
     )
     model.extra["node_index"] = index
     model.extra["action_map"] = action_map
+    model.extra["successors"] = [[index[x] for x in adjacency[n]] for n in nodes]  # networkx adjacency order
     if episodic:
         model.H = _time_horizon(model, family, H)
     return model

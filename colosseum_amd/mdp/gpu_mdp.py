@@ -227,16 +227,9 @@ class GpuMDP:
 
     @property
     def value_norm(self):
-        if self._episodic:
-            raise NotImplementedError("continuous-form value norm of episodic MDPs is not built yet")
+        from ..hardness import value_norm
 
-        def f():
-            m = self._model
-            if (np.diff(m.sp_ptr) == 1).all() and m.deterministic_rewards:
-                return 0.0  # mdp/base.py:1070-1074
-            return float(self._env.value_norm(self.optimal_value_functions[1])[0])
-
-        return self._memo("vnorm", f)
+        return self._memo("vnorm", lambda: float(value_norm([self._model])[0]))
 
     def close(self):
         self._env.close()

@@ -380,3 +380,34 @@ def test_episodic_diameter(need_gpu):
         checked += 1
         dp.close()
     assert checked >= 12
+
+
+def test_hardness_module_against_cached_values(need_gpu):
+    """colosseum_amd.hardness on mixed batches (all four families, episodic and continuous, deterministic and Beta
+    rewards) against the reference's cached files: diameter and value norm."""
+    import json
+    import os
+
+    from conftest import GOLDEN
+    from colosseum_amd import hardness
+
+    kat = json.load(open(os.path.join(GOLDEN, "G5_hardness_kat.json")))
+    seen, pick = set(), {"diameter": [], "value_norm": []}
+    for r in kat:
+        if r["measure"] not in pick:
+            continue
+        key = (r["cls"], r["measure"], json.dumps({k: v for k, v in r["kwargs"].items() if k != "seed"}, sort_keys=True))
+        if key in seen:
+            continue
+        seen.add(key)
+        m = make_model(r["cls"], **r["kwargs"])
+        if m.n_states * max(m.H, 1) > 3000 or m.n_states > 300:
+            continue
+        pick[r["measure"]].append((r, m))
+    assert len(pick["diameter"]) >= 15 and len(pick["value_norm"]) >= 15
+    d = hardness.diameter([m for _, m in pick["diameter"]])
+    for (r, m), got in zip(pick["diameter"], d):
+        assert got == pytest.approx(r["value"], rel=5e-6, abs=1e-3), r
+    v = hardness.value_norm([m for _, m in pick["value_norm"]])
+    for (r, m), got in zip(pick["value_norm"], v):
+        assert got == pytest.approx(r["value"], rel=5e-6, abs=2e-6), r

@@ -177,3 +177,34 @@ def test_episodic_diameter_vs_reference_and_cached_values():
         assert d == pytest.approx(r["value"], rel=5e-6, abs=1e-3), r  # cached by the multi-process path: other order
         classes.add(r["cls"])
     assert classes == {"DeepSeaEpisodic", "FrozenLakeEpisodic", "MiniGridEmptyEpisodic", "MiniGridRoomsEpisodic"}
+
+
+def test_episodic_value_norm_continuous_form():
+    """Value norm of episodic MDPs = norm on the continuous form (T_cf, R_cf): host construction + oracle DP against
+    the reference's recomputed (G6) and cached (G5) values."""
+    from colosseum_amd.mdp.episodic import continuous_form
+
+    def vnorm(m):
+        if (np.diff(m.sp_ptr) == 1).all() and m.deterministic_rewards:
+            return 0.0
+        N, A, csr, R = continuous_form(m)
+        Q, V, _, _ = O.vi_discounted(N, A, csr, R, 0.99, 1e-3, 0)
+        return O.value_norm(N, A, csr, V)
+
+    for r in json.load(open(os.path.join(GOLDEN, "G6_hardness_ref.json"))):
+        if "Episodic" in r["cls"]:
+            assert vnorm(make_model(r["cls"], **r["kwargs"])) == pytest.approx(r["value_norm"], rel=1e-6, abs=1e-7), r
+    kat = [r for r in json.load(open(os.path.join(GOLDEN, "G5_hardness_kat.json")))
+           if "Episodic" in r["cls"] and r["measure"] == "value_norm"]
+    seen, n = set(), 0
+    for r in kat:
+        key = (r["cls"], json.dumps({k: v for k, v in r["kwargs"].items() if k != "seed"}, sort_keys=True))
+        if key in seen:
+            continue
+        seen.add(key)
+        m = make_model(r["cls"], **r["kwargs"])
+        if m.n_states * m.H > 3000:
+            continue
+        assert vnorm(m) == pytest.approx(r["value"], rel=2e-6, abs=1e-6), r
+        n += 1
+    assert n >= 8
