@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--vi-instances", type=int, default=4096, help="FrozenLake instances per GPU for the VI leg (0: skip)")
     ap.add_argument("--cpu-instances", type=int, default=4096, help="instances of the CPU-oracle sample (0: skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (CPU rehearsal of the N>1 path)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: ranks share the visible GPUs (device = local_rank %% n_devices)")
     ap.add_argument("--lds-groups", type=int, default=0, help="LDS rollout workgroups per CU (0: library default)")
     ap.add_argument("--rollout-kernel", type=int, default=0, help="0 auto, 1 HBM tables, 2 LDS-resident")
     args = ap.parse_args()
@@ -110,13 +112,30 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    # Host-side model construction of the VI leg first: it uses a fork()ed process pool, which must not happen
+    # after the HIP runtime / RCCL have been initialised in this process.
+    fl, fl_build_s = None, 0.0
+    if args.vi_instances > 0:
+        workers = max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
+        tb = time.time()
+        fl = frozenlake_dp_tables(np.arange(rank * args.vi_instances, (rank + 1) * args.vi_instances), 20, workers)
+        fl_build_s = time.time() - tb
+
     dist = None
+    coll_device = "cpu"
+    device_index = local_rank
     if world > 1:
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+        if args.share_gpu:
+            device_index = local_rank % max(1, torch.cuda.device_count())
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(device_index)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))  # RCCL over xGMI
+            coll_device = "cuda"
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from colosseum_amd import _lib as L
     from colosseum_amd.batched import BatchedMDP
@@ -124,7 +143,7 @@ def main():
 
     lib = L.load()
     assert lib.cmdp_device_count() > 0, "no HIP device visible: the product path has no CPU fallback"
-    L.check(lib.cmdp_set_device(local_rank))
+    L.check(lib.cmdp_set_device(device_index))
 
     def barrier():
         if dist is not None:
@@ -166,7 +185,7 @@ def main():
     if dist is not None:
         import torch
 
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -178,12 +197,14 @@ def main():
     if dist is not None:
         import torch
 
-        local = torch.from_numpy(episodes).cuda()
-        allv = torch.empty(world * B, dtype=torch.int64, device="cuda")
-        torch.cuda.synchronize()
+        local = torch.from_numpy(episodes).to(coll_device)
+        allv = torch.empty(world * B, dtype=torch.int64, device=coll_device)
+        if coll_device == "cuda":
+            torch.cuda.synchronize()
         g0 = time.perf_counter()
         dist.all_gather_into_tensor(allv, local)
-        torch.cuda.synchronize()
+        if coll_device == "cuda":
+            torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
         assert bool((allv[rank * B:(rank + 1) * B] == local).all())
 
@@ -208,7 +229,7 @@ def main():
             traffic = None
 
     line = {
-        "metric": "env steps/sec (whole node), DeepSea size=%d x %d instances/GPU, random policy" % (args.size, B),
+        "metric": "env steps/sec (whole node) + value-iteration sweeps/sec, DeepSea size=%d x%d" % (args.size, B),
         "value": value,
         "unit": "env steps/s",
         "n_gpus": world,
@@ -239,11 +260,9 @@ def main():
 
     # ---- VI leg (config C3): FrozenLake 20x20, gamma .99, eps 1e-6, the reference's own scheme rule --------
     if args.vi_instances > 0:
-        workers = max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
         tb = time.time()
-        fl = frozenlake_dp_tables(np.arange(rank * args.vi_instances, (rank + 1) * args.vi_instances), 20, workers)
         dp = BatchedMDP(tables=fl, with_env=False)
-        tb = time.time() - tb
+        tb = time.time() - tb + fl_build_s
         dp.value_iteration(0.99, 1e-6)  # warm-up (also sizes the device buffers)
         barrier()
         t1 = time.perf_counter()
@@ -254,10 +273,10 @@ def main():
         if dist is not None:
             import torch
 
-            tt = torch.tensor([vi_s, -sweeps], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([vi_s], dtype=torch.float64, device=coll_device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             vi_s = float(tt[0].item())
-            ts = torch.tensor([sweeps], dtype=torch.float64, device="cuda")
+            ts = torch.tensor([sweeps], dtype=torch.float64, device=coll_device)
             dist.all_reduce(ts)
             sweeps = float(ts.item())
         line["vi"] = {
