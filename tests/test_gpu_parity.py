@@ -411,3 +411,67 @@ def test_hardness_module_against_cached_values(need_gpu):
     v = hardness.value_norm([m for _, m in pick["value_norm"]])
     for (r, m), got in zip(pick["value_norm"], v):
         assert got == pytest.approx(r["value"], rel=5e-6, abs=2e-6), r
+
+
+def test_edge_cases(need_gpu):
+    """Zero-length rollouts, a single instance, B not a multiple of anything, many start states, a large sparse
+    instance that only the HBM-table kernel can take, masks, repeated resets, bad arguments."""
+    m = make_model("DeepSeaEpisodic", seed=0, size=4)
+    env = BatchedMDP([m], rng_mode=L.RNG_PHILOX)
+    with pytest.raises(AssertionError):
+        env.rollout(10)  # reset pending
+    o0 = env.reset()
+    out = env.rollout(0)
+    assert out["last_obs"][0] == o0[0] and out["reward_sum"][0] == 0.0
+    vs, vsa = env.visits()
+    assert vs.sum() == 1 and vsa.sum() == 0
+    env.reset()  # a second reset() visits the start state again (BaseMDP.reset, mdp/base.py:1275-1276)
+    assert env.visits()[0][m.start_states[0]] == 2
+    cur, h, nr = env.state()
+    assert cur[0] == m.start_states[0] and h[0] == 0 and not nr[0]
+    env.reset_visits()
+    assert env.visits()[0].sum() == 0
+    env.close()
+
+    # masked reset: only instance 1 is reset
+    ms = [make_model("DeepSeaEpisodic", seed=s, size=4) for s in range(3)]
+    env = BatchedMDP(ms, rng_mode=L.RNG_PHILOX, with_dp=False)
+    env.reset()
+    env.rollout(2)
+    env.reset(mask=np.array([0, 1, 0], np.uint8))
+    cur, h, nr = env.state()
+    assert h.tolist() == [2, 0, 2]
+    env.close()
+
+    # 12 start states, stochastic start sampler + stochastic rows, MT_COMPAT vs the oracle over several episodes
+    m = make_model("MiniGridEmptyEpisodic", seed=3, size=5, n_starting_states=4, p_rand=0.3)
+    env = BatchedMDP([m], rng_mode=L.RNG_MT_COMPAT, with_dp=False)
+    e = O.OracleEnv(m, rng_mode=0)
+    acts = np.random.RandomState(0).randint(0, 3, 5000).astype(np.int8)
+    assert env.reset()[0] == e.reset()
+    got = env.rollout(5000, acts[:, None], trace=True)
+    ref = e.rollout(5000, acts)
+    np.testing.assert_array_equal(got["obs"][:, 0], ref["obs"])
+    np.testing.assert_array_equal(env.visits()[0], e.visits()[0])
+    env.close()
+
+    # |S| = 11 532: too large for any LDS-resident path; HBM-table rollout + oracle, and DP must refuse loudly or work
+    big = make_model("MiniGridRoomsContinuous", seed=0, room_size=13, n_rooms=16, p_lazy=0.1, n_starting_states=2)
+    assert big.n_states > 10_000
+    env = BatchedMDP([big], rng_mode=L.RNG_PHILOX, philox_keys=[5])
+    env.reset()
+    got = env.rollout(3000, None, trace=True)
+    e = O.OracleEnv(big, rng_mode=1, philox_key=5)
+    e.reset()
+    ref = e.rollout(3000)
+    np.testing.assert_array_equal(got["obs"][:, 0], ref["obs"])
+    Q, V, sw = env.value_iteration(0.9, 1e-4, L.SCHEME_JACOBI)  # V ping-pong of 92 KB still fits LDS
+    oQ, oV, oit, _ = O.vi_discounted(big.n_states, 3, big.csr(), big.reward_matrix(), 0.9, 1e-4, 1)
+    np.testing.assert_array_equal(V, oV)
+    assert sw[0] == oit
+    env.close()
+
+    with pytest.raises(ValueError):
+        BatchedMDP([make_model("DeepSeaEpisodic", seed=0, size=4), make_model("DeepSeaEpisodic", seed=0, size=5)])
+    with pytest.raises(L.CmdpError):  # stochastic reward tables are rejected, not silently replaced by their means
+        BatchedMDP([make_model("DeepSeaEpisodic", seed=0, size=4, make_reward_stochastic=True)])
