@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: ranks share the visible GPUs (device = local_rank %% n_devices)")
     ap.add_argument("--lds-groups", type=int, default=0, help="LDS rollout workgroups per CU (0: library default)")
     ap.add_argument("--rollout-kernel", type=int, default=0, help="0 auto, 1 HBM tables, 2 LDS-resident")
+    ap.add_argument("--layout", default="csr", choices=["csr", "dense"],
+                    help="csr (default, fastest) or dense = per-instance float32 P[s,a,:] rows in HBM (north-star layout)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -153,9 +155,11 @@ def main():
     B = args.instances
     seeds = np.arange(rank * B, (rank + 1) * B, dtype=np.int64)
     t_build = time.time()
-    tables = deepsea_episodic_tables(seeds, args.size)
+    dense = args.layout == "dense"
+    tables = deepsea_episodic_tables(seeds, args.size, with_dp=dense)
     keys = seeds.astype(np.uint64)  # Philox key = global instance id
-    env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX, philox_keys=keys)
+    env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX, philox_keys=keys,
+                     layout=L.LAYOUT_DENSE if dense else L.LAYOUT_CSR)
     env.reset()
     if args.rollout_kernel:
         env.set_rollout_kernel(args.rollout_kernel)
@@ -212,7 +216,7 @@ def main():
     value = total_steps / elapsed
     avg_launch_s = float(np.mean(launch_ms)) * 1e-3
     # SURVEY 8(d), CSR companion figure: 8 (row pointer pair) + 8*nnz(s,a) + 28 B per transition = 44 B at C2
-    bytes_per_step = 8 + 8 * 1 + 28
+    bytes_per_step = (4 * S + 28) if dense else (8 + 8 * 1 + 28)  # dense-row figure / CSR figure
     algo_bytes = bytes_per_step * B * args.launch_steps
     achieved = algo_bytes / avg_launch_s / 1e9
     # HBM bytes per launch from the PMC counters: they need their own rocprofv3 passes (--pmc FETCH_SIZE,
@@ -223,7 +227,7 @@ def main():
     if os.path.exists(pmc):
         try:
             j = json.load(open(pmc))
-            if j.get("transitions_per_launch") == B * args.launch_steps and args.size == 30:
+            if j.get("transitions_per_launch") == B * args.launch_steps and args.size == 30 and not dense:
                 traffic = j.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -245,13 +249,14 @@ def main():
             "workload": "C2: DeepSeaEpisodic(seed=i,size=%d), %d instances per GPU, on-device uniform random policy "
                         "(Philox-4x32-10), %d transitions per instance per step, auto-reset at h>=H" % (args.size, B, args.launch_steps),
             "instances_per_gpu": B, "states": S, "actions": 2, "horizon": int(env.H),
-            "transitions_per_instance_per_step": args.launch_steps, "layout": "csr", "rng": "philox4x32-10",
+            "transitions_per_instance_per_step": args.launch_steps, "layout": args.layout, "rng": "philox4x32-10",
             "build_s": round(t_build, 2),
         },
         "roofline": {
-            "bound": "hbm", "kernel": "k_rollout_lds" if args.rollout_kernel != 1 else "k_rollout<0,false>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm",
+            "kernel": "k_rollout_dense<0,NV>" if dense else ("k_rollout_lds" if args.rollout_kernel != 1 else "k_rollout<0,false>"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "algorithmic_bytes_per_transition": bytes_per_step, "accounting": "SURVEY 8(d) CSR figure (44 B/transition)",
+            "algorithmic_bytes_per_transition": bytes_per_step, "accounting": "SURVEY 8(d) dense-row figure (4*S+28 B/transition)" if dense else "SURVEY 8(d) CSR figure (44 B/transition)",
             "launch_ms_avg": avg_launch_s * 1e3, "launch_ms_min": float(np.min(launch_ms)),
         },
     }

@@ -58,7 +58,7 @@ def tables_from_models(models: Sequence[TabularModel], with_env: bool = True, wi
 class BatchedMDP:
     def __init__(self, models: Optional[Sequence[TabularModel]] = None, rng_mode: int = L.RNG_MT_COMPAT,
                  philox_keys: Optional[Sequence[int]] = None, with_env: bool = True, with_dp: bool = True,
-                 tables: Optional[dict] = None):
+                 tables: Optional[dict] = None, layout: int = L.LAYOUT_CSR):
         """Either `models` (TabularModel per instance) or pre-concatenated `tables` (see `tables_from_models`
         and colosseum_amd.mdp.fast_batch) describe the batch."""
         lib = L.load()
@@ -76,7 +76,7 @@ class BatchedMDP:
         self.rng_mode = rng_mode
         keep = {}
         d = L.CmdpDesc()
-        d.n_instances, d.n_actions, d.horizon, d.rng_mode, d.layout = self.B, A, self.H, rng_mode, L.LAYOUT_CSR
+        d.n_instances, d.n_actions, d.horizon, d.rng_mode, d.layout = self.B, A, self.H, rng_mode, layout
         d.reward_min, d.reward_max = float(rr[0]), float(rr[1])
         keep["state_off"] = self.state_off
         if "sp_ptr" in tables:

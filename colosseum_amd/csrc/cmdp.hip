@@ -98,6 +98,8 @@ struct cmdp {
   int rollout_kernel = 0;  // CMDP_OPT_ROLLOUT_KERNEL
   LdsPlan lds_plan{};
   size_t lds_bytes = 0;
+  DevBuf<float> d_dense;  // CMDP_LAYOUT_DENSE: [R][dense_spad]
+  int dense_spad = 0;
   DevBuf<uint16_t> d_next16;
   DevBuf<uint8_t> d_rcode;
   DevBuf<double> d_rvals;
@@ -164,7 +166,10 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
   if (d->n_instances < 1 || d->n_actions < 1 || d->n_actions > 64 || d->horizon < 0)
     return fail(CMDP_ERR_INVALID, "n_instances/n_actions/horizon out of range (1 <= A <= 64)");
   if (d->rng_mode != CMDP_RNG_MT_COMPAT && d->rng_mode != CMDP_RNG_PHILOX) return fail(CMDP_ERR_INVALID, "rng_mode");
-  if (d->layout != CMDP_LAYOUT_CSR) return fail(CMDP_ERR_UNSUPPORTED, "only CMDP_LAYOUT_CSR is built");
+  if (d->layout != CMDP_LAYOUT_CSR && d->layout != CMDP_LAYOUT_DENSE) return fail(CMDP_ERR_INVALID, "layout");
+  if (d->layout == CMDP_LAYOUT_DENSE && (d->rng_mode != CMDP_RNG_PHILOX || !d->sp_ptr || !d->csr_ptr))
+    return fail(CMDP_ERR_INVALID, "CMDP_LAYOUT_DENSE needs CMDP_RNG_PHILOX and both halves of the description "
+                                  "(the float32 rows come from the DP half, rewards and starts from the sampler half)");
   if (!d->state_off) return fail(CMDP_ERR_INVALID, "state_off is required");
   const bool has_env = d->sp_ptr != nullptr;
   const bool has_dp = d->csr_ptr != nullptr;
@@ -387,6 +392,31 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
     HIP_TRY(h->d_csr_val.upload(d->csr_val, N, st));
     HIP_TRY(h->d_R.upload(d->R, R, st));
   }
+  if (d->layout == CMDP_LAYOUT_DENSE) {
+    // exact float64 prefix sums need every probability to be a multiple of 2^-52 after scaling: p >= 2^-28
+    for (int64_t k = 0; k < h->n_csr; ++k)
+      if (!(d->csr_val[k] >= 3.7252902984619141e-09f) || d->csr_val[k] > 1.0f)
+        return fail(CMDP_ERR_INVALID, "dense layout needs probabilities in [2^-28, 1] (entry %lld)", (long long)k);
+    h->dense_spad = ((max_S + 255) / 256) * 256;
+    {
+      const int nv = h->dense_spad / 256;
+      const int allowed[] = {1, 2, 3, 4, 6, 8, 12, 16};
+      int pick = 0;
+      for (int v : allowed) if (v >= nv) { pick = v; break; }
+      if (!pick) return fail(CMDP_ERR_UNSUPPORTED, "dense layout supports at most 4096 states per instance");
+      h->dense_spad = pick * 256;
+    }
+    const size_t n = (size_t)R * h->dense_spad;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (n * sizeof(float) > free_b)
+      return fail(CMDP_ERR_INVALID, "dense layout needs %zu MiB, %zu MiB free", n * sizeof(float) >> 20, free_b >> 20);
+    HIP_TRY(h->d_dense.alloc(n));
+    HIP_TRY(h->d_dense.zero(st));
+    hipLaunchKernelGGL(k_dense_fill, dim3(grid_for(R, 256)), dim3(256), 0, st, h->d_dense.p, h->dense_spad,
+                       h->d_csr_ptr.p, h->d_csr_col.p, h->d_csr_val.p, R);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipStreamSynchronize(st));  // host staging vectors go out of scope
   guard.h = nullptr;
   *out = h;
@@ -430,6 +460,7 @@ int cmdp_step(cmdp_t* h, const int32_t* actions, int auto_reset, int32_t* obs, d
   if (int rc = bind(h)) return rc;
   if (!h->has_env) return fail(CMDP_ERR_INVALID, "handle was created without the sampler half");
   if (!actions || !obs || !reward || !step_type) return fail(CMDP_ERR_INVALID, "null argument");
+  if (h->layout == CMDP_LAYOUT_DENSE) return fail(CMDP_ERR_UNSUPPORTED, "dense layout: use cmdp_rollout");
   hipStream_t st = h->stream;
   const int B = h->B;
   if (h->d_i32_scratch.n < (size_t)2 * B) HIP_TRY(h->d_i32_scratch.alloc((size_t)2 * B));
@@ -464,6 +495,24 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
   const dim3 grid(grid_for(h->B, 256)), block(256);
   const bool trace = d_tobs || d_trew || d_ttype;
   EnvTables t = h->env();
+  if (h->layout == CMDP_LAYOUT_DENSE) {
+    if (trace) return fail(CMDP_ERR_UNSUPPORTED, "the dense-layout rollout does not record traces");
+    DenseArgs dn{h->d_dense.p, h->dense_spad};
+    const dim3 dgrid(grid_for(h->B, 4));
+    const int nv = h->dense_spad / 256;
+#define DENSE_CASE(NV)                                                                                            \
+  if (nv == NV) {                                                                                                 \
+    if (policy == CMDP_POLICY_RANDOM)                                                                             \
+      hipLaunchKernelGGL((k_rollout_dense<0, NV>), dgrid, block, 0, st, t, dn, d_actions, n_steps, d_rsum, d_last); \
+    else                                                                                                          \
+      hipLaunchKernelGGL((k_rollout_dense<1, NV>), dgrid, block, 0, st, t, dn, d_actions, n_steps, d_rsum, d_last); \
+  } else
+    DENSE_CASE(1) DENSE_CASE(2) DENSE_CASE(3) DENSE_CASE(4) DENSE_CASE(6) DENSE_CASE(8) DENSE_CASE(12) DENSE_CASE(16)
+    { return fail(CMDP_ERR_UNSUPPORTED, "dense layout: no kernel for a row stride of %d floats", h->dense_spad); }
+#undef DENSE_CASE
+    HIP_TRY(hipGetLastError());
+    return CMDP_OK;
+  }
   const bool lds_eligible = h->lds_ok && policy == CMDP_POLICY_RANDOM && !trace;
   if (h->rollout_kernel == 2 && !lds_eligible)
     return fail(CMDP_ERR_UNSUPPORTED, "LDS-resident rollout needs deterministic dynamics, one start state, <= 65535 "

@@ -533,6 +533,153 @@ __device__ __forceinline__ void flush_counts(int32_t* __restrict__ dst, int tota
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K1D: dense-row layout (CMDP_LAYOUT_DENSE, the layout BASELINE.json's north star names): every instance
+// keeps its float32 P[s,a,:] rows (row stride `spad` floats) in HBM.  One WAVEFRONT per instance: per
+// transition the 64 lanes stream the row with 16-byte coalesced loads, form exact float64 partial sums, take a
+// wavefront inclusive prefix sum (6 shuffle steps) and pick next = min{ j : cum_j > u * total } with a ballot.
+// Algorithmic bytes per transition: 4*S (row) + 28 -- this kernel is genuinely HBM-bound.
+// The prefix sums are exact in float64 (probabilities are >= 2^-28, checked at create time), so their
+// association does not matter and the result equals the oracle's sequential scan bit for bit.
+// ---------------------------------------------------------------------------------------------------
+struct DenseArgs {
+  const float* P;   // [R][spad]
+  int32_t spad;     // multiple of 256
+};
+
+__device__ __forceinline__ double wave_incl_scan(double v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double up = __shfl_up(v, o, 64);
+    if (lane >= o) v += up;
+  }
+  return v;
+}
+
+// NV = float4 loads per lane per row (row stride = 256 * NV floats); the row stays in registers between the
+// partial-sum pass and the search pass.  The Philox work of a wavefront is spread over its lanes: every 64
+// transitions lane j computes the transition uniform of transition base+j and the action block base/4+j, and
+// the per-transition values are then broadcast with one shuffle each (values are wave-uniform anyway).
+template <int POLICY, int NV>
+__global__ void __launch_bounds__(256) k_rollout_dense(EnvTables t, DenseArgs dn, const int8_t* __restrict__ actions,
+                                                       int64_t n_steps, double* __restrict__ reward_sum,
+                                                       int32_t* __restrict__ last_obs) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= t.B) return;  // whole wavefronts leave together
+  const int64_t soff = t.state_off[b], ebase = t.entry_base[b];
+  const uint2 key = t.philox_key[b];
+  int32_t cur = t.cur[b], h = t.hstep[b];
+  unsigned long long nt = t.n_trans[b], nr = t.n_reset[b];
+  double sum = 0.0;
+  unsigned long long base = nt;
+  double u_lane = 0.0;
+  uint32_t acts_lane = 0;
+  for (int64_t step = 0; step < n_steps; ++step) {
+    const int i = (int)(nt - base);
+    if (i == 0 || i == 64) {  // refill: 64 transitions' worth of random numbers, one Philox block per lane
+      base = nt;
+      uint32_t w[4];
+      const unsigned long long n = base + (unsigned long long)lane;
+      philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 0u, 0u, key.x, key.y, w);
+      u_lane = u53(w[0], w[1]);
+      if (POLICY == 0) {
+        const unsigned long long q = (base >> 2) + (unsigned long long)lane;
+        philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), 2u, 0u, key.x, key.y, w);
+        acts_lane = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acts_lane |= (uint32_t)(((uint64_t)w[j] * (uint64_t)t.A) >> 32) << (8 * j);
+      }
+    }
+    const int idx = (int)(nt - base);
+    const double u = __shfl(u_lane, idx, 64);
+    int a;
+    if (POLICY == 1) {
+      a = (int)actions[step * t.B + b];
+    } else {
+      const uint32_t word = __shfl(acts_lane, (int)((nt >> 2) - (base >> 2)), 64);
+      a = (int)((word >> (8 * (int)(nt & 3))) & 0xffu);
+    }
+    ++nt;
+    ++h;
+    const int64_t r = (soff + cur) * t.A + a;
+    const float4* row = reinterpret_cast<const float4*>(dn.P + r * dn.spad + (int64_t)lane * (4 * NV));
+    float4 v[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] = row[q];
+    const RowDesc d = t.row[r];  // independent of the row data: in flight together with it
+    double part = 0.0;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      part += (double)v[q].x; part += (double)v[q].y; part += (double)v[q].z; part += (double)v[q].w;
+    }
+    const double incl = wave_incl_scan(part, lane);
+    const double total = __shfl(incl, 63, 64);
+    const double x = u * total;
+    double c = incl - part;
+    int hit = -1, last_nz = -1;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = lane * (4 * NV) + q * 4 + k;
+        c += (double)e[k];
+        if (e[k] != 0.0f) last_nz = j;
+        if (hit < 0 && e[k] != 0.0f && c > x) hit = j;
+      }
+    }
+    const unsigned long long m = __ballot(hit >= 0);
+    int nxt;
+    if (m) {
+      nxt = __shfl(hit, __ffsll((long long)m) - 1, 64);
+    } else {  // u * total rounded up to total: the last non-zero column of the row
+      const unsigned long long mz = __ballot(last_nz >= 0);
+      nxt = __shfl(last_nz, 63 - __clzll((long long)mz), 64);
+    }
+    // reward of the sampler entry (s, a, nxt)
+    double rraw = d.reward_if_det;
+    if (d.n > 1) {
+      int found = -1;
+      for (int k0 = 0; k0 < d.n && found < 0; k0 += 64) {
+        const int k = k0 + lane;
+        const bool eq = k < d.n && t.sp_next[ebase + d.first + k] == nxt;
+        const unsigned long long me = __ballot(eq);
+        if (me) found = k0 + __ffsll((long long)me) - 1;
+      }
+      rraw = t.sp_reward[ebase + d.first + found];
+    }
+    sum += rraw * t.rscale - t.rmin;
+    if (lane == 0) {
+      bump(t.visits_s + soff + nxt);
+      bump(t.visits_sa + (soff + nxt) * t.A + a);
+    }
+    cur = nxt;
+    if (t.H > 0 && h >= t.H) {
+      int32_t s0 = 0;
+      if (lane == 0) s0 = env_reset(t, b, soff, key, nr);
+      cur = __shfl(s0, 0, 64);
+      h = 0;
+    }
+  }
+  if (lane == 0) {
+    t.cur[b] = cur;
+    t.hstep[b] = h;
+    t.n_trans[b] = nt;
+    t.n_reset[b] = nr;
+    if (reward_sum) reward_sum[b] = sum;
+    if (last_obs) last_obs[b] = cur;
+  }
+}
+
+// scatter of the CSR non-zeros into the (zero-filled) dense rows
+__global__ void k_dense_fill(float* __restrict__ P, int spad, const int64_t* __restrict__ csr_ptr,
+                             const int32_t* __restrict__ csr_col, const float* __restrict__ csr_val, int64_t n_rows) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  for (int64_t k = csr_ptr[r]; k < csr_ptr[r + 1]; ++k) P[r * spad + csr_col[k]] = csr_val[k];
+}
+
 // ===================================================================================================
 // Dynamic programming
 // ===================================================================================================

@@ -74,7 +74,11 @@ enum {
 enum {
   CMDP_LAYOUT_CSR = 0,   /* per-row successor lists (compact; the default)                           */
   CMDP_LAYOUT_DENSE = 1  /* per-instance dense float32 P[s,a,:] rows streamed from HBM, wavefront
-                            prefix-sum CDF lookup (Philox mode only)                                  */
+                            prefix-sum CDF lookup: next = min{ j : sum_{i<=j} P[s,a,i] > u*total } in
+                            STATE order (not the sampler's creation order), so stochastic rows draw
+                            different -- equally distributed -- successors than CMDP_LAYOUT_CSR for the
+                            same u.  Philox mode, cmdp_rollout only, needs both halves of the description
+                            and S_max*A*4*round_up(S_max,256) bytes per instance.                      */
 };
 
 typedef struct cmdp cmdp_t;

@@ -33,6 +33,7 @@ def lib():
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_int32, C.c_uint64]
         L.oracle_env_destroy.argtypes = [C.c_void_p]
+        L.oracle_env_set_dense.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_env_reset.restype = C.c_int32
         L.oracle_env_reset.argtypes = [C.c_void_p]
         L.oracle_env_step.restype = C.c_int
@@ -79,7 +80,7 @@ class OracleEnv:
     """One instance of the interaction loop on the CPU oracle.  `model` is a colosseum_amd TabularModel
     (only its plain arrays are read)."""
 
-    def __init__(self, model, rng_mode=0, philox_key=0):
+    def __init__(self, model, rng_mode=0, philox_key=0, dense=False):
         L = lib()
         self._keep = dict(
             sp_ptr=np.ascontiguousarray(model.sp_ptr, np.int64),
@@ -100,6 +101,11 @@ class OracleEnv:
                                       _ptr(k["sp_cum"]), _ptr(k["sp_reward"]), _ptr(k["sp_seed"]),
                                       len(k["start_state"]), _ptr(k["start_state"]), _ptr(k["start_cum"]),
                                       int(model.start_seed), int(philox_key))
+        if dense:
+            assert rng_mode == 1
+            ptr, col, val = _csr64(model.csr())
+            k.update(d_ptr=ptr, d_col=col, d_val=val)
+            L.oracle_env_set_dense(self._e, _ptr(ptr), _ptr(col), _ptr(val))
 
     def __del__(self):
         if getattr(self, "_e", None):

@@ -475,3 +475,47 @@ def test_edge_cases(need_gpu):
         BatchedMDP([make_model("DeepSeaEpisodic", seed=0, size=4), make_model("DeepSeaEpisodic", seed=0, size=5)])
     with pytest.raises(L.CmdpError):  # stochastic reward tables are rejected, not silently replaced by their means
         BatchedMDP([make_model("DeepSeaEpisodic", seed=0, size=4, make_reward_stochastic=True)])
+
+
+def test_dense_row_layout_vs_oracle(need_gpu):
+    """CMDP_LAYOUT_DENSE (float32 P[s,a,:] rows in HBM, wavefront prefix-sum CDF lookup): states, visit counts and
+    reward sums bit-equal to the oracle's sequential scan of the same rows; deterministic rows give the same
+    trajectories as the CSR layout."""
+    cases = [
+        [make_model("DeepSeaEpisodic", seed=s, size=9) for s in range(5)],
+        [make_model("FrozenLakeContinuous", seed=s, size=sz, p_frozen=0.9, p_rand=0.15, p_lazy=0.05) for s, sz in ((0, 5), (1, 9), (2, 17))],
+        [make_model("MiniGridEmptyEpisodic", seed=2, size=7, p_rand=0.3, n_starting_states=3)] * 2,
+        [make_model("MiniGridRoomsContinuous", seed=1, room_size=4, n_rooms=4, p_lazy=0.2, p_rand=0.1, n_starting_states=2)],
+    ]
+    for models in cases:
+        keys = np.arange(40, 40 + len(models), dtype=np.uint64)
+        env = BatchedMDP(models, rng_mode=L.RNG_PHILOX, philox_keys=keys, layout=L.LAYOUT_DENSE)
+        env.reset()
+        a = env.rollout(1500)
+        acts = np.random.RandomState(3).randint(0, models[0].n_actions, (700, len(models))).astype(np.int8)
+        b = env.rollout(700, acts)
+        vs, vsa = env.visits()
+        for i, m in enumerate(models):
+            e = O.OracleEnv(m, rng_mode=1, philox_key=int(keys[i]), dense=True)
+            e.reset()
+            ra = e.rollout(1500, trace=False)
+            rb = e.rollout(700, acts[:, i], trace=False)
+            assert a["last_obs"][i] == ra["last_obs"] and b["last_obs"][i] == rb["last_obs"], (m.extra["cls_name"], i)
+            assert a["reward_sum"][i] == ra["reward_sum"] and b["reward_sum"][i] == rb["reward_sum"]
+            ovs, ovsa = e.visits()
+            np.testing.assert_array_equal(env.split_states(vs)[i], ovs)
+            np.testing.assert_array_equal(env.split_rows(vsa)[i].reshape(-1, m.n_actions), ovsa)
+        env.close()
+    # deterministic dynamics: dense == CSR layout
+    models = cases[0]
+    outs = []
+    for layout in (L.LAYOUT_CSR, L.LAYOUT_DENSE):
+        env = BatchedMDP(models, rng_mode=L.RNG_PHILOX, layout=layout)
+        env.reset()
+        r = env.rollout(999)
+        outs.append((r["last_obs"], r["reward_sum"], env.visits()[1]))
+        env.close()
+    for x, y in zip(*outs):
+        np.testing.assert_array_equal(x, y)
+    with pytest.raises(L.CmdpError):
+        BatchedMDP(models, rng_mode=L.RNG_MT_COMPAT, layout=L.LAYOUT_DENSE)
