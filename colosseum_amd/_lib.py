@@ -14,6 +14,7 @@ RNG_MT_COMPAT, RNG_PHILOX = 0, 1
 POLICY_RANDOM, POLICY_HOST_ACTIONS, POLICY_GREEDY_Q = 0, 1, 2
 SCHEME_AUTO, SCHEME_JACOBI, SCHEME_GAUSS_SEIDEL = 0, 1, 2
 LAYOUT_CSR, LAYOUT_DENSE = 0, 1
+FLAG_REWARD_MEANS = 1
 OPT_ROLLOUT_KERNEL = 1
 OPT_DP_KERNEL = 2
 OPT_LDS_GROUPS_PER_CU = 3
@@ -31,7 +32,7 @@ EXPORTS = [
 class CmdpDesc(C.Structure):
     _fields_ = [
         ("n_instances", C.c_int32), ("n_actions", C.c_int32), ("horizon", C.c_int32), ("rng_mode", C.c_int32),
-        ("layout", C.c_int32), ("reserved", C.c_int32),
+        ("layout", C.c_int32), ("flags", C.c_int32),
         ("reward_min", C.c_double), ("reward_max", C.c_double),
         ("state_off", C.c_void_p),
         ("sp_ptr", C.c_void_p), ("sp_next", C.c_void_p), ("sp_cum", C.c_void_p), ("sp_reward", C.c_void_p),

@@ -34,7 +34,9 @@ def tables_from_models(models: Sequence[TabularModel], with_env: bool = True, wi
         t["sp_ptr"] = np.concatenate([m.sp_ptr[:-1] + ent_off[i] for i, m in enumerate(models)] + [ent_off[-1:]])
         t["sp_next"] = np.concatenate([m.sp_next for m in models])
         t["sp_cum"] = np.concatenate([m.sp_cum for m in models])
-        t["sp_reward"] = np.concatenate([m.sp_rp0 for m in models])
+        # the deterministic value (loc); for stochastic kinds the distribution mean (only accepted by the library
+        # under CMDP_FLAG_REWARD_MEANS)
+        t["sp_reward"] = np.concatenate([np.where(m.sp_rkind == 0, m.sp_rp0, m.sp_rmean) for m in models])
         t["sp_rkind"] = np.concatenate([m.sp_rkind for m in models])
         t["sp_seed"] = np.concatenate([m.sp_seed for m in models])
         ns = np.array([len(m.start_states) for m in models], np.int64)
@@ -58,7 +60,7 @@ def tables_from_models(models: Sequence[TabularModel], with_env: bool = True, wi
 class BatchedMDP:
     def __init__(self, models: Optional[Sequence[TabularModel]] = None, rng_mode: int = L.RNG_MT_COMPAT,
                  philox_keys: Optional[Sequence[int]] = None, with_env: bool = True, with_dp: bool = True,
-                 tables: Optional[dict] = None, layout: int = L.LAYOUT_CSR):
+                 tables: Optional[dict] = None, layout: int = L.LAYOUT_CSR, flags: int = 0):
         """Either `models` (TabularModel per instance) or pre-concatenated `tables` (see `tables_from_models`
         and colosseum_amd.mdp.fast_batch) describe the batch."""
         lib = L.load()
@@ -77,6 +79,7 @@ class BatchedMDP:
         keep = {}
         d = L.CmdpDesc()
         d.n_instances, d.n_actions, d.horizon, d.rng_mode, d.layout = self.B, A, self.H, rng_mode, layout
+        d.flags = int(flags)
         d.reward_min, d.reward_max = float(rr[0]), float(rr[1])
         keep["state_off"] = self.state_off
         if "sp_ptr" in tables:

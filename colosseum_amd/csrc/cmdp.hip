@@ -212,7 +212,7 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
     const int64_t E = d->sp_ptr[R];
     h->n_entries = E;
     if (d->sp_ptr[0] != 0) return fail(CMDP_ERR_INVALID, "sp_ptr[0] != 0");
-    if (d->sp_rkind)
+    if (d->sp_rkind && !(d->flags & CMDP_FLAG_REWARD_MEANS))
       for (int64_t e = 0; e < E; ++e)
         if (d->sp_rkind[e] != 0)
           return fail(CMDP_ERR_UNSUPPORTED, "stochastic reward distributions are not built (entry %lld)", (long long)e);

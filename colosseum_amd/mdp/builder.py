@@ -282,6 +282,9 @@ def build_model(
     )
     model.extra["node_index"] = index
     model.extra["action_map"] = action_map
+    # the MDP's numpy stream, positioned exactly where the reference's `mdp._rng` stands after construction: the
+    # reward caches (mdp/base.py:1196-1203) and `random_step` (:1336,1353) continue from here
+    model.extra["rng"] = rng
     model.extra["successors"] = [[index[x] for x in adjacency[n]] for n in nodes]  # networkx adjacency order
     if episodic:
         model.H = _time_horizon(model, family, H)

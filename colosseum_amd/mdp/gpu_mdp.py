@@ -17,6 +17,7 @@ from .. import timestep as ts_
 from ..batched import BatchedMDP
 from ..dynamic_programming import get_policy_from_q_values
 from .registry import make_model, split_class_name
+from .reward_sampler import CompatRewardSampler
 
 
 class GpuMDP:
@@ -27,7 +28,11 @@ class GpuMDP:
         self._model = make_model(cls_name, **kwargs)
         self._family_name, self._episodic = split_class_name(cls_name)
         m = self._model
-        self._env = BatchedMDP([m], rng_mode=L.RNG_MT_COMPAT)
+        # Beta rewards are sampled on the host exactly as the reference does (reward_sampler.py); the device then
+        # only reports the mean, which `step` replaces
+        self._reward_sampler = None if m.deterministic_rewards else CompatRewardSampler(m)
+        self._env = BatchedMDP([m], rng_mode=L.RNG_MT_COMPAT,
+                               flags=0 if m.deterministic_rewards else L.FLAG_REWARD_MEANS)
         self.n_states, self.n_actions = m.n_states, m.n_actions
         self.rewards_range = self._rewards_range = tuple(m.rewards_range)
         self.r_min, self.r_max = self.rewards_range
@@ -95,18 +100,17 @@ class GpuMDP:
         self.cur_node = self.index_to_node[int(cur[0])]
         self.last_edge = old, self.cur_node
         reward = float(rew[0])
+        if self._reward_sampler is not None:
+            reward = self._reward_sampler.sample(self.node_to_index[old], action, int(cur[0]))
         if st[0] == 2:
             self.necessary_reset = True
             return ts_.termination(reward=reward, observation=-1)
         return ts_.transition(reward=reward, observation=int(obs[0]))
 
     def random_step(self, auto_reset=False):
-        """mdp/base.py:1341-1355 draws the action from the MDP's own numpy stream, which the construction also
-        consumed; a stream positioned after construction is not kept on the host, so this draws from a generator
-        seeded like the reference's but is NOT draw-for-draw identical (documented deviation)."""
-        if "rand" not in self._cache:
-            self._cache["rand"] = np.random.RandomState(self._seed)
-        action = int(self._cache["rand"].randint(self.n_actions))
+        """mdp/base.py:1341-1355: the action comes from the MDP's own numpy stream (shared with the reward caches),
+        which the builder hands over positioned exactly as the reference's after construction."""
+        action = int(self._model.extra["rng"].randint(self.n_actions))
         return self.step(action, auto_reset), action
 
     def get_visitation_counts(self, state_only=True):

@@ -81,6 +81,14 @@ enum {
                             and S_max*A*4*round_up(S_max,256) bytes per instance.                      */
 };
 
+/* cmdp_desc.flags */
+enum {
+  /* Accept entries with sp_rkind != 0 (stochastic reward distributions) and report sp_reward -- which then holds
+     the distribution MEAN -- as the reward of such transitions.  For callers that sample those rewards themselves
+     (the reference-exact host sampler of colosseum_amd/mdp/reward_sampler.py) or only need expectations. */
+  CMDP_FLAG_REWARD_MEANS = 1
+};
+
 typedef struct cmdp cmdp_t;
 
 /* Model description handed to cmdp_create.  Either half may be absent (all its pointers NULL):
@@ -94,7 +102,7 @@ typedef struct cmdp_desc {
   int32_t horizon;           /* H > 0: episodic (EpisodicMDP.H); 0: continuous                       */
   int32_t rng_mode;          /* CMDP_RNG_*                                                           */
   int32_t layout;            /* CMDP_LAYOUT_*                                                        */
-  int32_t reserved;
+  int32_t flags;             /* CMDP_FLAG_*                                                          */
   double reward_min;         /* BaseMDP.rewards_range, applied as r*(max-min) - min                  */
   double reward_max;         /*   (sic, colosseum/mdp/base.py:1205-1207)                             */
   const int64_t* state_off;  /* [B+1]                                                                */
@@ -104,7 +112,8 @@ typedef struct cmdp_desc {
   const int32_t* sp_next;    /* [E]   successor state index, local to the instance                   */
   const double*  sp_cum;     /* [E]   itertools.accumulate(probs) within the row                     */
   const double*  sp_reward;  /* [E]   reward of (s,a,s'): the deterministic value (loc)              */
-  const uint8_t* sp_rkind;   /* [E]   0 deterministic; anything else -> CMDP_ERR_UNSUPPORTED; NULL=0 */
+  const uint8_t* sp_rkind;   /* [E]   0 deterministic; else CMDP_ERR_UNSUPPORTED unless
+                                      CMDP_FLAG_REWARD_MEANS; NULL = all 0                             */
   const int32_t* sp_seed;    /* [R]   seed given to the row's NextStateSampler (MT_COMPAT)           */
   const int64_t* start_off;  /* [B+1]                                                                */
   const int32_t* start_state;/* [NS]  starting states, local index                                   */

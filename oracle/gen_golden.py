@@ -21,6 +21,7 @@ Fixture groups:
   G5  hardness known-answer table lifted from benchmark/cached_hardness_measures/*.txt
   G6  episodic/continuous diameter + value-norm recomputed by the reference here (small cases)
   G7  MDPLoop + QLearningEpisodic logger rows and action stream (config C1, plumbing)
+  G8  trajectories with Beta rewards (the MDP's numpy stream, 5000-sample caches per visited triple)
 """
 import json
 import os
@@ -518,7 +519,35 @@ def g7():
         json.dump(cases, f)
 
 
-GROUPS = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7)
+def g8():
+    """Stochastic (Beta) rewards: trajectories whose rewards come from the MDP's numpy stream in 5000-sample blocks
+    per first-visited (s, a, s') triple (mdp/base.py:1187-1207)."""
+    specs = [
+        ("DeepSeaEpisodic", dict(seed=2, size=6, p_rand=0.3, make_reward_stochastic=True)),
+        ("DeepSeaContinuous", dict(seed=0, size=5, make_reward_stochastic=True, reward_variance_multiplier=0.7)),
+        ("FrozenLakeContinuous", dict(seed=1, size=4, p_frozen=0.9, p_lazy=0.05, make_reward_stochastic=True)),
+        ("MiniGridEmptyEpisodic", dict(seed=0, size=4, p_rand=0.1, make_reward_stochastic=True, n_starting_states=2)),
+        ("FrozenLakeEpisodic", dict(seed=3, size=4, p_frozen=0.9, make_reward_stochastic=True, rewards_range=(1.0, 3.0))),
+    ]
+    cases, arrays = [], {}
+    for cls, kw in specs:
+        mdp = CLASSES[cls](**kw)
+        key = f"c{len(cases)}_"
+        st = structure(mdp)
+        for k in ("nodes", "sp_ptr", "sp_next", "sp_prob", "sp_rmean", "R", "SAH", "start_states", "start_probs"):
+            arrays[key + k] = st[k]
+        # 7000 steps: with ~100 distinct triples some caches are exhausted and refilled (5000-sample blocks)
+        acts = np.random.RandomState(500 + len(cases)).randint(0, mdp.n_actions, 7000)
+        tr = trajectory(mdp, acts)
+        tr["actions"] = tr["actions"].astype(np.int8)
+        arrays.update(flat(key, tr))
+        cases.append(dict(cls=cls, kwargs=kw))
+        print("   ", cls, kw, "S=", mdp.n_states, "reward mean", tr["rew"].mean())
+    arrays["cases"] = np.array(json.dumps(cases))
+    save("G8_stochastic_rewards", **arrays)
+
+
+GROUPS = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)
