@@ -36,7 +36,7 @@ class CmdpDesc(C.Structure):
         ("reward_min", C.c_double), ("reward_max", C.c_double),
         ("state_off", C.c_void_p),
         ("sp_ptr", C.c_void_p), ("sp_next", C.c_void_p), ("sp_cum", C.c_void_p), ("sp_reward", C.c_void_p),
-        ("sp_rkind", C.c_void_p), ("sp_seed", C.c_void_p), ("start_off", C.c_void_p), ("start_state", C.c_void_p),
+        ("sp_rkind", C.c_void_p), ("sp_rp0", C.c_void_p), ("sp_rp1", C.c_void_p), ("sp_seed", C.c_void_p), ("start_off", C.c_void_p), ("start_state", C.c_void_p),
         ("start_cum", C.c_void_p), ("start_seed", C.c_void_p), ("philox_key", C.c_void_p),
         ("csr_ptr", C.c_void_p), ("csr_col", C.c_void_p), ("csr_val", C.c_void_p), ("R", C.c_void_p),
     ]

@@ -13,7 +13,7 @@ from .mdp.builder import TabularModel
 
 
 _ENV_FIELDS = (("sp_ptr", np.int64), ("sp_next", np.int32), ("sp_cum", np.float64), ("sp_reward", np.float64),
-               ("sp_rkind", np.uint8), ("sp_seed", np.int32), ("start_off", np.int64), ("start_state", np.int32),
+               ("sp_rkind", np.uint8), ("sp_rp0", np.float64), ("sp_rp1", np.float64), ("sp_seed", np.int32), ("start_off", np.int64), ("start_state", np.int32),
                ("start_cum", np.float64), ("start_seed", np.int32))
 _DP_FIELDS = (("csr_ptr", np.int64), ("csr_col", np.int32), ("csr_val", np.float32), ("R", np.float32))
 
@@ -38,6 +38,8 @@ def tables_from_models(models: Sequence[TabularModel], with_env: bool = True, wi
         # under CMDP_FLAG_REWARD_MEANS)
         t["sp_reward"] = np.concatenate([np.where(m.sp_rkind == 0, m.sp_rp0, m.sp_rmean) for m in models])
         t["sp_rkind"] = np.concatenate([m.sp_rkind for m in models])
+        t["sp_rp0"] = np.concatenate([m.sp_rp0 for m in models])
+        t["sp_rp1"] = np.concatenate([m.sp_rp1 for m in models])
         t["sp_seed"] = np.concatenate([m.sp_seed for m in models])
         ns = np.array([len(m.start_states) for m in models], np.int64)
         t["start_off"] = np.concatenate([[0], np.cumsum(ns)])
@@ -84,6 +86,8 @@ class BatchedMDP:
         keep["state_off"] = self.state_off
         if "sp_ptr" in tables:
             for k, dt in _ENV_FIELDS:
+                if k in ("sp_rp0", "sp_rp1") and k not in tables:
+                    continue  # optional: only read for Beta entries
                 keep[k] = np.ascontiguousarray(tables[k], dt)
             if philox_keys is None:
                 philox_keys = np.arange(self.B, dtype=np.uint64)

@@ -81,7 +81,8 @@ struct cmdp {
   DevBuf<RowDesc> d_row;
   DevBuf<int32_t> d_sp_next, d_start_state, d_start_slot, d_mt_pos, d_cur, d_h, d_visits_s, d_visits_sa, d_csr_col,
       d_flag, d_status, d_i32_scratch;
-  DevBuf<double> d_sp_cum, d_sp_reward, d_start_cum, d_f64_scratch;
+  DevBuf<double> d_sp_cum, d_sp_reward, d_start_cum, d_f64_scratch, d_sp_rp0, d_sp_rp1;
+  DevBuf<uint8_t> d_sp_rkind;
   DevBuf<uint2> d_key;
   DevBuf<uint32_t> d_mt;
   DevBuf<uint8_t> d_need_reset, d_u8_scratch;
@@ -110,6 +111,7 @@ struct cmdp {
     t.rscale = rmax - rmin; t.rmin = rmin;
     t.state_off = d_state_off.p; t.entry_base = d_entry_base.p; t.row = d_row.p;
     t.sp_next = d_sp_next.p; t.sp_cum = d_sp_cum.p; t.sp_reward = d_sp_reward.p;
+    t.sp_rkind = d_sp_rkind.p; t.sp_rp0 = d_sp_rp0.p; t.sp_rp1 = d_sp_rp1.p;
     t.start_off = d_start_off.p; t.start_state = d_start_state.p; t.start_cum = d_start_cum.p;
     t.start_slot = d_start_slot.p; t.philox_key = d_key.p; t.mt = d_mt.p; t.mt_pos = d_mt_pos.p;
     t.cur = d_cur.p; t.hstep = d_h.p; t.need_reset = d_need_reset.p; t.n_trans = d_ntrans.p; t.n_reset = d_nreset.p;
@@ -212,10 +214,24 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
     const int64_t E = d->sp_ptr[R];
     h->n_entries = E;
     if (d->sp_ptr[0] != 0) return fail(CMDP_ERR_INVALID, "sp_ptr[0] != 0");
-    if (d->sp_rkind && !(d->flags & CMDP_FLAG_REWARD_MEANS))
+    bool any_beta = false;
+    if (d->sp_rkind)
+      for (int64_t e = 0; e < E; ++e) {
+        if (d->sp_rkind[e] > 1) return fail(CMDP_ERR_UNSUPPORTED, "unknown reward distribution kind at entry %lld", (long long)e);
+        any_beta |= d->sp_rkind[e] == 1;
+      }
+    const bool sample_beta = any_beta && !(d->flags & CMDP_FLAG_REWARD_MEANS);
+    if (sample_beta) {
+      if (d->rng_mode != CMDP_RNG_PHILOX || !d->sp_rp0 || !d->sp_rp1)
+        return fail(CMDP_ERR_UNSUPPORTED, "Beta rewards are sampled on the device only in CMDP_RNG_PHILOX mode with sp_rp0/"
+                                          "sp_rp1; the reference-exact stream is host side (CMDP_FLAG_REWARD_MEANS)");
       for (int64_t e = 0; e < E; ++e)
-        if (d->sp_rkind[e] != 0)
-          return fail(CMDP_ERR_UNSUPPORTED, "stochastic reward distributions are not built (entry %lld)", (long long)e);
+        if (d->sp_rkind[e] == 1 && !(d->sp_rp0[e] > 0.0 && d->sp_rp1[e] > 0.0))
+          return fail(CMDP_ERR_INVALID, "Beta parameters must be positive (entry %lld)", (long long)e);
+      HIP_TRY(h->d_sp_rkind.upload(d->sp_rkind, E, st));
+      HIP_TRY(h->d_sp_rp0.upload(d->sp_rp0, E, st));
+      HIP_TRY(h->d_sp_rp1.upload(d->sp_rp1, E, st));
+    }
     // row descriptors, entry bases, MT slots -- validated on the host so that no kernel can index out of range
     std::vector<RowDesc> rows((size_t)R);
     std::vector<int64_t> ebase((size_t)B);
@@ -296,7 +312,7 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
     HIP_TRY(h->d_visits_sa.zero(st));
     // ---- eligibility of the LDS-resident rollout kernel --------------------------------------------------
     {
-      bool ok = max_S <= 65535 && h->n_slots == 0;
+      bool ok = max_S <= 65535 && h->n_slots == 0 && !sample_beta;
       for (int b = 0; ok && b < B; ++b) ok = (d->state_off[b + 1] - d->state_off[b]) == max_S;  // uniform S
       for (int64_t r = 0; ok && r < R; ++r) ok = rows[(size_t)r].n == 1;
       for (int b = 0; ok && b < B; ++b) ok = (d->start_off[b + 1] - d->start_off[b]) == 1;

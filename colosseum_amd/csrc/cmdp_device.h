@@ -10,6 +10,7 @@
 // domain 0, n = transition index      : w0,w1 = 53-bit transition uniform (stochastic rows only)
 // domain 1, n = reset index           : w0,w1 = start-state uniform (several start states only)
 // domain 2, n = transition index >> 2 : word (index & 3) = random-policy action, a = (word * A) >> 32
+// domain 3, n = transition index, c3 = draw counter : Beta reward of the transition (philox_beta below)
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t (&w)[4]) {
@@ -92,4 +93,41 @@ __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
   return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Beta(a, b) reward of transition n in CMDP_RNG_PHILOX mode (build-defined; the reference-exact path is the
+// host sampler of colosseum_amd/mdp/reward_sampler.py).  X = Ga / (Ga + Gb) with Marsaglia-Tsang gamma variates;
+// every Philox block (n, domain 3, draw k) supplies the two uniforms of one Box-Muller normal and, in its second
+// half, the acceptance uniform; shapes below one use Gamma(shape + 1) * U^(1/shape).  The CPU oracle runs the
+// same recipe with libm, so the two agree to rounding of log/sqrt/cos/pow (tests compare with rtol 1e-12).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double philox_gamma(double shape, unsigned long long n, uint2 key, uint32_t& draw) {
+  double boost = 1.0;
+  uint32_t w[4];
+  if (shape < 1.0) {
+    philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 3u, draw++, key.x, key.y, w);
+    boost = pow(1.0 - u53(w[0], w[1]), 1.0 / shape);
+    shape += 1.0;
+  }
+  const double d = shape - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+  for (int attempt = 0; attempt < 64; ++attempt) {
+    philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 3u, draw++, key.x, key.y, w);
+    const double u1 = u53(w[0], w[1]), u2 = u53(w[2], w[3]);
+    const double z = sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586476925286766559 * u2);
+    double v = 1.0 + c * z;
+    if (v <= 0.0) continue;
+    v = v * v * v;
+    philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 3u, draw++, key.x, key.y, w);
+    const double u3 = u53(w[0], w[1]);
+    if (log(u3) < 0.5 * z * z + d - d * v + d * log(v)) return boost * d * v;
+  }
+  return boost * d;  // unreachable in practice (acceptance > 95 % per attempt)
+}
+
+__device__ __forceinline__ double philox_beta(double a, double b, unsigned long long n, uint2 key) {
+  uint32_t draw = 0;
+  const double ga = philox_gamma(a, n, key, draw);
+  const double gb = philox_gamma(b, n, key, draw);
+  return ga / (ga + gb);
 }

@@ -36,7 +36,10 @@ struct EnvTables {
   const RowDesc* row;                // [R]
   const int32_t* sp_next;            // [E]
   const double* sp_cum;              // [E]
-  const double* sp_reward;           // [E]
+  const double* sp_reward;           // [E]  deterministic value | distribution mean
+  const uint8_t* sp_rkind;           // [E]  null: every reward is deterministic; 1 = Beta(sp_rp0, sp_rp1) sampled per transition
+  const double* sp_rp0;              // [E]
+  const double* sp_rp1;              // [E]
   const int64_t* start_off;          // [B+1]
   const int32_t* start_state;        // [NS]
   const double* start_cum;           // [NS]
@@ -109,6 +112,7 @@ __device__ __forceinline__ int env_step(const EnvTables& t, int64_t soff, int64_
   const RowDesc d = t.row[r];
   int32_t nxt = d.next_if_det;
   double rraw = d.reward_if_det;
+  int64_t e = ebase + d.first;
   if (d.n > 1) {  // NextStateSampler.sample (custom_samplers.py:59-72)
     double u;
     if (t.rng_mode == 0) {
@@ -118,11 +122,11 @@ __device__ __forceinline__ int env_step(const EnvTables& t, int64_t soff, int64_
       philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 0u, 0u, key.x, key.y, w);
       u = u53(w[0], w[1]);
     }
-    const int64_t e0 = ebase + d.first;
-    const int64_t e = e0 + choose_index(t.sp_cum + e0, d.n, u);
+    e += choose_index(t.sp_cum + e, d.n, u);
     nxt = t.sp_next[e];
     rraw = t.sp_reward[e];
   }
+  if (t.sp_rkind && t.sp_rkind[e] == 1) rraw = philox_beta(t.sp_rp0[e], t.sp_rp1[e], n, key);  // throughput mode only
   // visit counts on the arrival node with the action taken at the departure node (base.py:1302-1303)
   bump(t.visits_s + soff + nxt);
   bump(t.visits_sa + (soff + nxt) * t.A + action);
@@ -639,6 +643,7 @@ __global__ void __launch_bounds__(256) k_rollout_dense(EnvTables t, DenseArgs dn
     }
     // reward of the sampler entry (s, a, nxt)
     double rraw = d.reward_if_det;
+    int64_t ent = ebase + d.first;
     if (d.n > 1) {
       int found = -1;
       for (int k0 = 0; k0 < d.n && found < 0; k0 += 64) {
@@ -647,8 +652,10 @@ __global__ void __launch_bounds__(256) k_rollout_dense(EnvTables t, DenseArgs dn
         const unsigned long long me = __ballot(eq);
         if (me) found = k0 + __ffsll((long long)me) - 1;
       }
-      rraw = t.sp_reward[ebase + d.first + found];
+      ent += found;
+      rraw = t.sp_reward[ent];
     }
+    if (t.sp_rkind && t.sp_rkind[ent] == 1) rraw = philox_beta(t.sp_rp0[ent], t.sp_rp1[ent], nt - 1, key);
     sum += rraw * t.rscale - t.rmin;
     if (lane == 0) {
       bump(t.visits_s + soff + nxt);

@@ -112,8 +112,11 @@ typedef struct cmdp_desc {
   const int32_t* sp_next;    /* [E]   successor state index, local to the instance                   */
   const double*  sp_cum;     /* [E]   itertools.accumulate(probs) within the row                     */
   const double*  sp_reward;  /* [E]   reward of (s,a,s'): the deterministic value (loc)              */
-  const uint8_t* sp_rkind;   /* [E]   0 deterministic; else CMDP_ERR_UNSUPPORTED unless
-                                      CMDP_FLAG_REWARD_MEANS; NULL = all 0                             */
+  const uint8_t* sp_rkind;   /* [E]   0 deterministic, 1 Beta(sp_rp0, sp_rp1); NULL = all 0.  Beta entries
+                                      need CMDP_FLAG_REWARD_MEANS (report the mean) or CMDP_RNG_PHILOX with
+                                      sp_rp0/sp_rp1 (sampled on the device, Philox domain 3)            */
+  const double*  sp_rp0;     /* [E]   Beta a (ignored for deterministic entries); may be NULL           */
+  const double*  sp_rp1;     /* [E]   Beta b                                                            */
   const int32_t* sp_seed;    /* [R]   seed given to the row's NextStateSampler (MT_COMPAT)           */
   const int64_t* start_off;  /* [B+1]                                                                */
   const int32_t* start_state;/* [NS]  starting states, local index                                   */

@@ -33,6 +33,7 @@ def lib():
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_int32, C.c_uint64]
         L.oracle_env_destroy.argtypes = [C.c_void_p]
+        L.oracle_env_set_reward_dists.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_env_set_dense.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_env_reset.restype = C.c_int32
         L.oracle_env_reset.argtypes = [C.c_void_p]
@@ -80,20 +81,21 @@ class OracleEnv:
     """One instance of the interaction loop on the CPU oracle.  `model` is a colosseum_amd TabularModel
     (only its plain arrays are read)."""
 
-    def __init__(self, model, rng_mode=0, philox_key=0, dense=False):
+    def __init__(self, model, rng_mode=0, philox_key=0, dense=False, sample_beta=False):
         L = lib()
         self._keep = dict(
             sp_ptr=np.ascontiguousarray(model.sp_ptr, np.int64),
             sp_next=np.ascontiguousarray(model.sp_next, np.int32),
             sp_cum=np.ascontiguousarray(model.sp_cum, np.float64),
-            sp_reward=np.ascontiguousarray(model.sp_rp0, np.float64),
+            sp_reward=np.ascontiguousarray(np.where(model.sp_rkind == 0, model.sp_rp0, model.sp_rmean), np.float64),
             sp_seed=np.ascontiguousarray(model.sp_seed, np.int32),
             start_state=np.ascontiguousarray(model.start_states, np.int32),
             start_cum=np.ascontiguousarray(np.cumsum(model.start_probs), np.float64),
         )
         # itertools.accumulate == sequential float64 adds == np.cumsum on float64
-        if not model.deterministic_rewards:
-            raise NotImplementedError("oracle restates deterministic rewards only")
+        if not model.deterministic_rewards and not sample_beta:
+            raise NotImplementedError("Beta rewards: pass sample_beta=True (Philox recipe); the reference-exact "
+                                      "stream is colosseum_amd.mdp.reward_sampler")
         k = self._keep
         self.S, self.A, self.H = model.n_states, model.n_actions, model.H
         self._e = L.oracle_env_create(self.S, self.A, self.H, rng_mode, model.rewards_range[0],
@@ -101,6 +103,11 @@ class OracleEnv:
                                       _ptr(k["sp_cum"]), _ptr(k["sp_reward"]), _ptr(k["sp_seed"]),
                                       len(k["start_state"]), _ptr(k["start_state"]), _ptr(k["start_cum"]),
                                       int(model.start_seed), int(philox_key))
+        if sample_beta:
+            assert rng_mode == 1
+            k.update(r_kind=np.ascontiguousarray(model.sp_rkind, np.uint8), r_p0=np.ascontiguousarray(model.sp_rp0, np.float64),
+                     r_p1=np.ascontiguousarray(model.sp_rp1, np.float64))
+            L.oracle_env_set_reward_dists(self._e, _ptr(k["r_kind"]), _ptr(k["r_p0"]), _ptr(k["r_p1"]))
         if dense:
             assert rng_mode == 1
             ptr, col, val = _csr64(model.csr())

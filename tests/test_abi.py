@@ -28,7 +28,7 @@ def test_header_and_library_agree():
 
 
 def test_struct_layout_matches_header():
-    assert C.sizeof(L.CmdpDesc) == 6 * 4 + 2 * 8 + 16 * 8
+    assert C.sizeof(L.CmdpDesc) == 6 * 4 + 2 * 8 + 18 * 8
 
 
 def test_no_silent_cpu_fallback():
