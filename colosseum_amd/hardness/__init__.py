@@ -35,6 +35,41 @@ def diameter(models: Sequence[TabularModel], epsilon: float = 1e-3) -> np.ndarra
     return out
 
 
+def sum_reciprocals_suboptimality_gaps(models: Sequence[TabularModel], regularization: float = 0.1) -> np.ndarray:
+    """`get_sum_reciprocals_suboptimality_gaps` (colosseum/hardness/measures/sum_reciprocals_suboptimality_gaps.py:6-28)
+    on the optimal value functions (`BaseMDP.sum_reciprocals_suboptimality_gaps`, mdp/base.py:1018-1040): discounted VI
+    (gamma 0.99, eps 1e-3) for continuous MDPs, backward induction restricted to the reachable (h, s) pairs for
+    episodic ones.  The DP runs on the GPU; the final reduction is the reference's numpy expression."""
+    from ..mdp.episodic import episodic_graph_nodes
+
+    out = np.zeros(len(models), np.float64)
+    groups = {}
+    for i, m in enumerate(models):
+        key = (m.H, m.n_actions, 0 if m.is_episodic else _vi_rule(m.n_states, m.n_actions, len(m.csr()[1])))
+        groups.setdefault(key, []).append(i)
+    for (H, A, scheme), idx in groups.items():
+        ms = [models[i] for i in idx]
+        dp = BatchedMDP(ms, with_env=False)
+        if H > 0:
+            Q, V = dp.episodic_value_iteration()
+            for j, m in enumerate(ms):
+                S = m.n_states
+                q = dp.split_rows(Q, H + 1)[j].reshape(H + 1, S, A)
+                v = dp.split_states(V, H + 1)[j].reshape(H + 1, S)
+                gaps = v[..., None] - q
+                reach = episodic_graph_nodes(m)[0]
+                gaps = np.vstack([gaps[h, s] for h, s in reach])
+                out[idx[j]] = (1 / (gaps + regularization)).sum()
+        else:
+            Q, V, _ = dp.value_iteration(0.99, 1e-3, scheme)
+            for j, m in enumerate(ms):
+                q = dp.split_rows(Q)[j].reshape(m.n_states, A)
+                v = dp.split_states(V)[j]
+                out[idx[j]] = (1 / (v[..., None] - q + regularization)).sum()
+        dp.close()
+    return out
+
+
 def value_norm(models: Sequence[TabularModel]) -> np.ndarray:
     """`BaseMDP.discounted_value_norm`: 0 for fully deterministic MDPs, else
     `calculate_norm_discounted(T, V*)` with V* = discounted_value_iteration(T, R) (gamma 0.99, eps 1e-3, the

@@ -519,3 +519,19 @@ def test_dense_row_layout_vs_oracle(need_gpu):
         np.testing.assert_array_equal(x, y)
     with pytest.raises(L.CmdpError):
         BatchedMDP(models, rng_mode=L.RNG_MT_COMPAT, layout=L.LAYOUT_DENSE)
+
+
+def test_suboptimality_gaps_vs_reference(need_gpu):
+    import json
+    import os
+
+    from conftest import GOLDEN
+    from colosseum_amd import hardness
+
+    rows = json.load(open(os.path.join(GOLDEN, "G6_hardness_ref.json")))
+    models = [make_model(r["cls"], **r["kwargs"]) for r in rows]
+    got = hardness.sum_reciprocals_suboptimality_gaps(models)
+    for r, g in zip(rows, got):
+        # every term 1/(gap + 0.1) amplifies a value difference by up to 1/0.1^2 = 100: values within 1e-6 (the
+        # Gauss-Seidel path is not bit-reproducible against BLAS) => the sum within ~1e-5 relative
+        assert g == pytest.approx(r["suboptimal_gaps"], rel=2e-5), r
