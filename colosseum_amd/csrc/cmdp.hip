@@ -976,6 +976,34 @@ int cmdp_diameter_episodic(cmdp_t* h, int H, const int64_t* start_off, const int
   return CMDP_OK;
 }
 
+int cmdp_gth(int count, const int32_t* dims, const double* mats, double* out) {
+  if (count < 0 || (count > 0 && (!dims || !mats || !out))) return fail(CMDP_ERR_INVALID, "bad argument");
+  if (count == 0) return CMDP_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(CMDP_ERR_NO_DEVICE, "no HIP device visible");
+  std::vector<int64_t> moff((size_t)count), xoff((size_t)count);
+  int64_t mt = 0, xt = 0;
+  for (int m = 0; m < count; ++m) {
+    if (dims[m] < 1 || dims[m] > 46340) return fail(CMDP_ERR_INVALID, "chain %d has dimension %d", m, dims[m]);
+    moff[m] = mt; xoff[m] = xt;
+    mt += (int64_t)dims[m] * dims[m];
+    xt += dims[m];
+  }
+  DevBuf<int64_t> d_moff, d_xoff;
+  DevBuf<int32_t> d_dims;
+  DevBuf<double> d_mats, d_x;
+  hipStream_t st = nullptr;  // the device's default stream: this entry point has no handle
+  HIP_TRY(d_moff.upload(moff.data(), count, st));
+  HIP_TRY(d_xoff.upload(xoff.data(), count, st));
+  HIP_TRY(d_dims.upload(dims, count, st));
+  HIP_TRY(d_mats.upload(mats, (size_t)mt, st));
+  HIP_TRY(d_x.alloc((size_t)xt));
+  hipLaunchKernelGGL(k_gth, dim3(count), dim3(256), 0, st, d_moff.p, d_dims.p, d_xoff.p, d_mats.p, d_x.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, d_x.p, sizeof(double) * (size_t)xt, hipMemcpyDeviceToHost));
+  return CMDP_OK;
+}
+
 int cmdp_value_norm(cmdp_t* h, const float* V, float* out) {
   if (int rc = bind(h)) return rc;
   if (!h->has_dp) return fail(CMDP_ERR_INVALID, "handle was created without the DP half");

@@ -1237,3 +1237,60 @@ __global__ void __launch_bounds__(256) k_value_norm(DpTables t, const float* __r
     out[b] = m;
   }
 }
+
+
+// ===================================================================================================
+// K7: stationary distribution by GTH elimination (reference colosseum/mdp/utils/markov_chain.py:139-166,
+// `_gth_solve_numba`), float64, one workgroup per chain (the matrix is a work copy in HBM/L2, n <= a few hundred
+// in the benchmark).  Step i: scale = sum_k a[i,k>i] (one lane, index order, as the reference); column i below the
+// diagonal is divided by it; the trailing block gets the rank-1 update a[j,k] += a[j,i]*a[i,k] (all threads,
+// multiply and add rounded separately).  Back-substitution and the normalisation are index-order sums as well.
+// ===================================================================================================
+__global__ void __launch_bounds__(256) k_gth(const int64_t* __restrict__ mat_off, const int32_t* __restrict__ dims,
+                                             const int64_t* __restrict__ x_off, double* __restrict__ mats,
+                                             double* __restrict__ xs) {
+  __shared__ double s_scale;
+  __shared__ int s_n;
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const int n = dims[m];
+  double* a = mats + mat_off[m];
+  double* x = xs + x_off[m];
+  if (tid == 0) s_n = n;
+  __syncthreads();
+  for (int i = 0; i < s_n - 1; ++i) {
+    const int nn = s_n;
+    if (tid == 0) {
+      double sc = 0.0;
+      for (int k = i + 1; k < nn; ++k) sc = __dadd_rn(sc, a[(size_t)i * n + k]);
+      s_scale = sc;
+      if (sc <= 0.0) s_n = i + 1;
+    }
+    __syncthreads();
+    if (s_n != nn) break;
+    const double sc = s_scale;
+    for (int j = i + 1 + tid; j < nn; j += 256) a[(size_t)j * n + i] = a[(size_t)j * n + i] / sc;
+    __syncthreads();
+    const int w = nn - i - 1;
+    for (int e = tid; e < w * w; e += 256) {
+      const int j = i + 1 + e / w, k = i + 1 + e % w;
+      a[(size_t)j * n + k] = __dadd_rn(a[(size_t)j * n + k], __dmul_rn(a[(size_t)j * n + i], a[(size_t)i * n + k]));
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  const int nn = s_n;
+  for (int i = tid; i < n; i += 256) x[i] = 0.0;
+  __syncthreads();
+  if (tid == 0) {
+    x[nn - 1] = 1.0;
+    if (nn >= 2) x[nn - 2] = a[(size_t)(nn - 1) * n + (nn - 2)];
+    for (int i = nn - 3; i >= 0; --i) {
+      double acc = 0.0;
+      for (int j = i + 1; j < nn; ++j) acc = __dadd_rn(acc, __dmul_rn(x[j], a[(size_t)j * n + i]));
+      x[i] = acc;
+    }
+    double tot = 0.0;
+    for (int i = 0; i < nn; ++i) tot = __dadd_rn(tot, x[i]);
+    for (int i = 0; i < nn; ++i) x[i] = x[i] / tot;
+  }
+}

@@ -6,15 +6,16 @@ the regret indicators runs on the HIP dynamic-programming kernels.  Agents are h
 reference's `BaseAgent` contract (`select_action`, `step_update`, `is_episode_end`, `episode_end_update`,
 `before_start_interacting`, `agent_logs`, `current_optimal_stochastic_policy`, `is_episodic`).
 
-Built: the episodic setting (config C1).  The continuous setting needs the stationary distribution of the agent's
-Markov chain (colosseum/mdp/utils/markov_chain.py:12-31), a SURVEY section-8(f2) "next" row: it raises
-NotImplementedError."""
+Both settings are built.  Episodic regrets come from finite-horizon policy evaluation (config C1); continuous regrets
+from the stationary distribution of the agent's current greedy policy (colosseum/mdp/utils/markov_chain.py:12-31),
+computed by the GTH kernel through colosseum_amd.markov_chain."""
 from time import time
 from typing import Any, NamedTuple, Tuple
 
 import numpy as np
 
 from ..dynamic_programming import episodic_policy_evaluation, episodic_value_iteration
+from ..markov_chain import get_average_reward
 
 
 class MDPSpec(NamedTuple):
@@ -82,8 +83,6 @@ class MDPLoop:
         self._episodic = mdp.is_episodic()
         self._n_steps_to_check_for_agent_optimality = n_log_intervals_to_check_for_agent_optimality
         assert self._episodic == agent.is_episodic()
-        if not self._episodic:
-            raise NotImplementedError("continuous-setting regret needs the stationary distribution (SURVEY 8 f2)")
         self.actions_sequence = []
 
     @property
@@ -151,14 +150,24 @@ class MDPLoop:
         self._n_episodes = 0
         self._last_logs = None
         self._cached_episodic_regrets = None
+        self._cached_continuous_regrets = None
         self._latest_expected_regrets = []
         m = self._mdp
-        span = m.episodic_optimal_average_reward - m.episodic_worst_average_reward
-        self._episodic_regret_random_agent = m.episodic_optimal_average_reward - m.episodic_random_average_reward
-        self._episodic_normalized_regret_random_agent = self._episodic_regret_random_agent / span
-        self._episodic_regret_worst_agent = span
-        self._episodic_normalized_regret_worst_agent = self._episodic_regret_worst_agent / span
-        self._cumulative_reward_normalizer = lambda t, cr: (cr - t * m.episodic_worst_average_reward) / span
+        if self._episodic:
+            span = m.episodic_optimal_average_reward - m.episodic_worst_average_reward
+            self._episodic_regret_random_agent = m.episodic_optimal_average_reward - m.episodic_random_average_reward
+            self._episodic_normalized_regret_random_agent = self._episodic_regret_random_agent / span
+            self._episodic_regret_worst_agent = span
+            self._episodic_normalized_regret_worst_agent = self._episodic_regret_worst_agent / span
+            self._cumulative_reward_normalizer = lambda t, cr: (cr - t * m.episodic_worst_average_reward) / span
+        else:
+            span = m.optimal_average_reward - m.worst_average_reward
+            self._regret_random_agent = m.optimal_average_reward - m.random_average_reward
+            self._normalized_regret_random_agent = self._regret_random_agent / span
+            self._regret_worst_agent = span
+            self._normalized_regret_worst_agent = self._regret_worst_agent / span
+            assert span > 0.0002, type(m).__name__ + str(m.parameters)  # agent_mdp_interaction.py:379-382
+            self._cumulative_reward_normalizer = lambda t, cr: (cr - t * m.worst_average_reward) / span
         self.logger.reset()
         self._mdp_loop_timer = time()
 
@@ -191,20 +200,53 @@ class MDPLoop:
 
     # -- agent_mdp_interaction.py:435-502 -------------------------------------------------------------------------------
     def _compute_performance_indicators(self, t: int):
-        self._compute_episodic_regret()
         m = self._mdp
-        self._cumulative_regret_random_agent = self._episodic_regret_random_agent * t
-        self._normalized_cumulative_regret_random_agent = self._episodic_normalized_regret_random_agent * t
-        self._cumulative_regret_worst_agent = self._episodic_regret_worst_agent * t
-        self._normalized_cumulative_regret_worst_agent = self._episodic_normalized_regret_worst_agent * t
-        self._cumulative_reward_random_agent = m.episodic_random_average_reward * t
-        self._cumulative_reward_worst_agent = m.episodic_worst_average_reward * t
-        self._cumulative_reward_optimal_agent = m.episodic_optimal_average_reward * t
+        if self._episodic:
+            self._compute_episodic_regret()
+            self._cumulative_regret_random_agent = self._episodic_regret_random_agent * t
+            self._normalized_cumulative_regret_random_agent = self._episodic_normalized_regret_random_agent * t
+            self._cumulative_regret_worst_agent = self._episodic_regret_worst_agent * t
+            self._normalized_cumulative_regret_worst_agent = self._episodic_normalized_regret_worst_agent * t
+            self._cumulative_reward_random_agent = m.episodic_random_average_reward * t
+            self._cumulative_reward_worst_agent = m.episodic_worst_average_reward * t
+            self._cumulative_reward_optimal_agent = m.episodic_optimal_average_reward * t
+            agent_average_reward = lambda: self._episodic_agent_average_reward / m.H  # noqa: E731
+        else:
+            self._compute_continuous_regret()
+            self._cumulative_regret_random_agent = self._regret_random_agent * t
+            self._normalized_cumulative_regret_random_agent = self._normalized_regret_random_agent * t
+            self._cumulative_regret_worst_agent = self._regret_worst_agent * t
+            self._normalized_cumulative_regret_worst_agent = self._normalized_regret_worst_agent * t
+            self._cumulative_reward_random_agent = m.random_average_reward * t
+            self._cumulative_reward_worst_agent = m.worst_average_reward * t
+            self._cumulative_reward_optimal_agent = m.optimal_average_reward * t
+            agent_average_reward = lambda: self._agent_continuous_average_reward  # noqa: E731
         assert self._regret >= 0.0, self._regret
         assert self._normalized_regret >= 0.0, self._normalized_regret
         self._cumulative_regret += self._regret * self._n_steps_since_last_log
         self._normalized_cumulative_regret += self._normalized_regret * self._n_steps_since_last_log
-        self._cumulative_expected_reward_agent += (self._episodic_agent_average_reward / m.H) * self._n_steps_since_last_log
+        self._cumulative_expected_reward_agent += agent_average_reward() * self._n_steps_since_last_log
+
+    # -- agent_mdp_interaction.py:510-532 ---------------------------------------------------------------------------------
+    def _compute_continuous_regret(self):
+        if not self._is_training:
+            if self._cached_continuous_regrets is None:
+                self._cached_continuous_regrets = self._get_continuous_regrets()
+            self._regret, self._normalized_regret = self._cached_continuous_regrets
+        else:
+            self._regret, self._normalized_regret = self._get_continuous_regrets()
+
+    def _get_continuous_regrets(self):
+        m = self._mdp
+        self._agent_continuous_average_reward = get_average_reward(
+            m.T, m.R, self._agent.current_optimal_stochastic_policy, [(m.node_to_index[m.cur_node], 1.0)])
+        r = m.optimal_average_reward - self._agent_continuous_average_reward
+        if np.isclose(r, 0.0, atol=1e-3):
+            r = 0.0
+        if r < 0:
+            r = 0
+        nr = r / (m.optimal_average_reward - m.worst_average_reward)
+        return r, nr
 
     # -- agent_mdp_interaction.py:534-578 ---------------------------------------------------------------------------------
     def _compute_episodic_regret(self):
@@ -232,7 +274,10 @@ class MDPLoop:
 
     def _is_policy_optimal(self) -> bool:
         if (len(self._latest_expected_regrets) == self._n_steps_to_check_for_agent_optimality
-                and np.isclose(0, self._latest_expected_regrets, atol=1e-4).all()):
-            self._compute_episodic_regret()
+                and np.isclose(0, self._latest_expected_regrets, atol=1e-4 if self._episodic else 1e-5).all()):
+            if self._episodic:
+                self._compute_episodic_regret()
+            else:
+                self._compute_continuous_regret()
             return bool(np.isclose(self._normalized_regret, 0).all())
         return False

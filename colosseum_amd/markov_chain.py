@@ -1,0 +1,84 @@
+"""Markov chain of a policy: transition probabilities, stationary distribution, average reward
+(reference colosseum/mdp/utils/markov_chain.py:12-136).  The recurrent-class bookkeeping is host side (scipy's
+strongly connected components instead of networkx's `attracting_components`: the same sets); the stationary
+distribution of every recurrent class is computed on the GPU by the GTH kernel (`cmdp_gth`).
+
+Deviation, documented: above 500 x 500 the reference switches to ARPACK's shift-invert eigen solver
+(`_eigen_method`, :188-203; parity-unpinned in SURVEY 8c); GTH is used here for every size -- the two agree to ~1e-8."""
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+from scipy.sparse import csr_matrix
+from scipy.sparse.csgraph import breadth_first_order, connected_components
+
+from . import _lib as L
+
+
+def get_average_rewards(R: np.ndarray, policy: np.ndarray) -> np.ndarray:
+    return np.einsum("sa,sa->s", R, policy)
+
+
+def get_transition_probabilities(T: np.ndarray, policy: np.ndarray) -> np.ndarray:
+    return np.minimum(1.0, np.einsum("saj,sa->sj", T, policy))
+
+
+def gth_batch(mats: Sequence[np.ndarray]) -> List[np.ndarray]:
+    """Stationary distributions of single-recurrent-class chains on the device (float64 GTH)."""
+    lib = L.load()
+    mats = [np.ascontiguousarray(m, np.float64) for m in mats]
+    if not mats:
+        return []
+    dims = np.array([m.shape[0] for m in mats], np.int32)
+    flat = np.concatenate([m.ravel() for m in mats])
+    out = np.zeros(int(dims.sum()), np.float64)
+    L.check(lib.cmdp_gth(len(mats), L.ptr(dims), L.ptr(flat), L.ptr(out)))
+    off = np.concatenate([[0], np.cumsum(dims)])
+    return [out[off[i]: off[i + 1]] for i in range(len(mats))]
+
+
+def recurrent_classes(tps: np.ndarray) -> List[np.ndarray]:
+    """Closed communicating classes (the attracting components of the chain's digraph), each in ascending order."""
+    n = len(tps)
+    g = csr_matrix(tps > 0)
+    ncomp, label = connected_components(g, directed=True, connection="strong")
+    src, dst = g.nonzero()
+    leaks = np.zeros(ncomp, bool)
+    leaks[label[src[label[src] != label[dst]]]] = True
+    return [np.flatnonzero(label == c) for c in range(ncomp) if not leaks[c]]
+
+
+def _class_distribution(tps: np.ndarray, cls: np.ndarray) -> np.ndarray:
+    if len(cls) == 1:
+        return np.ones(1)
+    return gth_batch([tps[np.ix_(cls, cls)]])[0]
+
+
+def get_stationary_distribution(tps: np.ndarray,
+                                starting_states_and_probs: Optional[Iterable[Tuple[int, float]]]) -> np.ndarray:
+    """markov_chain.py:64-136."""
+    n = len(tps)
+    classes = recurrent_classes(tps)
+    if len(classes) == 1 and len(classes[0]) < n:
+        sd = np.zeros(n, np.float32)
+        sd[classes[0]] = _class_distribution(tps, classes[0])
+        return sd
+    if len(classes) > 1:
+        sd = np.zeros(n)
+        g = csr_matrix(tps > 0)
+        for ss, p in starting_states_and_probs:
+            reach = set(breadth_first_order(g, ss, directed=True, return_predecessors=False).tolist())
+            for cls in classes:  # the first recurrent class the starting state is connected to
+                if int(cls[0]) in reach:
+                    sd[cls] += p * _class_distribution(tps, cls)
+                    break
+        return sd
+    return _class_distribution(tps, np.arange(n))
+
+
+def get_average_reward(T: np.ndarray, R: np.ndarray, policy: np.ndarray, next_states_and_probs) -> float:
+    """markov_chain.py:12-31."""
+    assert np.isclose(policy.sum(-1), 1).all(), "the policy specification is incorrect."
+    average_rewards = get_average_rewards(R, policy)
+    tps = get_transition_probabilities(T, policy)
+    sd = get_stationary_distribution(tps, next_states_and_probs)
+    return (average_rewards * sd).sum()

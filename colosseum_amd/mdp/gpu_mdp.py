@@ -222,6 +222,50 @@ class GpuMDP:
     def episodic_random_average_reward(self):
         return self._memo("erar", lambda: self._episodic_average(self.get_random_policy_starting_value))
 
+    # -- Markov chains of the baseline policies, average rewards (colosseum/mdp/base.py:681-941) -------------------
+    def get_stationary_distribution(self, policy):
+        from .. import markov_chain as mc
+
+        return mc.get_stationary_distribution(mc.get_transition_probabilities(self.T, policy),
+                                              self.starting_states_and_probs)
+
+    def get_average_reward(self, policy):
+        from .. import markov_chain as mc
+
+        return sum(self.get_stationary_distribution(policy) * mc.get_average_rewards(self.R, policy))
+
+    def _baseline(self, which):
+        """(transition probabilities, stationary distribution, per-state average rewards, average reward) of the
+        optimal / worst / uniform policy; for episodic MDPs the reference evaluates them on the continuous form,
+        which is not built (not used by the episodic MDPLoop)."""
+        from .. import markov_chain as mc
+
+        if self._episodic:
+            raise NotImplementedError("average rewards of episodic MDPs (continuous form chains) are not built")
+
+        def f():
+            pi = {"optimal": lambda: self.get_optimal_policy(True), "worst": lambda: self.get_worst_policy(True),
+                  "random": lambda: self.random_policy}[which]()
+            tps = mc.get_transition_probabilities(self.T, pi)
+            sd = mc.get_stationary_distribution(tps, None if which == "random" else self.starting_states_and_probs)
+            ars = mc.get_average_rewards(self.R, pi)
+            return tps, sd, ars, sum(sd * ars)
+
+        return self._memo(("baseline", which), f)
+
+    optimal_transition_probabilities = property(lambda self: self._baseline("optimal")[0])
+    worst_transition_probabilities = property(lambda self: self._baseline("worst")[0])
+    random_transition_probabilities = property(lambda self: self._baseline("random")[0])
+    optimal_stationary_distribution = property(lambda self: self._baseline("optimal")[1])
+    worst_stationary_distribution = property(lambda self: self._baseline("worst")[1])
+    random_stationary_distribution = property(lambda self: self._baseline("random")[1])
+    optimal_average_rewards = property(lambda self: self._baseline("optimal")[2])
+    worst_average_rewards = property(lambda self: self._baseline("worst")[2])
+    random_average_rewards = property(lambda self: self._baseline("random")[2])
+    optimal_average_reward = property(lambda self: self._baseline("optimal")[3])
+    worst_average_reward = property(lambda self: self._baseline("worst")[3])
+    random_average_reward = property(lambda self: self._baseline("random")[3])
+
     # -- hardness (continuous setting; colosseum/mdp/base.py:996-1016,1060-1081) -----------------------------------
     @property
     def diameter(self):

@@ -227,6 +227,13 @@ int cmdp_diameter_episodic(cmdp_t* h, int H, const int64_t* start_off, const int
 /* calculate_norm_discounted (colosseum/hardness/measures/value_norm.py:83-87). V [state_off[B]]. */
 int cmdp_value_norm(cmdp_t* h, const float* V, float* out);
 
+/* ---- Markov chains ------------------------------------------------------------------------------------ */
+/* _gth_solve_numba (colosseum/mdp/utils/markov_chain.py:139-166): stationary distributions of `count` chains with a
+   single recurrent class each, float64 GTH elimination on the current device.  Chain m is the dims[m] x dims[m]
+   row-major matrix at mats + sum_{i<m} dims[i]^2 (not modified); its distribution goes to
+   out + sum_{i<m} dims[i]. */
+int cmdp_gth(int count, const int32_t* dims, const double* mats, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,8 @@ Fixture groups:
   G5  hardness known-answer table lifted from benchmark/cached_hardness_measures/*.txt
   G6  episodic/continuous diameter + value-norm recomputed by the reference here (small cases)
   G7  MDPLoop + QLearningEpisodic logger rows and action stream (config C1, plumbing)
+  G10 MDPLoop + QLearningContinuous logger rows (continuous-setting regret via stationary distributions)
+  G9  stationary distributions / average rewards of the continuous setting
   G8  trajectories with Beta rewards (the MDP's numpy stream, 5000-sample caches per visited triple)
 """
 import json
@@ -547,7 +549,99 @@ def g8():
     save("G8_stochastic_rewards", **arrays)
 
 
-GROUPS = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8)
+def g9():
+    """Continuous setting: stationary distributions and average rewards of the optimal / worst / uniform policies and of
+    a random stochastic policy (colosseum/mdp/utils/markov_chain.py:12-136, mdp/base.py:700-941)."""
+    from colosseum.mdp.utils.markov_chain import get_average_reward, get_stationary_distribution, get_transition_probabilities
+
+    specs = [
+        ("DeepSeaContinuous", dict(seed=0, size=6, p_rand=0.2)),
+        ("DeepSeaContinuous", dict(seed=1, size=10)),
+        ("FrozenLakeContinuous", dict(seed=0, size=5, p_frozen=0.95, p_lazy=0.01, p_rand=0.05)),
+        ("FrozenLakeContinuous", dict(seed=3, size=8, p_frozen=0.8, is_slippery=False)),
+        ("MiniGridEmptyContinuous", dict(seed=0, size=5, p_rand=0.1, n_starting_states=2)),
+        ("MiniGridEmptyContinuous", dict(seed=2, size=6)),
+        ("MiniGridRoomsContinuous", dict(seed=0, room_size=3, n_rooms=4, p_lazy=0.1, n_starting_states=2)),
+    ]
+    cases, arrays = [], {}
+    for cls, kw in specs:
+        mdp = CLASSES[cls](**kw)
+        key = f"c{len(cases)}_"
+        T, R = mdp.transition_matrix_and_rewards
+        info = dict(cls=cls, kwargs=kw, n_states=mdp.n_states,
+                    optimal_average_reward=float(mdp.optimal_average_reward),
+                    worst_average_reward=float(mdp.worst_average_reward),
+                    random_average_reward=float(mdp.random_average_reward))
+        arrays[key + "sd_optimal"] = np.asarray(mdp.optimal_stationary_distribution, np.float64)
+        arrays[key + "sd_worst"] = np.asarray(mdp.worst_stationary_distribution, np.float64)
+        arrays[key + "sd_random"] = np.asarray(mdp.random_stationary_distribution, np.float64)
+        arrays[key + "pi_optimal"] = np.asarray(mdp.get_optimal_policy(True), np.float32)
+        arrays[key + "pi_worst"] = np.asarray(mdp.get_worst_policy(True), np.float32)
+        pol = np.random.RandomState(9).dirichlet(np.ones(mdp.n_actions), mdp.n_states).astype(np.float32)
+        arrays[key + "pi_rand"] = pol
+        starts = [(mdp.node_to_index[mdp.starting_nodes[0]], 1.0)]
+        info["avg_reward_pi_rand"] = float(get_average_reward(T, R, pol, starts))
+        arrays[key + "sd_pi_rand"] = np.asarray(get_stationary_distribution(get_transition_probabilities(T, pol), starts), np.float64)
+        cases.append(info)
+        print("   ", cls, kw, {k: v for k, v in info.items() if "reward" in k})
+    arrays["cases"] = np.array(json.dumps(cases))
+    save("G9_stationary", **arrays)
+
+
+def g10():
+    """Continuous-setting MDPLoop: the reference's QLearningContinuous (tuned hyper-parameters of
+    benchmark/cached_hyperparameters/agent_configs/QLearningContinuous.gin) on continuous MDPs; logger rows whose regret
+    columns come from the stationary distribution of the agent's current greedy policy."""
+    import importlib
+    import types
+
+    from colosseum.experiment.agent_mdp_interaction import MDPLoop
+    from colosseum.utils.acme.specs import make_mdp_spec
+
+    _import_reference_qlearning()
+    name = "colosseum.agent.agents.infinite_horizon"
+    if name not in sys.modules:
+        try:
+            importlib.import_module(name)
+        except Exception:
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(ref_env.REFERENCE, "colosseum", "agent", "agents", "infinite_horizon")]
+            sys.modules[name] = m
+    from colosseum.agent.agents.infinite_horizon.q_learning import QLearningContinuous
+
+    hp = dict(h_weight=0.942, span_approx_weight=0.014, min_at=0.073)
+    cases = []
+    for cls, mdp_kw, T, log_every in (
+        ("DeepSeaContinuous", dict(seed=0, size=5, p_rand=0.1), 8_000, 500),
+        ("FrozenLakeContinuous", dict(seed=2, size=4, p_frozen=0.9, p_lazy=0.05), 6_000, 500),
+        ("MiniGridEmptyContinuous", dict(seed=1, size=4, p_rand=0.2, n_starting_states=2), 6_000, 1000),
+    ):
+        mdp = CLASSES[cls](**mdp_kw)
+        agent = QLearningContinuous(seed=mdp_kw["seed"], mdp_specs=make_mdp_spec(mdp), optimization_horizon=T, **hp)
+        actions = []
+        sel = agent.select_action
+
+        def select_action(ts, h, _sel=sel, _log=actions):
+            a = _sel(ts, h)
+            _log.append(int(a))
+            return a
+
+        agent.select_action = select_action
+        loop = MDPLoop(mdp, agent)
+        last_training_step, _ = loop.run(T=T, log_every=log_every)
+        rows = [{k: float(v) for k, v in r.items() if k != "steps_per_second"} for r in loop.logger.data]
+        cases.append(dict(mdp_cls=cls, mdp_kwargs=mdp_kw, agent="QLearningContinuous",
+                          agent_kwargs=dict(seed=mdp_kw["seed"], optimization_horizon=T, **hp), T=T, log_every=log_every,
+                          last_training_step=int(last_training_step), rows=rows, actions=actions,
+                          optimal_average_reward=float(mdp.optimal_average_reward),
+                          worst_average_reward=float(mdp.worst_average_reward),
+                          random_average_reward=float(mdp.random_average_reward)))
+        print("   ", cls, mdp_kw, "rows", len(rows), "cumulative_regret", rows[-1]["cumulative_regret"])
+    with open(os.path.join(OUT, "G10_mdploop_continuous.json"), "w") as f:
+        json.dump(cases, f)
+
+
+GROUPS = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

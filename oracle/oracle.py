@@ -63,6 +63,8 @@ def lib():
         L.oracle_diameter_episodic.restype = C.c_int
         L.oracle_diameter_episodic.argtypes = [C.c_int, C.c_int, C.c_int, _i64p, _i32p, _f32p, C.c_int, _i32p, _f32p,
                                                C.c_double, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+        L.oracle_gth.restype = C.c_int
+        L.oracle_gth.argtypes = [C.c_int, _f64p, _f64p]
         L.oracle_batch_rollout.restype = C.c_int
         L.oracle_batch_rollout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double] + \
             [C.c_void_p] * 11 + [C.c_int64] + [C.c_void_p] * 4
@@ -286,3 +288,12 @@ def batch_vi(tables, b0, b1, gamma=0.99, eps=1e-6, scheme=0, max_sweeps=1_000_00
     if tot < 0:
         raise RuntimeError(f"oracle batch VI failed ({tot})")
     return Q, V, sw
+
+
+def gth(tps):
+    """Stationary distribution of a single-recurrent-class chain (float64 GTH, the reference's numba routine)."""
+    a = np.array(tps, np.float64, order="C", copy=True)
+    n = a.shape[0]
+    x = np.zeros(n, np.float64)
+    lib().oracle_gth(n, a, x)
+    return x

@@ -10,7 +10,7 @@ import pytest
 from conftest import GOLDEN
 from colosseum_amd.experiment import MDPLoop, make_mdp_spec
 from colosseum_amd.mdp import gpu_mdp
-from helpers_agents import QLearningEpisodic
+from helpers_agents import QLearningContinuous, QLearningEpisodic
 
 pytestmark = pytest.mark.gpu
 
@@ -58,5 +58,50 @@ def test_mdploop_qlearning_matches_reference_logs(need_gpu):
             assert set(ref) == set(got) - {"steps_per_second"}
             for k, v in ref.items():
                 # values are rounded to 5 decimals by the loop; float32 DP => 1e-6 relative slack on top
+                assert float(got[k]) == pytest.approx(v, rel=2e-6, abs=2e-5), (k, got["steps"])
+        mdp.close()
+
+
+def test_stationary_distributions_and_average_rewards(need_gpu):
+    """GTH kernel + recurrent-class logic vs the reference (golden G9) and the oracle's sequential GTH."""
+    import numpy as np
+
+    from conftest import load_golden
+    from colosseum_amd import markov_chain as mc
+    from oracle import oracle as O
+
+    z, cases = load_golden("G9_stationary")
+    for i, c in enumerate(cases):
+        mdp = getattr(gpu_mdp, c["cls"])(**c["kwargs"])
+        k = f"c{i}_"
+        for name in ("optimal", "worst", "random"):
+            np.testing.assert_allclose(getattr(mdp, f"{name}_stationary_distribution"), z[k + f"sd_{name}"], atol=1e-12)
+            assert getattr(mdp, f"{name}_average_reward") == pytest.approx(c[f"{name}_average_reward"], rel=1e-9, abs=1e-12)
+        ar = mc.get_average_reward(mdp.T, mdp.R, z[k + "pi_rand"], [(mdp.starting_states[0], 1.0)])
+        assert ar == pytest.approx(c["avg_reward_pi_rand"], rel=1e-9)
+        tps = mc.get_transition_probabilities(mdp.T, z[k + "pi_rand"])
+        cls = mc.recurrent_classes(tps)[0]
+        sub = tps[np.ix_(cls, cls)]
+        np.testing.assert_array_equal(mc.gth_batch([sub, sub])[1], O.gth(sub))  # device == oracle, bit for bit
+        mdp.close()
+
+
+def test_mdploop_continuous_matches_reference_logs(need_gpu):
+    cases = json.load(open(os.path.join(GOLDEN, "G10_mdploop_continuous.json")))
+    for c in cases:
+        mdp = getattr(gpu_mdp, c["mdp_cls"])(**c["mdp_kwargs"])
+        assert mdp.optimal_average_reward == pytest.approx(c["optimal_average_reward"], rel=1e-9)
+        agent = QLearningContinuous(mdp_specs=make_mdp_spec(mdp), **c["agent_kwargs"])
+        actions = []
+        sel = agent.select_action
+        agent.select_action = lambda ts, h, _s=sel: (actions.append(int(_s(ts, h))) or actions[-1])
+        loop = MDPLoop(mdp, agent)
+        last, logs = loop.run(T=c["T"], log_every=c["log_every"])
+        assert last == c["last_training_step"]
+        assert actions == c["actions"]
+        rows = loop.logger.data
+        assert len(rows) == len(c["rows"])
+        for got, ref in zip(rows, c["rows"]):
+            for k, v in ref.items():
                 assert float(got[k]) == pytest.approx(v, rel=2e-6, abs=2e-5), (k, got["steps"])
         mdp.close()

@@ -208,3 +208,27 @@ def test_episodic_value_norm_continuous_form():
         assert vnorm(m) == pytest.approx(r["value"], rel=2e-6, abs=1e-6), r
         n += 1
     assert n >= 8
+
+
+def test_gth_stationary_distribution_vs_reference(monkeypatch):
+    """Oracle GTH (float64, index-order sums) + the host recurrent-class logic against the reference's stationary
+    distributions and average rewards (golden G9).  The device kernel is swapped for the oracle here (no GPU)."""
+    import colosseum_amd.markov_chain as mc
+
+    monkeypatch.setattr(mc, "gth_batch", lambda mats: [O.gth(m) for m in mats])
+    z, cases = load_golden("G9_stationary")
+    for i, c in enumerate(cases):
+        m = make_model(c["cls"], **c["kwargs"])
+        T, R = m.dense()
+        k = f"c{i}_"
+        starts = list(zip(m.start_states.tolist(), m.start_probs.tolist()))
+        for name in ("optimal", "worst"):
+            pi = z[k + f"pi_{name}"]
+            sd = mc.get_stationary_distribution(mc.get_transition_probabilities(T, pi), starts)
+            np.testing.assert_allclose(sd, z[k + f"sd_{name}"], atol=1e-12)
+            assert sum(sd * mc.get_average_rewards(R, pi)) == pytest.approx(c[f"{name}_average_reward"], rel=1e-9, abs=1e-12)
+        pi = np.ones((m.n_states, m.n_actions), np.float32) / m.n_actions
+        np.testing.assert_allclose(mc.get_stationary_distribution(mc.get_transition_probabilities(T, pi), None),
+                                   z[k + "sd_random"], atol=1e-12)
+        ar = mc.get_average_reward(T, R, z[k + "pi_rand"], [(int(m.start_states[0]), 1.0)])
+        assert ar == pytest.approx(c["avg_reward_pi_rand"], rel=1e-9)
