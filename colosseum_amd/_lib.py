@@ -25,7 +25,8 @@ EXPORTS = [
     "cmdp_version", "cmdp_last_error", "cmdp_device_count", "cmdp_set_device", "cmdp_create", "cmdp_destroy",
     "cmdp_stream", "cmdp_reset", "cmdp_step", "cmdp_rollout", "cmdp_rollout_async", "cmdp_synchronize", "cmdp_set_option",
     "cmdp_visits", "cmdp_reset_visits", "cmdp_state", "cmdp_vi_discounted", "cmdp_pe_discounted",
-    "cmdp_vi_episodic", "cmdp_pe_episodic", "cmdp_diameter", "cmdp_diameter_episodic", "cmdp_value_norm", "cmdp_gth",
+    "cmdp_vi_episodic", "cmdp_pe_episodic", "cmdp_diameter", "cmdp_diameter_episodic", "cmdp_value_norm", "cmdp_gth", "cmdp_qlearning_create", "cmdp_qlearning_destroy", "cmdp_qlearning_run",
+    "cmdp_qlearning_tables",
 ]
 
 
@@ -90,6 +91,10 @@ def load():
         L.cmdp_diameter_episodic.argtypes = [vp, i32, vp, vp, vp, f64, i64, vp, vp]
         L.cmdp_value_norm.argtypes = [vp, vp, vp]
         L.cmdp_gth.argtypes = [i32, vp, vp, vp]
+        L.cmdp_qlearning_create.argtypes = [C.POINTER(vp), vp, vp, i64, f64, f64, f64, f64, i32]
+        L.cmdp_qlearning_destroy.argtypes = [vp]
+        L.cmdp_qlearning_run.argtypes = [vp, i64, i32, vp, vp]
+        L.cmdp_qlearning_tables.argtypes = [vp, vp, vp]
         _lib = L
     return _lib
 

@@ -1,0 +1,54 @@
+"""Agents that run on the device next to their environments.
+
+`BatchedQLearningEpisodic` = one reference `QLearningEpisodic` agent (colosseum/agent/agents/episodic/q_learning.py)
+per instance of a `BatchedMDP`, advanced by a kernel that fuses select_action -> step -> step_update; Q tables and action
+streams are bit-equal to the reference agent driven by the reference's MDPLoop (golden G7)."""
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+from .batched import BatchedMDP
+
+
+class BatchedQLearningEpisodic:
+    def __init__(self, env: BatchedMDP, seeds: Sequence[int], optimization_horizon: int, p: float, c_1: float,
+                 c_2: Optional[float] = None, min_at: float = 0.0, UCB_type: str = "hoeffding"):
+        ucb = {"hoeffding": 0, "bernstein": 1}[UCB_type.lower()]
+        self._lib = L.load()
+        self.env = env
+        seeds = np.ascontiguousarray(seeds, np.int32)
+        assert len(seeds) == env.B
+        self._h = C.c_void_p()
+        L.check(self._lib.cmdp_qlearning_create(C.byref(self._h), env._h, L.ptr(seeds), int(optimization_horizon), float(p),
+                                                float(c_1), float(c_2 or 0.0), float(min_at), ucb))
+
+    def run(self, n_steps: int, train: bool = True, trace_actions: bool = False):
+        n_steps = int(n_steps)
+        acts = np.zeros((n_steps, self.env.B), np.int8) if trace_actions else None
+        rsum = np.zeros(self.env.B, np.float64)
+        L.check(self._lib.cmdp_qlearning_run(self._h, n_steps, int(train), L.ptr(acts), L.ptr(rsum)))
+        return dict(reward_sum=rsum, actions=acts)
+
+    def tables(self):
+        """(Q, N): per instance arrays of shape [H, S_b, A]."""
+        env = self.env
+        n = int(env.H * env.row_off[-1])
+        Q = np.zeros(n, np.float32)
+        N = np.zeros(n, np.int32)
+        L.check(self._lib.cmdp_qlearning_tables(self._h, L.ptr(Q), L.ptr(N)))
+        qs = [x.reshape(env.H, -1, env.A) for x in env.split_rows(Q, env.H)]
+        ns = [x.reshape(env.H, -1, env.A) for x in env.split_rows(N, env.H)]
+        return qs, ns
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            self._lib.cmdp_qlearning_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

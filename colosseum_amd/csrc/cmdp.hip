@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "cmdp_kernels.h"
+#include "cmdp_agent.h"
 
 namespace {
 
@@ -973,6 +974,126 @@ int cmdp_diameter_episodic(cmdp_t* h, int H, const int64_t* start_off, const int
     diameter[b] = dmax;
   }
   if (per_target) std::memcpy(per_target, per.data(), sizeof(float) * NS);
+  return CMDP_OK;
+}
+
+// ---- device agents -----------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct cmdp_agent {
+  cmdp_t* env = nullptr;
+  QlArgs args{};
+  DevBuf<double> d_ilog, d_s7;
+  DevBuf<int64_t> d_qoff, d_voff;
+  DevBuf<int32_t> d_N, d_mtpos;
+  DevBuf<float> d_Q, d_V, d_mu, d_sigma, d_beta;
+  DevBuf<uint32_t> d_mt;
+  DevBuf<int8_t> d_act;
+  DevBuf<double> d_rsum;
+  int64_t n_q = 0, n_v = 0;
+};
+
+extern "C" {
+
+int cmdp_qlearning_create(cmdp_agent_t** out, cmdp_t* env, const int32_t* seeds, int64_t optimization_horizon, double p,
+                          double c_1, double c_2, double min_at, int ucb_type) {
+  if (!out || !env || !seeds) return fail(CMDP_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (int rc = bind(env)) return rc;
+  if (!env->has_env || env->H < 1) return fail(CMDP_ERR_INVALID, "the episodic Q-learning agent needs an episodic environment handle");
+  if (env->layout != CMDP_LAYOUT_CSR) return fail(CMDP_ERR_UNSUPPORTED, "agents run on the CSR layout");
+  if (!(p > 0 && p < 1) || !(c_1 > 0) || !(min_at >= 0 && min_at < 0.99) || (ucb_type != 0 && ucb_type != 1) ||
+      (ucb_type == 1 && !(c_2 > 0)) || optimization_horizon < 1)
+    return fail(CMDP_ERR_INVALID, "hyper-parameters out of range (0<p<1, c_1>0, 0<=min_at<0.99, bernstein needs c_2>0)");
+  const int B = env->B, A = env->A, H = env->H;
+  cmdp_agent_t* a = new cmdp_agent;
+  struct Guard { cmdp_agent_t* a; ~Guard() { delete a; } } guard{a};
+  a->env = env;
+  hipStream_t st = env->stream;
+  std::vector<double> ilog((size_t)B), s7((size_t)B);
+  std::vector<int64_t> qoff((size_t)B), voff((size_t)B);
+  for (int b = 0; b < B; ++b) {
+    const int64_t S = env->state_off[b + 1] - env->state_off[b];
+    // self.i = np.log(n_states * n_actions * optimization_horizon / p): integer product, one division, one log
+    ilog[b] = std::log((double)(S * A * optimization_horizon) / p);
+    s7[b] = std::sqrt(std::pow((double)H, 7) * (double)S * (double)A);
+    qoff[b] = (int64_t)H * env->state_off[b] * A;
+    voff[b] = (int64_t)(H + 1) * env->state_off[b];
+  }
+  a->n_q = (int64_t)H * env->n_states * A;
+  a->n_v = (int64_t)(H + 1) * env->n_states;
+  HIP_TRY(a->d_ilog.upload(ilog.data(), B, st));
+  HIP_TRY(a->d_s7.upload(s7.data(), B, st));
+  HIP_TRY(a->d_qoff.upload(qoff.data(), B, st));
+  HIP_TRY(a->d_voff.upload(voff.data(), B, st));
+  HIP_TRY(a->d_N.alloc(a->n_q));
+  HIP_TRY(a->d_Q.alloc(a->n_q));
+  HIP_TRY(a->d_V.alloc(a->n_v));
+  HIP_TRY(a->d_V.zero(st));
+  HIP_TRY(a->d_mu.alloc(a->n_q)); HIP_TRY(a->d_mu.zero(st));
+  HIP_TRY(a->d_sigma.alloc(a->n_q)); HIP_TRY(a->d_sigma.zero(st));
+  HIP_TRY(a->d_beta.alloc(a->n_q)); HIP_TRY(a->d_beta.zero(st));
+  hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(a->n_q, 256)), dim3(256), 0, st, a->d_N.p, 1, a->n_q);
+  hipLaunchKernelGGL(k_fill_f32, dim3(grid_for(a->n_q, 256)), dim3(256), 0, st, a->d_Q.p, (float)H, a->n_q);
+  HIP_TRY(a->d_mt.alloc((size_t)B * 624));
+  HIP_TRY(a->d_mtpos.alloc(B));
+  std::vector<uint32_t> useeds((size_t)B);
+  for (int b = 0; b < B; ++b) useeds[b] = (uint32_t)seeds[b];
+  DevBuf<uint32_t> d_seeds;
+  HIP_TRY(d_seeds.upload(useeds.data(), B, st));
+  hipLaunchKernelGGL(k_mt_seed_numpy, dim3(grid_for(B, 64)), dim3(64), 0, st, a->d_mt.p, a->d_mtpos.p, d_seeds.p, B);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  QlArgs& q = a->args;
+  q.H = H; q.ucb = ucb_type; q.c1 = c_1; q.c2 = c_2; q.min_at = min_at; q.H3 = (double)H * H * H;
+  q.i_log = a->d_ilog.p; q.sqrtH7SA = a->d_s7.p; q.q_off = a->d_qoff.p; q.v_off = a->d_voff.p;
+  q.N = a->d_N.p; q.Q = a->d_Q.p; q.V = a->d_V.p; q.mu = a->d_mu.p; q.sigma = a->d_sigma.p; q.beta = a->d_beta.p;
+  q.mt = a->d_mt.p; q.mt_pos = a->d_mtpos.p;
+  guard.a = nullptr;
+  *out = a;
+  return CMDP_OK;
+}
+
+int cmdp_qlearning_destroy(cmdp_agent_t* a) {
+  if (!a) return CMDP_OK;
+  if (a->env) { (void)hipSetDevice(a->env->device); (void)hipStreamSynchronize(a->env->stream); }
+  delete a;
+  return CMDP_OK;
+}
+
+int cmdp_qlearning_run(cmdp_agent_t* a, int64_t n_steps, int train, int8_t* actions_trace, double* reward_sum) {
+  if (!a) return fail(CMDP_ERR_INVALID, "null agent");
+  cmdp_t* h = a->env;
+  if (int rc = bind(h)) return rc;
+  if (n_steps < 0) return fail(CMDP_ERR_INVALID, "n_steps < 0");
+  bool any = false;
+  if (int rc = any_needs_reset(h, &any)) return rc;
+  if (any) return fail(CMDP_ERR_NEEDS_RESET, "the environment needs reset() before the agent can run");
+  hipStream_t st = h->stream;
+  const size_t NB = (size_t)n_steps * h->B;
+  if (actions_trace && a->d_act.n < NB) HIP_TRY(a->d_act.alloc(NB));
+  if (a->d_rsum.n < (size_t)h->B) HIP_TRY(a->d_rsum.alloc(h->B));
+  const dim3 grid(grid_for(h->B, 256)), block(256);
+  if (a->args.ucb == 0)
+    hipLaunchKernelGGL((k_qlearn_episodic<0>), grid, block, 0, st, h->env(), a->args, n_steps, train,
+                       actions_trace ? a->d_act.p : nullptr, a->d_rsum.p);
+  else
+    hipLaunchKernelGGL((k_qlearn_episodic<1>), grid, block, 0, st, h->env(), a->args, n_steps, train,
+                       actions_trace ? a->d_act.p : nullptr, a->d_rsum.p);
+  HIP_TRY(hipGetLastError());
+  if (actions_trace) HIP_TRY(hipMemcpyAsync(actions_trace, a->d_act.p, NB, hipMemcpyDeviceToHost, st));
+  if (reward_sum) HIP_TRY(hipMemcpyAsync(reward_sum, a->d_rsum.p, sizeof(double) * h->B, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return CMDP_OK;
+}
+
+int cmdp_qlearning_tables(cmdp_agent_t* a, float* Q, int32_t* N) {
+  if (!a) return fail(CMDP_ERR_INVALID, "null agent");
+  if (int rc = bind(a->env)) return rc;
+  hipStream_t st = a->env->stream;
+  if (Q) HIP_TRY(hipMemcpyAsync(Q, a->d_Q.p, sizeof(float) * a->n_q, hipMemcpyDeviceToHost, st));
+  if (N) HIP_TRY(hipMemcpyAsync(N, a->d_N.p, sizeof(int32_t) * a->n_q, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   return CMDP_OK;
 }
 

@@ -1,0 +1,152 @@
+// cmdp_agent.h -- batched tabular Q-learning with UCB exploration, fused with the interaction kernel
+// (SURVEY.md section 8 f1).  Restates the reference's episodic agent
+//   colosseum/agent/agents/episodic/q_learning.py:19-104   (QValuesModel.step_update, Jin et al. 2018)
+//   colosseum/agent/actors/Q_values_actor.py:67-88         (greedy action, uniform tie-break from RandomState(seed))
+// one lane per (environment instance, agent) pair.  The update mirrors numpy's scalar arithmetic OPERATION BY
+// OPERATION, including its dtype promotion (NEP 50, numpy >= 2): which sub-expressions are float32 and which
+// float64 depends on whether `alpha` is the Python float `min_at` or the numpy float64 (H+1)/(H+t) -- both
+// regimes are reproduced, so Q tables and action streams are bit-equal to the reference's (golden G7).
+#pragma once
+#include "cmdp_kernels.h"
+
+struct QlArgs {
+  int32_t H, ucb;                 // ucb: 0 hoeffding, 1 bernstein
+  double c1, c2, min_at, H3;      // H3 = H**3 (exact)
+  const double* i_log;            // [B] np.log(S * A * optimization_horizon / p)
+  const double* sqrtH7SA;         // [B] np.sqrt(H**7 * S * A)
+  const int64_t* q_off;           // [B] = H * state_off[b] * A
+  const int64_t* v_off;           // [B] = (H + 1) * state_off[b]
+  int32_t* N;                     // [sum H*S*A] starts at 1
+  float* Q;                       // starts at H
+  float* V;                       // [sum (H+1)*S] starts at 0
+  float* mu; float* sigma; float* beta;
+  uint32_t* mt;                   // [B][624] numpy RandomState(seed) of the actor
+  int32_t* mt_pos;
+};
+
+// numpy legacy RandomState(seed): init_genrand
+__global__ void k_mt_seed_numpy(uint32_t* __restrict__ mt, int32_t* __restrict__ pos, const uint32_t* __restrict__ seeds,
+                                int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t* m = mt + (int64_t)i * 624;
+  m[0] = seeds[i];
+  for (int k = 1; k < 624; ++k) m[k] = 1812433253u * (m[k - 1] ^ (m[k - 1] >> 30)) + (uint32_t)k;
+  pos[i] = 0;
+}
+
+__global__ void k_fill_f32(float* __restrict__ p, float v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void k_fill_i32(int32_t* __restrict__ p, int32_t v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+template <int UCB>
+__global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, int64_t n_steps, int train,
+                                                         int8_t* __restrict__ act_trace, double* __restrict__ reward_sum) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= t.B) return;
+  const int64_t soff = t.state_off[b], ebase = t.entry_base[b];
+  const int S = (int)(t.state_off[b + 1] - soff);
+  const int A = t.A, H = q.H;
+  const uint2 key = t.philox_key ? t.philox_key[b] : make_uint2(0, 0);
+  int32_t cur = t.cur[b], h = t.hstep[b];
+  unsigned long long nt = t.n_trans[b], nr = t.n_reset[b];
+  float* Q = q.Q + q.q_off[b];
+  int32_t* N = q.N + q.q_off[b];
+  float* MU = q.mu + q.q_off[b];
+  float* SG = q.sigma + q.q_off[b];
+  float* BT = q.beta + q.q_off[b];
+  float* V = q.V + q.v_off[b];
+  uint32_t* mt = q.mt + (int64_t)b * 624;
+  int32_t* mtp = q.mt_pos + b;
+  const double il = q.i_log[b], s7 = q.sqrtH7SA[b];
+  double sum = 0.0;
+  for (int64_t step = 0; step < n_steps; ++step) {
+    // ---- QValuesActor.select_action: greedy with uniform tie-break --------------------------------------
+    const float* qrow = Q + ((int64_t)h * S + cur) * A;
+    float qmax = qrow[0];
+    for (int a = 1; a < A; ++a) qmax = fmaxf(qmax, qrow[a]);
+    int n_tie = 0;
+    for (int a = 0; a < A; ++a) n_tie += (qrow[a] == qmax) ? 1 : 0;
+    int pick = 0;
+    if (n_tie > 1) {  // RandomState.choice(ties) == ties[randint(0, n)]: masked rejection on 32-bit draws
+      const uint32_t mx = (uint32_t)(n_tie - 1);
+      uint32_t mask = mx;
+      mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+      int pos = *mtp;
+      uint32_t v;
+      do { v = mt_next_word(mt, pos) & mask; } while (v > mx);
+      *mtp = pos;
+      pick = (int)v;
+    }
+    int action = 0;
+    for (int a = 0, k = 0; a < A; ++a)
+      if (qrow[a] == qmax) { if (k == pick) action = a; ++k; }
+    if (act_trace) act_trace[step * t.B + b] = (int8_t)action;
+    // ---- BaseMDP.step -------------------------------------------------------------------------------------------
+    const int32_t s_t = cur, time = h;
+    int32_t obs;
+    double reward;
+    const int ty = env_step(t, soff, ebase, key, cur, h, nt, action, obs, reward);
+    sum += reward;
+    // ---- QValuesModel.step_update ---------------------------------------------------------------------------------
+    if (train) {
+      // s_tp1 = -1 at termination indexes the LAST state of row time+1 == H, which is never written (0)
+      const float vnext = V[(int64_t)(time + 1) * S + (ty == 2 ? S - 1 : obs)];
+      const int64_t idx = ((int64_t)time * S + s_t) * A + action;
+      const int32_t tN = N[idx] + 1;
+      N[idx] = tN;
+      const double x = (double)(H + 1) / (double)(H + tN);
+      const bool alpha_py = !(x > q.min_at);  // max(min_at, x) returns the Python float unless x is larger
+      const double alpha = alpha_py ? q.min_at : x;
+      const float qold = Q[idx];
+      const float rv = __fadd_rn((float)reward, vnext);  // python float + np.float32 -> float32
+      float qnew;
+      if (UCB == 0) {
+        const double b_t = q.c1 * sqrt(q.H3 * il / (double)tN);  // np.float64
+        const double first = alpha_py ? (double)__fmul_rn((float)alpha, qold) : alpha * (double)qold;
+        qnew = (float)(first + (1.0 - alpha) * ((double)rv + b_t));
+      } else {
+        MU[idx] = __fadd_rn(MU[idx], vnext);
+        SG[idx] = __fadd_rn(SG[idx], __fmul_rn(vnext, vnext));
+        const float old_beta = BT[idx];
+        const float dm = __fsub_rn(SG[idx], MU[idx]);
+        const float hdm2 = __fmul_rn((float)H, __fmul_rn(dm, dm));
+        const int32_t t2 = (int32_t)((uint32_t)tN * (uint32_t)tN);  // np.int32 ** 2 wraps like numpy
+        const double inner = (double)hdm2 / (double)t2 + (double)H;  // float32 / int32 -> float64
+        const double a1 = sqrt(inner * il);
+        const double a2 = s7 * il / (double)tN;
+        const double cand1 = q.c1 * (a1 + a2);
+        const double cand2 = q.c2 * sqrt(q.H3 * il / (double)tN);
+        const float nb = (float)((cand2 < cand1) ? cand2 : cand1);
+        BT[idx] = nb;
+        if (alpha_py) {  // python-float alpha: everything stays float32
+          const float om = (float)(1.0 - alpha);
+          const float b_t = __fdiv_rn(__fdiv_rn(__fsub_rn(nb, __fmul_rn(om, old_beta)), 2.0f), (float)alpha);
+          qnew = __fadd_rn(__fmul_rn((float)alpha, qold), __fmul_rn(om, __fadd_rn(rv, b_t)));
+        } else {  // numpy-float64 alpha
+          const double b_t = (((double)nb - (1.0 - alpha) * (double)old_beta) / 2.0) / alpha;
+          qnew = (float)(alpha * (double)qold + (1.0 - alpha) * ((double)rv + b_t));
+        }
+      }
+      Q[idx] = qnew;
+      const float* qr = Q + ((int64_t)time * S + s_t) * A;
+      float m2 = qr[0];
+      for (int a = 1; a < A; ++a) m2 = fmaxf(m2, qr[a]);
+      V[(int64_t)time * S + s_t] = (m2 < (float)H) ? m2 : (float)H;  // min(H, Q[time, s_t].max())
+    }
+    if (ty == 2) {
+      cur = env_reset(t, b, soff, key, nr);
+      h = 0;
+    }
+  }
+  t.cur[b] = cur;
+  t.hstep[b] = h;
+  t.n_trans[b] = nt;
+  t.n_reset[b] = nr;
+  if (reward_sum) reward_sum[b] = sum;
+}

@@ -227,6 +227,22 @@ int cmdp_diameter_episodic(cmdp_t* h, int H, const int64_t* start_off, const int
 /* calculate_norm_discounted (colosseum/hardness/measures/value_norm.py:83-87). V [state_off[B]]. */
 int cmdp_value_norm(cmdp_t* h, const float* V, float* out);
 
+/* ---- agents on the device --------------------------------------------------------- */
+/* Batched tabular Q-learning with UCB exploration for episodic MDPs: one agent per environment instance of `env`,
+   reproducing colosseum/agent/agents/episodic/q_learning.py (QLearningEpisodic: QValuesModel.step_update + the
+   greedy QValuesActor with its RandomState(seed) tie-break) bit for bit.  seeds [B]; ucb_type 0 = hoeffding,
+   1 = bernstein (c_2 required). */
+typedef struct cmdp_agent cmdp_agent_t;
+int cmdp_qlearning_create(cmdp_agent_t** out, cmdp_t* env, const int32_t* seeds, int64_t optimization_horizon,
+                          double p, double c_1, double c_2, double min_at, int ucb_type);
+int cmdp_qlearning_destroy(cmdp_agent_t* a);
+/* MDPLoop.run's loop with the agent in it (colosseum/experiment/agent_mdp_interaction.py:238-298): per step
+   select_action -> BaseMDP.step -> step_update (skipped when train == 0, as after MDPLoop freezes training) ->
+   reset() at the end of an episode.  actions_trace [n_steps][B] and reward_sum [B] may be NULL. */
+int cmdp_qlearning_run(cmdp_agent_t* a, int64_t n_steps, int train, int8_t* actions_trace, double* reward_sum);
+/* Q [B instances concatenated: H*S_b*A floats each], N likewise (int32); either may be NULL. */
+int cmdp_qlearning_tables(cmdp_agent_t* a, float* Q, int32_t* N);
+
 /* ---- Markov chains ------------------------------------------------------------------------------------ */
 /* _gth_solve_numba (colosseum/mdp/utils/markov_chain.py:139-166): stationary distributions of `count` chains with a
    single recurrent class each, float64 GTH elimination on the current device.  Chain m is the dims[m] x dims[m]

@@ -497,9 +497,12 @@ def g7():
     hp = dict(p=0.05, UCB_type="bernstein", c_1=0.9415278732894797, c_2=0.013873778519317169,
               min_at=0.07263563483119442)
     cases = []
-    for mdp_kw, T, log_every in ((dict(seed=0, size=8), 20_000, 1_000), (dict(seed=3, size=5, p_rand=0.2), 6_000, 500)):
+    hp_h = dict(p=0.05, UCB_type="hoeffding", c_1=0.0031, min_at=0.0)
+    for mdp_kw, T, log_every, hpx in ((dict(seed=0, size=8), 20_000, 1_000, hp), (dict(seed=3, size=5, p_rand=0.2), 6_000, 500, hp),
+                                      (dict(seed=1, size=6, p_rand=0.1), 6_000, 500, hp_h)):
+        hp_used = hpx
         mdp = DeepSeaEpisodic(**mdp_kw)
-        agent = QLearningEpisodic(seed=mdp_kw["seed"], mdp_specs=make_mdp_spec(mdp), optimization_horizon=T, **hp)
+        agent = QLearningEpisodic(seed=mdp_kw["seed"], mdp_specs=make_mdp_spec(mdp), optimization_horizon=T, **hp_used)
         actions = []
         sel = agent.select_action
 
@@ -513,9 +516,12 @@ def g7():
         last_training_step, last_logs = loop.run(T=T, log_every=log_every)
         rows = [{k: float(v) for k, v in r.items() if k != "steps_per_second"} for r in loop.logger.data]
         cases.append(dict(mdp_cls="DeepSeaEpisodic", mdp_kwargs=mdp_kw, agent="QLearningEpisodic",
-                          agent_kwargs=dict(seed=mdp_kw["seed"], optimization_horizon=T, **hp), T=T, log_every=log_every,
+                          agent_kwargs=dict(seed=mdp_kw["seed"], optimization_horizon=T, **hp_used), T=T, log_every=log_every,
                           last_training_step=int(last_training_step), rows=rows, actions=actions,
-                          Q_final=np.asarray(agent._mdp_model.Q, np.float64).round(7).tolist()))
+                          Q_final=np.asarray(agent._mdp_model.Q, np.float64).tolist(),  # float32 values, exact in JSON
+                          N_final=np.asarray(agent._mdp_model.N).tolist(),
+                          # MDPLoop stops calling step_update once the policy is confidently optimal (:284-288)
+                          n_updates=int(np.asarray(agent._mdp_model.N).sum() - np.asarray(agent._mdp_model.N).size)))
         print("   ", mdp_kw, "rows", len(rows), "cumulative_regret", rows[-1]["cumulative_regret"])
     with open(os.path.join(OUT, "G7_mdploop_qlearning.json"), "w") as f:
         json.dump(cases, f)

@@ -1,0 +1,91 @@
+"""the batched on-device Q-learning agent against the reference.  Golden G7 holds the action stream and
+the final Q / N tables of the reference's QLearningEpisodic driven by the reference's MDPLoop; the device agent (fused
+select_action -> step -> step_update kernel) must reproduce them bit for bit, including the steps after MDPLoop froze
+training.  A second test runs a batch of different instances and seeds against the numpy restatement of the agent
+(tests/helpers_agents.py, itself pinned to G7) stepping the CPU oracle environment."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from colosseum_amd import _lib as L
+from colosseum_amd import timestep as ts_
+from colosseum_amd.agents import BatchedQLearningEpisodic
+from colosseum_amd.batched import BatchedMDP
+from colosseum_amd.mdp import make_model
+from helpers_agents import QLearningEpisodic
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+class _Spec:
+    def __init__(self, m):
+        self.time_horizon = m.H
+        self.observations = type("o", (), {"num_values": m.n_states})()
+        self.actions = type("a", (), {"num_values": m.n_actions})()
+
+
+def _host_run(m, kw, n_steps, rng_mode=0, key=0):
+    """helper agent + oracle env; returns (actions, Q, N)"""
+    e = O.OracleEnv(m, rng_mode=rng_mode, philox_key=key)
+    ag = QLearningEpisodic(mdp_specs=_Spec(m), **kw)
+    ts, h, acts = ts_.restart(e.reset()), 0, []
+    for _ in range(n_steps):
+        a = int(ag.select_action(ts, h))
+        acts.append(a)
+        ty, o, r, _ = e.step(a)
+        nts = ts_.termination(r, -1) if ty == 2 else ts_.transition(r, o)
+        ag.step_update(ts, a, nts, h)
+        h, ts = h + 1, nts
+        if ty == 2:
+            ts, h = ts_.restart(e.reset()), 0
+    return np.array(acts), ag.Q, ag.N
+
+
+def test_device_qlearning_reproduces_reference_run(need_gpu):
+    cases = json.load(open(os.path.join(GOLDEN, "G7_mdploop_qlearning.json")))
+    for c in cases:
+        m = make_model(c["mdp_cls"], **c["mdp_kwargs"])
+        env = BatchedMDP([m], rng_mode=L.RNG_MT_COMPAT, with_dp=False)
+        env.reset()
+        kw = dict(c["agent_kwargs"])
+        seed = kw.pop("seed")
+        ag = BatchedQLearningEpisodic(env, [seed], **kw)
+        n_train = c["n_updates"]
+        a1 = ag.run(n_train, train=True, trace_actions=True)["actions"][:, 0]
+        Q, N = ag.tables()
+        np.testing.assert_array_equal(N[0], np.asarray(c["N_final"], np.int32))
+        np.testing.assert_array_equal(Q[0].astype(np.float64), np.asarray(c["Q_final"]))  # bit-equal float32 tables
+        a2 = ag.run(c["T"] - n_train, train=False, trace_actions=True)["actions"][:, 0]
+        np.testing.assert_array_equal(np.concatenate([a1, a2]), np.asarray(c["actions"], np.int8), err_msg=str(c["mdp_kwargs"]))
+        ag.close()
+        env.close()
+
+
+def test_device_qlearning_batch_vs_numpy_agent(need_gpu):
+    specs = [("DeepSeaEpisodic", dict(seed=s, size=sz, p_rand=pr)) for s, sz, pr in ((0, 5, None), (1, 7, 0.3), (2, 7, 0.05))]
+    specs += [("FrozenLakeEpisodic", dict(seed=4, size=4, p_frozen=0.9, p_rand=0.1, H=12))]
+    for ucb, hp in (("bernstein", dict(p=0.05, c_1=0.9415278732894797, c_2=0.013873778519317169, min_at=0.07263563483119442)),
+                    ("hoeffding", dict(p=0.1, c_1=0.01, min_at=0.0)),
+                    ("bernstein", dict(p=0.05, c_1=0.2, c_2=0.5, min_at=0.3))):
+        for cls, kw in specs:
+            base = make_model(cls, **kw)
+            ms = [base, base, base]
+            seeds = [11, 12, 13]
+            keys = np.array([101, 102, 103], np.uint64)
+            env = BatchedMDP(ms, rng_mode=L.RNG_PHILOX, philox_keys=keys, with_dp=False)
+            env.reset()
+            ag = BatchedQLearningEpisodic(env, seeds, optimization_horizon=3000, UCB_type=ucb, **hp)
+            out = ag.run(3000, train=True, trace_actions=True)
+            Q, N = ag.tables()
+            for i in range(3):
+                acts, hQ, hN = _host_run(base, dict(seed=seeds[i], optimization_horizon=3000, UCB_type=ucb, **hp), 3000,
+                                         rng_mode=1, key=int(keys[i]))
+                np.testing.assert_array_equal(out["actions"][:, i], acts, err_msg=f"{cls} {kw} {ucb} inst {i}")
+                np.testing.assert_array_equal(N[i], hN)
+                np.testing.assert_array_equal(Q[i], hQ)
+            ag.close()
+            env.close()
