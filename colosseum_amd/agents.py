@@ -24,12 +24,23 @@ class BatchedQLearningEpisodic:
         L.check(self._lib.cmdp_qlearning_create(C.byref(self._h), env._h, L.ptr(seeds), int(optimization_horizon), float(p),
                                                 float(c_1), float(c_2 or 0.0), float(min_at), ucb))
 
-    def run(self, n_steps: int, train: bool = True, trace_actions: bool = False):
+    def run(self, n_steps: int, train=True, trace_actions: bool = False):
+        """n_steps of select_action -> step -> step_update per instance.  `train`: bool or per-instance mask.
+        Returns the running cumulative reward (since creation) and, optionally, the actions [n_steps, B]."""
         n_steps = int(n_steps)
         acts = np.zeros((n_steps, self.env.B), np.int8) if trace_actions else None
         rsum = np.zeros(self.env.B, np.float64)
-        L.check(self._lib.cmdp_qlearning_run(self._h, n_steps, int(train), L.ptr(acts), L.ptr(rsum)))
-        return dict(reward_sum=rsum, actions=acts)
+        mask = None
+        if train is not True:
+            mask = np.ascontiguousarray(np.broadcast_to(np.asarray(train, bool), (self.env.B,)), np.uint8)
+        L.check(self._lib.cmdp_qlearning_run(self._h, n_steps, L.ptr(mask), L.ptr(acts), L.ptr(rsum)))
+        return dict(cumulative_reward=rsum, actions=acts)
+
+    def evaluate(self) -> np.ndarray:
+        """V[0, :] (concatenated over instances) of the current greedy policies, policy and evaluation on device."""
+        V0 = np.zeros(int(self.env.state_off[-1]), np.float32)
+        L.check(self._lib.cmdp_qlearning_evaluate(self._h, L.ptr(V0)))
+        return V0
 
     def tables(self):
         """(Q, N): per instance arrays of shape [H, S_b, A]."""

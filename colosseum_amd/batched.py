@@ -243,6 +243,15 @@ class BatchedMDP:
         L.check(self._lib.cmdp_pe_episodic(self._h, H, L.ptr(p), L.ptr(Rov), L.ptr(Q), L.ptr(V)))
         return Q, V
 
+    def greedy_policy_episodic(self, Q, q_layers: int, H=None):
+        """argmax_3d with the reference's RandomState(42) tie-break on the device: Q per instance [q_layers, S, A]
+        (flat concatenation or list) -> one-hot policies, flat [B: H*S*A]."""
+        H = self.H if H is None else int(H)
+        q = self._flat_rows(Q, lead=q_layers)
+        pi = np.zeros(H * int(self.row_off[-1]), np.float32)
+        L.check(self._lib.cmdp_greedy_policy_episodic(self._h, H, int(q_layers), L.ptr(q), L.ptr(pi)))
+        return pi
+
     def diameter(self, epsilon=1e-3, scheme=L.SCHEME_AUTO, max_sweeps=1_000_000):
         per = np.zeros(int(self.state_off[-1]), np.float32)
         diam = np.zeros(self.B, np.float32)

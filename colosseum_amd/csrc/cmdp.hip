@@ -989,7 +989,10 @@ struct cmdp_agent {
   DevBuf<float> d_Q, d_V, d_mu, d_sigma, d_beta;
   DevBuf<uint32_t> d_mt;
   DevBuf<int8_t> d_act;
-  DevBuf<double> d_rsum;
+  DevBuf<double> d_rsum;   // MDPLoop._cumulative_reward per instance
+  DevBuf<uint8_t> d_mask;
+  DevBuf<float> d_pi;      // greedy policy [H][S][A]
+  DevBuf<uint32_t> d_mt42; // scratch streams of the tie-break
   int64_t n_q = 0, n_v = 0;
 };
 
@@ -1037,6 +1040,8 @@ int cmdp_qlearning_create(cmdp_agent_t** out, cmdp_t* env, const int32_t* seeds,
   hipLaunchKernelGGL(k_fill_f32, dim3(grid_for(a->n_q, 256)), dim3(256), 0, st, a->d_Q.p, (float)H, a->n_q);
   HIP_TRY(a->d_mt.alloc((size_t)B * 624));
   HIP_TRY(a->d_mtpos.alloc(B));
+  HIP_TRY(a->d_rsum.alloc(B));
+  HIP_TRY(a->d_rsum.zero(st));
   std::vector<uint32_t> useeds((size_t)B);
   for (int b = 0; b < B; ++b) useeds[b] = (uint32_t)seeds[b];
   DevBuf<uint32_t> d_seeds;
@@ -1061,7 +1066,8 @@ int cmdp_qlearning_destroy(cmdp_agent_t* a) {
   return CMDP_OK;
 }
 
-int cmdp_qlearning_run(cmdp_agent_t* a, int64_t n_steps, int train, int8_t* actions_trace, double* reward_sum) {
+int cmdp_qlearning_run(cmdp_agent_t* a, int64_t n_steps, const uint8_t* train_mask, int8_t* actions_trace,
+                       double* reward_sum) {
   if (!a) return fail(CMDP_ERR_INVALID, "null agent");
   cmdp_t* h = a->env;
   if (int rc = bind(h)) return rc;
@@ -1072,17 +1078,70 @@ int cmdp_qlearning_run(cmdp_agent_t* a, int64_t n_steps, int train, int8_t* acti
   hipStream_t st = h->stream;
   const size_t NB = (size_t)n_steps * h->B;
   if (actions_trace && a->d_act.n < NB) HIP_TRY(a->d_act.alloc(NB));
-  if (a->d_rsum.n < (size_t)h->B) HIP_TRY(a->d_rsum.alloc(h->B));
+  const uint8_t* dmask = nullptr;
+  if (train_mask) {
+    HIP_TRY(a->d_mask.upload(train_mask, h->B, st));
+    dmask = a->d_mask.p;
+  }
   const dim3 grid(grid_for(h->B, 256)), block(256);
   if (a->args.ucb == 0)
-    hipLaunchKernelGGL((k_qlearn_episodic<0>), grid, block, 0, st, h->env(), a->args, n_steps, train,
+    hipLaunchKernelGGL((k_qlearn_episodic<0>), grid, block, 0, st, h->env(), a->args, n_steps, dmask,
                        actions_trace ? a->d_act.p : nullptr, a->d_rsum.p);
   else
-    hipLaunchKernelGGL((k_qlearn_episodic<1>), grid, block, 0, st, h->env(), a->args, n_steps, train,
+    hipLaunchKernelGGL((k_qlearn_episodic<1>), grid, block, 0, st, h->env(), a->args, n_steps, dmask,
                        actions_trace ? a->d_act.p : nullptr, a->d_rsum.p);
   HIP_TRY(hipGetLastError());
   if (actions_trace) HIP_TRY(hipMemcpyAsync(actions_trace, a->d_act.p, NB, hipMemcpyDeviceToHost, st));
   if (reward_sum) HIP_TRY(hipMemcpyAsync(reward_sum, a->d_rsum.p, sizeof(double) * h->B, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return CMDP_OK;
+}
+
+int cmdp_qlearning_evaluate(cmdp_agent_t* a, float* V0) {
+  if (!a || !V0) return fail(CMDP_ERR_INVALID, "null argument");
+  cmdp_t* h = a->env;
+  if (int rc = bind(h)) return rc;
+  if (!h->has_dp) return fail(CMDP_ERR_INVALID, "the environment handle was created without the DP half");
+  hipStream_t st = h->stream;
+  const int H = h->H;
+  const size_t lds = 2 * sizeof(float) * (size_t)h->max_S;
+  if (lds > (size_t)kLdsBudget) return fail(CMDP_ERR_UNSUPPORTED, "instance with %d states does not fit LDS", h->max_S);
+  if (a->d_pi.n < (size_t)a->n_q) HIP_TRY(a->d_pi.alloc(a->n_q));
+  if (a->d_mt42.n < (size_t)h->B * 624) HIP_TRY(a->d_mt42.alloc((size_t)h->B * 624));
+  hipLaunchKernelGGL(k_greedy_policy_episodic, dim3(grid_for(h->B, 64)), dim3(64), 0, st, h->B, h->A, H, H,
+                     h->d_state_off.p, a->d_Q.p, a->d_pi.p, a->d_mt42.p);
+  const size_t nq = (size_t)(H + 1) * h->n_rows, nv = (size_t)(H + 1) * h->n_states;
+  if (h->d_Q.n < nq) HIP_TRY(h->d_Q.alloc(nq));
+  if (h->d_V.n < nv) HIP_TRY(h->d_V.alloc(nv));
+  DpTables t{};
+  t.B = h->B; t.A = h->A; t.state_off = h->d_state_off.p; t.csr_ptr = h->d_csr_ptr.p; t.csr_col = h->d_csr_col.p;
+  t.csr_val = h->d_csr_val.p; t.R = h->d_R.p; t.pi = a->d_pi.p;
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_episodic<DP_PE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_episodic<DP_PE>), dim3(h->B), dim3(kDpBlock), lds, st, t, H, h->d_Q.p, h->d_V.p);
+  HIP_TRY(hipGetLastError());
+  // V[0, :] of instance b sits at (H+1)*state_off[b]
+  for (int b = 0; b < h->B; ++b) {
+    const int64_t so = h->state_off[b], S = h->state_off[b + 1] - so;
+    HIP_TRY(hipMemcpyAsync(V0 + so, h->d_V.p + (size_t)(H + 1) * so, sizeof(float) * S, hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  return CMDP_OK;
+}
+
+int cmdp_greedy_policy_episodic(cmdp_t* h, int H, int q_layers, const float* Q, float* pi) {
+  if (int rc = bind(h)) return rc;
+  if (!Q || !pi || H < 1 || q_layers < H) return fail(CMDP_ERR_INVALID, "bad argument");
+  hipStream_t st = h->stream;
+  DevBuf<float> d_q, d_p;
+  DevBuf<uint32_t> d_mt;
+  HIP_TRY(d_q.upload(Q, (size_t)q_layers * h->n_rows, st));
+  HIP_TRY(d_p.alloc((size_t)H * h->n_rows));
+  HIP_TRY(d_mt.alloc((size_t)h->B * 624));
+  hipLaunchKernelGGL(k_greedy_policy_episodic, dim3(grid_for(h->B, 64)), dim3(64), 0, st, h->B, h->A, H, q_layers,
+                     h->d_state_off.p, d_q.p, d_p.p, d_mt.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(pi, d_p.p, sizeof(float) * (size_t)H * h->n_rows, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   return CMDP_OK;
 }

@@ -45,8 +45,9 @@ __global__ void k_fill_i32(int32_t* __restrict__ p, int32_t v, int64_t n) {
 }
 
 template <int UCB>
-__global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, int64_t n_steps, int train,
-                                                         int8_t* __restrict__ act_trace, double* __restrict__ reward_sum) {
+__global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, int64_t n_steps,
+                                                         const uint8_t* __restrict__ train_mask,
+                                                         int8_t* __restrict__ act_trace, double* __restrict__ cum_reward) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= t.B) return;
   const int64_t soff = t.state_off[b], ebase = t.entry_base[b];
@@ -64,7 +65,9 @@ __global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, 
   uint32_t* mt = q.mt + (int64_t)b * 624;
   int32_t* mtp = q.mt_pos + b;
   const double il = q.i_log[b], s7 = q.sqrtH7SA[b];
-  double sum = 0.0;
+  const bool train = train_mask ? train_mask[b] != 0 : true;
+  // `self._cumulative_reward += new_ts.reward` (agent_mdp_interaction.py:291) continues across launches
+  double sum = cum_reward[b];
   for (int64_t step = 0; step < n_steps; ++step) {
     // ---- QValuesActor.select_action: greedy with uniform tie-break --------------------------------------
     const float* qrow = Q + ((int64_t)h * S + cur) * A;
@@ -148,5 +151,46 @@ __global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, 
   t.hstep[b] = h;
   t.n_trans[b] = nt;
   t.n_reset[b] = nr;
-  if (reward_sum) reward_sum[b] = sum;
+  cum_reward[b] = sum;
+}
+
+
+// argmax_3d (reference colosseum/dynamic_programming/utils.py:28-39): one-hot greedy policy of Q[layers >= H][S][A]
+// with ties broken by `np.random.seed(42); np.random.choice(ties)` -- one numpy MT19937(42) stream per table, rows in
+// (h, s) order, a draw only where there is a tie.  One lane per instance; `mt` is scratch [B][624].
+__global__ void __launch_bounds__(64) k_greedy_policy_episodic(int B, int A, int H, int q_layers,
+                                                              const int64_t* __restrict__ state_off,
+                                                              const float* __restrict__ Q, float* __restrict__ pi,
+                                                              uint32_t* __restrict__ mt_all) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int64_t soff = state_off[b];
+  const int S = (int)(state_off[b + 1] - soff);
+  const float* q = Q + (int64_t)q_layers * soff * A;
+  float* p = pi + (int64_t)H * soff * A;
+  uint32_t* mt = mt_all + (int64_t)b * 624;
+  mt[0] = 42u;
+  for (int k = 1; k < 624; ++k) mt[k] = 1812433253u * (mt[k - 1] ^ (mt[k - 1] >> 30)) + (uint32_t)k;
+  int pos = 0;
+  for (int64_t r = 0; r < (int64_t)H * S; ++r) {
+    const float* row = q + r * A;
+    float m = row[0];
+    for (int a = 1; a < A; ++a) m = fmaxf(m, row[a]);
+    int n_tie = 0;
+    for (int a = 0; a < A; ++a) n_tie += (row[a] == m) ? 1 : 0;
+    int pick = 0;
+    if (n_tie > 1) {
+      const uint32_t mx = (uint32_t)(n_tie - 1);
+      uint32_t mask = mx;
+      mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+      uint32_t v;
+      do { v = mt_next_word(mt, pos) & mask; } while (v > mx);
+      pick = (int)v;
+    }
+    for (int a = 0, k = 0; a < A; ++a) {
+      const bool tie = row[a] == m;
+      p[r * A + a] = (tie && k == pick) ? 1.0f : 0.0f;
+      k += tie ? 1 : 0;
+    }
+  }
 }

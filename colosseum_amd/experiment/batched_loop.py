@@ -1,0 +1,129 @@
+"""BatchedEpisodicLoop: `MDPLoop.run` for B (environment, agent) pairs at once, agents on the device.
+
+The reference runs one `MDPLoop` per OS process (colosseum/experiment/experiment_instances.py:160-166,178-223).  Here
+the interaction (select_action -> step -> step_update, reset at episode ends) is the fused kernel of
+colosseum_amd.agents; at every logging step the greedy policies of all agents are extracted and evaluated on the device
+in one call, and the 18 indicators of every instance are then produced by the very indicator code of
+`colosseum_amd.experiment.MDPLoop` (one light tracker object per instance), so rows are identical to a per-instance run:
+same step at which the reward sum is read (the reference logs BEFORE adding the current step's reward), same
+`_is_policy_optimal` freeze of training, same float32/float64 scalar arithmetic."""
+from typing import Dict, List
+
+import numpy as np
+
+from ..agents import BatchedQLearningEpisodic
+from ..batched import BatchedMDP
+from .mdp_loop import InMemoryLogger, MDPLoop
+
+
+class _InstanceView:
+    """What MDPLoop's indicator code reads from `mdp`, for one instance of the batch (states are plain indices)."""
+
+    def __init__(self, H, start_states, start_probs, v_opt0, v_worst0, v_rand0):
+        self.H = H
+        self.starting_nodes = [int(s) for s in start_states]
+        self.node_to_index = {s: s for s in self.starting_nodes}
+        self.last_starting_node = self.starting_nodes[0]
+        self._probs = [float(p) for p in start_probs]
+        self._v = dict(opt=v_opt0, worst=v_worst0, rand=v_rand0)
+        self.parameters = {}
+
+        def avg(v):
+            acc = 0.0
+            for sn, p in zip(self.starting_nodes, self._probs):
+                acc += p * v[sn]
+            return acc / H
+
+        self.episodic_optimal_average_reward = avg(v_opt0)
+        self.episodic_worst_average_reward = avg(v_worst0)
+        self.episodic_random_average_reward = avg(v_rand0)
+
+    @staticmethod
+    def is_episodic():
+        return True
+
+    def get_minimal_regret_for_starting_node(self, n):
+        return self._v["opt"][n] - self._v["worst"][n]
+
+
+class _Tracker(MDPLoop):
+    def __init__(self, view: _InstanceView, ssd: np.ndarray, n_check: int):
+        self.logger = InMemoryLogger()
+        self._mdp = view
+        self._agent = None
+        self._episodic = True
+        self._n_steps_to_check_for_agent_optimality = n_check
+        self._ssd = ssd
+        self._eval = None
+        self._max_time = np.inf
+
+    def set_evaluation(self, v0: np.ndarray):
+        """indicators.py:29-45 on the device-evaluated V[0]"""
+        epi = sum(v0 * self._ssd)
+        self._eval = (np.maximum(self._mdp._v["opt"] - v0, 0.0), epi)
+
+    def _episodic_regrets_and_average_reward(self):
+        return self._eval
+
+
+class BatchedEpisodicLoop:
+    def __init__(self, env: BatchedMDP, agent: BatchedQLearningEpisodic,
+                 n_log_intervals_to_check_for_agent_optimality: int = 10):
+        assert env.H > 0 and env.models is not None
+        self.env, self.agent = env, agent
+        H, A = env.H, env.A
+        # baselines of every instance, batched: optimal values, worst policy values, uniform policy values
+        Q, V = env.episodic_value_iteration()
+        Qw, _ = env.episodic_value_iteration(R=[-m.reward_matrix() for m in env.models])
+        pi_w = env.greedy_policy_episodic(Qw, q_layers=H + 1)
+        _, Vw = env.episodic_policy_evaluation(pi_w)
+        _, Vr = env.episodic_policy_evaluation([np.ones((H, m.n_states, A), np.float32) / A for m in env.models])
+        self.trackers: List[_Tracker] = []
+        for b, m in enumerate(env.models):
+            S = m.n_states
+            v0 = [env.split_states(x, H + 1)[b][:S] for x in (V, Vw, Vr)]
+            view = _InstanceView(H, m.start_states, m.start_probs, *v0)
+            ssd = np.zeros(S)
+            ssd[m.start_states] = m.start_probs
+            self.trackers.append(_Tracker(view, ssd, n_log_intervals_to_check_for_agent_optimality))
+
+    def _log(self, t: int, cum: np.ndarray, n_since: int, T: int, in_loop: bool):
+        V0 = self.agent.evaluate()
+        for b, tr in enumerate(self.trackers):
+            tr.set_evaluation(self.env.split_states(V0)[b])
+            tr._cumulative_reward = float(cum[b])
+            tr._n_steps_since_last_log = n_since
+            tr._update_performance_logs(t)
+            if in_loop:  # agent_mdp_interaction.py:265-288
+                tr._latest_expected_regrets.append(tr._normalized_regret)
+                if len(tr._latest_expected_regrets) > tr._n_steps_to_check_for_agent_optimality:
+                    tr._latest_expected_regrets.pop(0)
+                if tr._is_training and t > 0.2 * T and tr._is_policy_optimal():
+                    tr._is_training = False
+
+    def run(self, T: int, log_every: int = -1) -> List[List[Dict[str, float]]]:
+        env, agent = self.env, self.agent
+        for tr in self.trackers:
+            tr._reset_run_variables()
+        env.reset_visits()
+        env.reset()
+        done, n_since = 0, 0
+        mask = np.ones(env.B, bool)
+        cum = np.zeros(env.B)
+        log_ts = [t for t in range(log_every, T, log_every)] if log_every and log_every > 0 else []
+        for tl in log_ts:
+            # the reference reads `_cumulative_reward` at step tl BEFORE adding that step's reward: stop after step
+            # tl-1 to read the sum, then execute step tl (whose update the logged policy already contains)
+            if tl - done > 0:
+                cum = agent.run(tl - done, train=mask)["cumulative_reward"]
+                n_since += tl - done
+            agent.run(1, train=mask)
+            done = tl + 1
+            self._log(tl, cum, n_since, T, in_loop=True)
+            mask = np.array([tr._is_training for tr in self.trackers])
+            n_since = 1
+        if T - done > 0:
+            n_since += T - done
+        cum = agent.run(T - done, train=mask)["cumulative_reward"]
+        self._log(T - 1, cum, n_since, T, in_loop=False)
+        return [tr.logger.data for tr in self.trackers]

@@ -249,13 +249,17 @@ class MDPLoop:
         return r, nr
 
     # -- agent_mdp_interaction.py:534-578 ---------------------------------------------------------------------------------
+    def _episodic_regrets_and_average_reward(self):
+        """(regret at in-episode time zero for every state, average value at time zero) of the agent's current greedy
+        policy; overridden by the batched loop, which evaluates all instances in one device call."""
+        m = self._mdp
+        return get_episodic_regrets_and_average_reward_at_time_zero(
+            m.H, m.T, m.R, self._agent.current_optimal_stochastic_policy, m.starting_state_distribution,
+            m.optimal_value_functions[1])
+
     def _compute_episodic_regret(self):
         m = self._mdp
-
-        def evaluate():
-            return get_episodic_regrets_and_average_reward_at_time_zero(
-                m.H, m.T, m.R, self._agent.current_optimal_stochastic_policy, m.starting_state_distribution,
-                m.optimal_value_functions[1])
+        evaluate = self._episodic_regrets_and_average_reward
 
         if not self._is_training:
             if self._cached_episodic_regrets is None:

@@ -237,9 +237,19 @@ int cmdp_qlearning_create(cmdp_agent_t** out, cmdp_t* env, const int32_t* seeds,
                           double p, double c_1, double c_2, double min_at, int ucb_type);
 int cmdp_qlearning_destroy(cmdp_agent_t* a);
 /* MDPLoop.run's loop with the agent in it (colosseum/experiment/agent_mdp_interaction.py:238-298): per step
-   select_action -> BaseMDP.step -> step_update (skipped when train == 0, as after MDPLoop freezes training) ->
-   reset() at the end of an episode.  actions_trace [n_steps][B] and reward_sum [B] may be NULL. */
-int cmdp_qlearning_run(cmdp_agent_t* a, int64_t n_steps, int train, int8_t* actions_trace, double* reward_sum);
+   select_action -> BaseMDP.step -> step_update -> reset() at the end of an episode.  train_mask [B] (NULL = all
+   ones): instances with 0 act but do not update, as after MDPLoop froze their training (:284-288).
+   cumulative_reward [B] receives `MDPLoop._cumulative_reward`, the running float64 sum of ALL rewards since the agent
+   was created (the additions continue across calls in transition order).  actions_trace [n_steps][B] may be NULL. */
+int cmdp_qlearning_run(cmdp_agent_t* a, int64_t n_steps, const uint8_t* train_mask, int8_t* actions_trace,
+                       double* cumulative_reward);
+/* V[0, :] of episodic_policy_evaluation for the agents' current greedy policies
+   (BaseAgent.current_optimal_stochastic_policy = argmax_3d(Q), ties by RandomState(42)): what
+   MDPLoop._compute_episodic_regret needs.  The environment handle must carry the DP half.  V0 [state_off[B]]. */
+int cmdp_qlearning_evaluate(cmdp_agent_t* a, float* V0);
+/* argmax_3d (colosseum/dynamic_programming/utils.py:28-39) of host tables Q [per instance q_layers*S_b*A, q_layers
+   >= H]: one-hot float32 policy of the first H layers, pi [per instance H*S_b*A]. */
+int cmdp_greedy_policy_episodic(cmdp_t* h, int H, int q_layers, const float* Q, float* pi);
 /* Q [B instances concatenated: H*S_b*A floats each], N likewise (int32); either may be NULL. */
 int cmdp_qlearning_tables(cmdp_agent_t* a, float* Q, int32_t* N);
 

@@ -89,3 +89,27 @@ def test_device_qlearning_batch_vs_numpy_agent(need_gpu):
                 np.testing.assert_array_equal(Q[i], hQ)
             ag.close()
             env.close()
+
+
+def test_batched_episodic_loop_matches_reference_logger_rows(need_gpu):
+    """The whole MDPLoop.run on the device for a batch: golden G7 rows (17 deterministic indicators per logging step)
+    for each reference run, here executed with the instance replicated three times in one batch."""
+    from colosseum_amd.experiment.batched_loop import BatchedEpisodicLoop
+
+    cases = json.load(open(os.path.join(GOLDEN, "G7_mdploop_qlearning.json")))
+    for c in cases:
+        m = make_model(c["mdp_cls"], **c["mdp_kwargs"])
+        env = BatchedMDP([m, m, m], rng_mode=L.RNG_MT_COMPAT)
+        kw = dict(c["agent_kwargs"])
+        seed = kw.pop("seed")
+        ag = BatchedQLearningEpisodic(env, [seed, seed, seed], **kw)
+        rows = BatchedEpisodicLoop(env, ag).run(T=c["T"], log_every=c["log_every"])
+        for inst in rows:
+            assert len(inst) == len(c["rows"])
+            for got, ref in zip(inst, c["rows"]):
+                for k, v in ref.items():
+                    assert float(got[k]) == pytest.approx(v, rel=2e-6, abs=2e-5), (c["mdp_kwargs"], k, got["steps"])
+        Q, N = ag.tables()
+        np.testing.assert_array_equal(Q[2].astype(np.float64), np.asarray(c["Q_final"]))
+        ag.close()
+        env.close()
