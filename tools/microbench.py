@@ -51,4 +51,17 @@ acts = np.random.RandomState(0).randint(0, 2, B).astype(np.int32)
 dt = timed(lambda: env.step(acts, auto_reset=True), n=50)
 out["step_api_deepsea30"] = dict(instances=B, ms_per_call=dt * 1e3, steps_per_s=B / dt)
 env.close()
+# f1: on-device Q-learning agents (Bernstein UCB) fused with the environment step, DeepSea-30
+from colosseum_amd.agents import BatchedQLearningEpisodic  # noqa: E402
+
+for B in (4096, 32768):
+    env = BatchedMDP(tables=deepsea_episodic_tables(np.arange(B), 30), rng_mode=L.RNG_PHILOX)
+    env.reset()
+    ag = BatchedQLearningEpisodic(env, np.arange(B), optimization_horizon=500_000, p=0.05, c_1=0.9415278732894797,
+                                  c_2=0.013873778519317169, min_at=0.07263563483119442, UCB_type="bernstein")
+    n = 2000
+    dt = timed(lambda: ag.run(n), n=3)
+    out[f"qlearning_deepsea30_B{B}"] = dict(instances=B, agent_steps_per_s=B * n / dt)
+    ag.close()
+    env.close()
 print(json.dumps(out, indent=1))
