@@ -26,7 +26,8 @@ EXPORTS = [
     "cmdp_stream", "cmdp_reset", "cmdp_step", "cmdp_rollout", "cmdp_rollout_async", "cmdp_synchronize", "cmdp_set_option",
     "cmdp_visits", "cmdp_reset_visits", "cmdp_state", "cmdp_vi_discounted", "cmdp_pe_discounted",
     "cmdp_vi_episodic", "cmdp_pe_episodic", "cmdp_diameter", "cmdp_diameter_episodic", "cmdp_value_norm", "cmdp_gth", "cmdp_qlearning_create", "cmdp_qlearning_destroy", "cmdp_qlearning_run",
-    "cmdp_qlearning_tables", "cmdp_qlearning_evaluate", "cmdp_greedy_policy_episodic",
+    "cmdp_qlearning_tables", "cmdp_qlearning_evaluate", "cmdp_greedy_policy_episodic", "cmdp_qlearning_continuous_create",
+    "cmdp_qlearning_policy",
 ]
 
 
@@ -95,6 +96,8 @@ def load():
         L.cmdp_qlearning_destroy.argtypes = [vp]
         L.cmdp_qlearning_run.argtypes = [vp, i64, vp, vp, vp]
         L.cmdp_qlearning_evaluate.argtypes = [vp, vp]
+        L.cmdp_qlearning_continuous_create.argtypes = [C.POINTER(vp), vp, vp, i64, f64, f64, f64, f64]
+        L.cmdp_qlearning_policy.argtypes = [vp, vp]
         L.cmdp_greedy_policy_episodic.argtypes = [vp, i32, i32, vp, vp]
         L.cmdp_qlearning_tables.argtypes = [vp, vp, vp]
         _lib = L

@@ -63,3 +63,35 @@ class BatchedQLearningEpisodic:
             self.close()
         except Exception:
             pass
+
+
+class BatchedQLearningContinuous(BatchedQLearningEpisodic):
+    """One reference `QLearningContinuous` (colosseum/agent/agents/infinite_horizon/q_learning.py) per instance."""
+
+    def __init__(self, env: BatchedMDP, seeds: Sequence[int], optimization_horizon: int, min_at: float = 0.0,
+                 confidence: float = 0.95, span_approx_weight: float = 1.0, h_weight: float = 1.0):
+        self._lib = L.load()
+        self.env = env
+        seeds = np.ascontiguousarray(seeds, np.int32)
+        assert len(seeds) == env.B
+        self._h = C.c_void_p()
+        L.check(self._lib.cmdp_qlearning_continuous_create(C.byref(self._h), env._h, L.ptr(seeds), int(optimization_horizon),
+                                                           float(min_at), float(confidence), float(span_approx_weight),
+                                                           float(h_weight)))
+
+    def tables(self):
+        env = self.env
+        Q = np.zeros(int(env.row_off[-1]), np.float64)  # float64 tables (NEP 50: float32 zeros + numpy float64 H)
+        N = np.zeros(int(env.row_off[-1]), np.int32)
+        L.check(self._lib.cmdp_qlearning_tables(self._h, L.ptr(Q), L.ptr(N)))
+        return ([x.reshape(-1, env.A) for x in env.split_rows(Q)], [x.reshape(-1, env.A) for x in env.split_rows(N)])
+
+    def evaluate(self):
+        raise NotImplementedError("use policy(): continuous regrets come from the stationary distribution")
+
+    def policy(self):
+        """argmax_2d greedy policies (RandomState(42) tie-break), per instance [S, A]."""
+        env = self.env
+        pi = np.zeros(int(env.row_off[-1]), np.float32)
+        L.check(self._lib.cmdp_qlearning_policy(self._h, L.ptr(pi)))
+        return [x.reshape(-1, env.A) for x in env.split_rows(pi)]

@@ -982,7 +982,10 @@ int cmdp_diameter_episodic(cmdp_t* h, int H, const int64_t* start_off, const int
 
 struct cmdp_agent {
   cmdp_t* env = nullptr;
+  bool continuous = false;
   QlArgs args{};
+  QlcArgs cargs{};
+  DevBuf<double> d_Hh, d_gamma, d_Qc, d_Qmainc, d_Vc;  // continuous agent: float64 tables
   DevBuf<double> d_ilog, d_s7;
   DevBuf<int64_t> d_qoff, d_voff;
   DevBuf<int32_t> d_N, d_mtpos;
@@ -1059,6 +1062,90 @@ int cmdp_qlearning_create(cmdp_agent_t** out, cmdp_t* env, const int32_t* seeds,
   return CMDP_OK;
 }
 
+int cmdp_qlearning_continuous_create(cmdp_agent_t** out, cmdp_t* env, const int32_t* seeds, int64_t optimization_horizon,
+                                     double min_at, double confidence, double span_approx_weight, double h_weight) {
+  if (!out || !env || !seeds) return fail(CMDP_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (int rc = bind(env)) return rc;
+  if (!env->has_env || env->H != 0) return fail(CMDP_ERR_INVALID, "the continuous Q-learning agent needs a continuous environment handle");
+  if (env->layout != CMDP_LAYOUT_CSR) return fail(CMDP_ERR_UNSUPPORTED, "agents run on the CSR layout");
+  if (!(min_at >= 0 && min_at < 0.99) || !(confidence > 0 && confidence < 1) || !(span_approx_weight > 0) || !(h_weight > 0) ||
+      optimization_horizon < 1)
+    return fail(CMDP_ERR_INVALID, "hyper-parameters out of range");
+  const int B = env->B, A = env->A;
+  cmdp_agent_t* a = new cmdp_agent;
+  struct Guard { cmdp_agent_t* a; ~Guard() { delete a; } } guard{a};
+  a->env = env;
+  a->continuous = true;
+  hipStream_t st = env->stream;
+  const double T = (double)optimization_horizon;
+  std::vector<double> Hh((size_t)B), gm((size_t)B);
+  std::vector<int64_t> qoff((size_t)B);
+  for (int b = 0; b < B; ++b) {
+    const double S = (double)(env->state_off[b + 1] - env->state_off[b]);
+    // get_H (q_learning.py:19-44): min(sqrt(span * T / S / A), (T / S / A / log(4 T / confidence)) ** 0.333)
+    const double h1 = std::sqrt(span_approx_weight * T / S / A);
+    const double h2 = std::pow(T / S / A / std::log(4 * T / confidence), 0.333);
+    Hh[b] = h_weight * std::min(h1, h2);
+    gm[b] = 1 - 1 / Hh[b];
+    qoff[b] = env->state_off[b] * A;
+  }
+  a->n_q = env->n_rows;
+  a->n_v = env->n_states;
+  HIP_TRY(a->d_Hh.upload(Hh.data(), B, st));
+  HIP_TRY(a->d_gamma.upload(gm.data(), B, st));
+  HIP_TRY(a->d_qoff.upload(qoff.data(), B, st));
+  HIP_TRY(a->d_N.alloc(a->n_q)); HIP_TRY(a->d_N.zero(st));
+  HIP_TRY(a->d_Qc.alloc(a->n_q));
+  HIP_TRY(a->d_Qmainc.alloc(a->n_q));
+  HIP_TRY(a->d_Vc.alloc(a->n_v));
+  // Q, Q_main, V start at H: `np.zeros(float32) + np.float64` is float64 under NEP 50
+  std::vector<double> q0((size_t)a->n_q), v0((size_t)a->n_v);
+  for (int b = 0; b < B; ++b) {
+    for (int64_t r = env->state_off[b] * A; r < env->state_off[b + 1] * A; ++r) q0[(size_t)r] = Hh[b];
+    for (int64_t s2 = env->state_off[b]; s2 < env->state_off[b + 1]; ++s2) v0[(size_t)s2] = Hh[b];
+  }
+  HIP_TRY(hipMemcpyAsync(a->d_Qc.p, q0.data(), sizeof(double) * a->n_q, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(a->d_Qmainc.p, q0.data(), sizeof(double) * a->n_q, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(a->d_Vc.p, v0.data(), sizeof(double) * a->n_v, hipMemcpyHostToDevice, st));
+  HIP_TRY(a->d_mt.alloc((size_t)B * 624));
+  HIP_TRY(a->d_mtpos.alloc(B));
+  HIP_TRY(a->d_rsum.alloc(B));
+  HIP_TRY(a->d_rsum.zero(st));
+  std::vector<uint32_t> useeds((size_t)B);
+  for (int b = 0; b < B; ++b) useeds[b] = (uint32_t)seeds[b];
+  DevBuf<uint32_t> d_seeds;
+  HIP_TRY(d_seeds.upload(useeds.data(), B, st));
+  hipLaunchKernelGGL(k_mt_seed_numpy, dim3(grid_for(B, 64)), dim3(64), 0, st, a->d_mt.p, a->d_mtpos.p, d_seeds.p, B);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  QlcArgs& q = a->cargs;
+  q.min_at = min_at > 0.009 ? min_at : 0.0;
+  q.four_span = 4 * span_approx_weight;
+  q.log_term = std::log(2 * T / confidence);
+  q.Hh = a->d_Hh.p; q.gamma = a->d_gamma.p; q.q_off = a->d_qoff.p;
+  q.N = a->d_N.p; q.Q = a->d_Qc.p; q.Qmain = a->d_Qmainc.p; q.V = a->d_Vc.p; q.mt = a->d_mt.p; q.mt_pos = a->d_mtpos.p;
+  guard.a = nullptr;
+  *out = a;
+  return CMDP_OK;
+}
+
+int cmdp_qlearning_policy(cmdp_agent_t* a, float* pi) {
+  if (!a || !pi) return fail(CMDP_ERR_INVALID, "null argument");
+  cmdp_t* h = a->env;
+  if (int rc = bind(h)) return rc;
+  if (!a->continuous) return fail(CMDP_ERR_INVALID, "cmdp_qlearning_policy is for the continuous agent; use cmdp_qlearning_evaluate");
+  hipStream_t st = h->stream;
+  if (a->d_pi.n < (size_t)a->n_q) HIP_TRY(a->d_pi.alloc(a->n_q));
+  if (a->d_mt42.n < (size_t)h->B * 624) HIP_TRY(a->d_mt42.alloc((size_t)h->B * 624));
+  hipLaunchKernelGGL(k_greedy_policy_episodic<double>, dim3(grid_for(h->B, 64)), dim3(64), 0, st, h->B, h->A, 1, 1,
+                     h->d_state_off.p, a->d_Qc.p, a->d_pi.p, a->d_mt42.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(pi, a->d_pi.p, sizeof(float) * a->n_q, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return CMDP_OK;
+}
+
 int cmdp_qlearning_destroy(cmdp_agent_t* a) {
   if (!a) return CMDP_OK;
   if (a->env) { (void)hipSetDevice(a->env->device); (void)hipStreamSynchronize(a->env->stream); }
@@ -1084,7 +1171,10 @@ int cmdp_qlearning_run(cmdp_agent_t* a, int64_t n_steps, const uint8_t* train_ma
     dmask = a->d_mask.p;
   }
   const dim3 grid(grid_for(h->B, 256)), block(256);
-  if (a->args.ucb == 0)
+  if (a->continuous)
+    hipLaunchKernelGGL(k_qlearn_continuous, grid, block, 0, st, h->env(), a->cargs, n_steps, dmask,
+                       actions_trace ? a->d_act.p : nullptr, a->d_rsum.p);
+  else if (a->args.ucb == 0)
     hipLaunchKernelGGL((k_qlearn_episodic<0>), grid, block, 0, st, h->env(), a->args, n_steps, dmask,
                        actions_trace ? a->d_act.p : nullptr, a->d_rsum.p);
   else
@@ -1101,6 +1191,7 @@ int cmdp_qlearning_evaluate(cmdp_agent_t* a, float* V0) {
   if (!a || !V0) return fail(CMDP_ERR_INVALID, "null argument");
   cmdp_t* h = a->env;
   if (int rc = bind(h)) return rc;
+  if (a->continuous) return fail(CMDP_ERR_INVALID, "cmdp_qlearning_evaluate is for the episodic agent; use cmdp_qlearning_policy");
   if (!h->has_dp) return fail(CMDP_ERR_INVALID, "the environment handle was created without the DP half");
   hipStream_t st = h->stream;
   const int H = h->H;
@@ -1108,7 +1199,7 @@ int cmdp_qlearning_evaluate(cmdp_agent_t* a, float* V0) {
   if (lds > (size_t)kLdsBudget) return fail(CMDP_ERR_UNSUPPORTED, "instance with %d states does not fit LDS", h->max_S);
   if (a->d_pi.n < (size_t)a->n_q) HIP_TRY(a->d_pi.alloc(a->n_q));
   if (a->d_mt42.n < (size_t)h->B * 624) HIP_TRY(a->d_mt42.alloc((size_t)h->B * 624));
-  hipLaunchKernelGGL(k_greedy_policy_episodic, dim3(grid_for(h->B, 64)), dim3(64), 0, st, h->B, h->A, H, H,
+  hipLaunchKernelGGL(k_greedy_policy_episodic<float>, dim3(grid_for(h->B, 64)), dim3(64), 0, st, h->B, h->A, H, H,
                      h->d_state_off.p, a->d_Q.p, a->d_pi.p, a->d_mt42.p);
   const size_t nq = (size_t)(H + 1) * h->n_rows, nv = (size_t)(H + 1) * h->n_states;
   if (h->d_Q.n < nq) HIP_TRY(h->d_Q.alloc(nq));
@@ -1138,7 +1229,7 @@ int cmdp_greedy_policy_episodic(cmdp_t* h, int H, int q_layers, const float* Q, 
   HIP_TRY(d_q.upload(Q, (size_t)q_layers * h->n_rows, st));
   HIP_TRY(d_p.alloc((size_t)H * h->n_rows));
   HIP_TRY(d_mt.alloc((size_t)h->B * 624));
-  hipLaunchKernelGGL(k_greedy_policy_episodic, dim3(grid_for(h->B, 64)), dim3(64), 0, st, h->B, h->A, H, q_layers,
+  hipLaunchKernelGGL(k_greedy_policy_episodic<float>, dim3(grid_for(h->B, 64)), dim3(64), 0, st, h->B, h->A, H, q_layers,
                      h->d_state_off.p, d_q.p, d_p.p, d_mt.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(pi, d_p.p, sizeof(float) * (size_t)H * h->n_rows, hipMemcpyDeviceToHost, st));
@@ -1150,7 +1241,9 @@ int cmdp_qlearning_tables(cmdp_agent_t* a, float* Q, int32_t* N) {
   if (!a) return fail(CMDP_ERR_INVALID, "null agent");
   if (int rc = bind(a->env)) return rc;
   hipStream_t st = a->env->stream;
-  if (Q) HIP_TRY(hipMemcpyAsync(Q, a->d_Q.p, sizeof(float) * a->n_q, hipMemcpyDeviceToHost, st));
+  if (Q && a->continuous)  // the continuous agent's tables are float64: Q is read as `double*` here
+    HIP_TRY(hipMemcpyAsync(Q, a->d_Qc.p, sizeof(double) * a->n_q, hipMemcpyDeviceToHost, st));
+  else if (Q) HIP_TRY(hipMemcpyAsync(Q, a->d_Q.p, sizeof(float) * a->n_q, hipMemcpyDeviceToHost, st));
   if (N) HIP_TRY(hipMemcpyAsync(N, a->d_N.p, sizeof(int32_t) * a->n_q, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   return CMDP_OK;

@@ -158,24 +158,25 @@ __global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, 
 // argmax_3d (reference colosseum/dynamic_programming/utils.py:28-39): one-hot greedy policy of Q[layers >= H][S][A]
 // with ties broken by `np.random.seed(42); np.random.choice(ties)` -- one numpy MT19937(42) stream per table, rows in
 // (h, s) order, a draw only where there is a tie.  One lane per instance; `mt` is scratch [B][624].
+template <typename QT>
 __global__ void __launch_bounds__(64) k_greedy_policy_episodic(int B, int A, int H, int q_layers,
                                                               const int64_t* __restrict__ state_off,
-                                                              const float* __restrict__ Q, float* __restrict__ pi,
+                                                              const QT* __restrict__ Q, float* __restrict__ pi,
                                                               uint32_t* __restrict__ mt_all) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int64_t soff = state_off[b];
   const int S = (int)(state_off[b + 1] - soff);
-  const float* q = Q + (int64_t)q_layers * soff * A;
+  const QT* q = Q + (int64_t)q_layers * soff * A;
   float* p = pi + (int64_t)H * soff * A;
   uint32_t* mt = mt_all + (int64_t)b * 624;
   mt[0] = 42u;
   for (int k = 1; k < 624; ++k) mt[k] = 1812433253u * (mt[k - 1] ^ (mt[k - 1] >> 30)) + (uint32_t)k;
   int pos = 0;
   for (int64_t r = 0; r < (int64_t)H * S; ++r) {
-    const float* row = q + r * A;
-    float m = row[0];
-    for (int a = 1; a < A; ++a) m = fmaxf(m, row[a]);
+    const QT* row = q + r * A;
+    QT m = row[0];
+    for (int a = 1; a < A; ++a) m = (row[a] > m) ? row[a] : m;
     int n_tie = 0;
     for (int a = 0; a < A; ++a) n_tie += (row[a] == m) ? 1 : 0;
     int pick = 0;
@@ -193,4 +194,96 @@ __global__ void __launch_bounds__(64) k_greedy_policy_episodic(int B, int A, int
       k += tie ? 1 : 0;
     }
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Continuous (average-reward) optimistic Q-learning, reference
+//   colosseum/agent/agents/infinite_horizon/q_learning.py:47-112 (_QValuesModel.step_update, Wei et al. 2020)
+// with the same greedy actor.  Same discipline as above: numpy's scalar arithmetic, dtype promotion included.
+// ---------------------------------------------------------------------------------------------------
+struct QlcArgs {
+  double min_at;                  // python float (or int 0): `min_at if min_at > 0.009 else 0`
+  double four_span;               // 4 * span_approx (python float product)
+  double log_term;                // np.log(2 * optimization_horizon / confidence)
+  const double* Hh;               // [B] np.float64 horizon approximation h_weight * get_H(...)
+  const double* gamma;            // [B] 1 - 1 / H
+  const int64_t* q_off;           // [B] = state_off[b] * A
+  int32_t* N;                     // [rows] starts at 0
+  // `np.zeros(..., np.float32) + self.H` with self.H a numpy float64 scalar is a FLOAT64 array under NEP 50
+  // (numpy >= 2, the semantics the goldens were produced with): the tables and every operation are float64.
+  double* Q;                      // starts at H
+  double* Qmain;                  // starts at H
+  double* V;                      // [states] starts at H
+  uint32_t* mt;
+  int32_t* mt_pos;
+};
+
+__global__ void __launch_bounds__(256) k_qlearn_continuous(EnvTables t, QlcArgs q, int64_t n_steps,
+                                                           const uint8_t* __restrict__ train_mask,
+                                                           int8_t* __restrict__ act_trace, double* __restrict__ cum_reward) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= t.B) return;
+  const int64_t soff = t.state_off[b], ebase = t.entry_base[b];
+  const int A = t.A;
+  const uint2 key = t.philox_key ? t.philox_key[b] : make_uint2(0, 0);
+  int32_t cur = t.cur[b], h = t.hstep[b];
+  unsigned long long nt = t.n_trans[b];
+  double* Q = q.Q + q.q_off[b];
+  double* QM = q.Qmain + q.q_off[b];
+  int32_t* N = q.N + q.q_off[b];
+  double* V = q.V + soff;
+  uint32_t* mt = q.mt + (int64_t)b * 624;
+  int32_t* mtp = q.mt_pos + b;
+  const double Hh = q.Hh[b], gamma = q.gamma[b];
+  const bool train = train_mask ? train_mask[b] != 0 : true;
+  double sum = cum_reward[b];
+  for (int64_t step = 0; step < n_steps; ++step) {
+    const double* qrow = Q + (int64_t)cur * A;
+    double qmax = qrow[0];
+    for (int a = 1; a < A; ++a) qmax = fmax(qmax, qrow[a]);
+    int n_tie = 0;
+    for (int a = 0; a < A; ++a) n_tie += (qrow[a] == qmax) ? 1 : 0;
+    int pick = 0;
+    if (n_tie > 1) {
+      const uint32_t mx = (uint32_t)(n_tie - 1);
+      uint32_t mask = mx;
+      mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+      int pos = *mtp;
+      uint32_t v;
+      do { v = mt_next_word(mt, pos) & mask; } while (v > mx);
+      *mtp = pos;
+      pick = (int)v;
+    }
+    int action = 0;
+    for (int a = 0, k = 0; a < A; ++a)
+      if (qrow[a] == qmax) { if (k == pick) action = a; ++k; }
+    if (act_trace) act_trace[step * t.B + b] = (int8_t)action;
+    const int32_t s_t = cur;
+    int32_t obs;
+    double reward;
+    env_step(t, soff, ebase, key, cur, h, nt, action, obs, reward);  // continuous: never terminates
+    sum += reward;
+    if (train) {
+      const int64_t idx = (int64_t)s_t * A + action;
+      const int32_t n = N[idx] + 1;
+      N[idx] = n;
+      const double x = (Hh + 1.0) / (Hh + (double)n);
+      const double alpha = (x > q.min_at) ? x : q.min_at;  // max(min_at, x)
+      const double b_t = q.four_span * sqrt(Hh / (double)n * q.log_term);
+      const double target = (reward + gamma * V[obs]) + b_t;
+      const double qold = Q[idx];
+      const double qm = (1.0 - alpha) * qold + alpha * target;
+      QM[idx] = qm;
+      Q[idx] = (qm < qold) ? qm : qold;  // min(Q, Q_main)
+      const double* qr = Q + (int64_t)obs * A;
+      double m2 = qr[0];
+      for (int a = 1; a < A; ++a) m2 = fmax(m2, qr[a]);
+      V[obs] = m2;  // self.V[s_tp1] = self.Q[s_tp1].max()
+    }
+  }
+  t.cur[b] = cur;
+  t.hstep[b] = h;
+  t.n_trans[b] = nt;
+  cum_reward[b] = sum;
 }

@@ -127,3 +127,80 @@ class BatchedEpisodicLoop:
         cum = agent.run(T - done, train=mask)["cumulative_reward"]
         self._log(T - 1, cum, n_since, T, in_loop=False)
         return [tr.logger.data for tr in self.trackers]
+
+
+class _ContinuousView:
+    def __init__(self, optimal, worst, random, parameters):
+        self.optimal_average_reward, self.worst_average_reward, self.random_average_reward = optimal, worst, random
+        self.parameters = parameters
+
+    @staticmethod
+    def is_episodic():
+        return False
+
+
+class _ContinuousTracker(MDPLoop):
+    def __init__(self, view, n_check):
+        self.logger = InMemoryLogger()
+        self._mdp = view
+        self._agent = None
+        self._episodic = False
+        self._n_steps_to_check_for_agent_optimality = n_check
+        self._avg = None
+        self._max_time = np.inf
+
+    def _average_reward_of_agent_policy(self):
+        return self._avg
+
+
+class BatchedContinuousLoop:
+    """`MDPLoop.run` for a batch of continuous (environment, QLearningContinuous) pairs: interaction on the device,
+    regrets from the stationary distributions of the agents' greedy policies (host class bookkeeping, one batched GTH
+    call per logging step)."""
+
+    def __init__(self, env: BatchedMDP, agent, n_log_intervals_to_check_for_agent_optimality: int = 10):
+        from ..dynamic_programming import get_policy_from_q_values
+        from ..markov_chain import get_average_reward_batch
+
+        assert env.H == 0 and env.models is not None
+        self.env, self.agent = env, agent
+        self._batch = get_average_reward_batch
+        A = env.A
+        self._TR = [m.dense() for m in env.models]
+        # baselines: optimal / worst (greedy w.r.t. VI on R / -R, gamma .99, eps 1e-3) and uniform policies
+        Q, _, _ = env.value_iteration()
+        Qw, _, _ = env.value_iteration(R=[-m.reward_matrix() for m in env.models])
+        probs = []
+        for b, m in enumerate(env.models):
+            T, R = self._TR[b]
+            starts = list(zip(m.start_states.tolist(), m.start_probs.tolist()))
+            S = m.n_states
+            pi_o = get_policy_from_q_values(env.split_rows(Q)[b].reshape(S, A), True)
+            pi_w = get_policy_from_q_values(env.split_rows(Qw)[b].reshape(S, A), True)
+            pi_r = np.ones((S, A), np.float32) / A
+            probs += [(T, R, pi_o, starts), (T, R, pi_w, starts), (T, R, pi_r, None)]
+        vals = self._batch(probs)
+        self.trackers = []
+        for b, m in enumerate(env.models):
+            # `sum(sd * ars)` of the reference is a left-to-right Python sum; the batched helper uses ndarray.sum --
+            # the difference is below 1e-15 relative and far below the 5-decimal rounding of the logger
+            view = _ContinuousView(vals[3 * b], vals[3 * b + 1], vals[3 * b + 2], m.extra.get("kwargs", {}))
+            self.trackers.append(_ContinuousTracker(view, n_log_intervals_to_check_for_agent_optimality))
+
+    def _log(self, t, cum, n_since, T, in_loop):
+        policies = self.agent.policy()
+        cur, _, _ = self.env.state()
+        avgs = self._batch([(self._TR[b][0], self._TR[b][1], policies[b], [(int(cur[b]), 1.0)]) for b in range(self.env.B)])
+        for b, tr in enumerate(self.trackers):
+            tr._avg = avgs[b]
+            tr._cumulative_reward = float(cum[b])
+            tr._n_steps_since_last_log = n_since
+            tr._update_performance_logs(t)
+            if in_loop:
+                tr._latest_expected_regrets.append(tr._normalized_regret)
+                if len(tr._latest_expected_regrets) > tr._n_steps_to_check_for_agent_optimality:
+                    tr._latest_expected_regrets.pop(0)
+                if tr._is_training and t > 0.2 * T and tr._is_policy_optimal():
+                    tr._is_training = False
+
+    run = BatchedEpisodicLoop.run

@@ -236,10 +236,16 @@ class MDPLoop:
         else:
             self._regret, self._normalized_regret = self._get_continuous_regrets()
 
+    def _average_reward_of_agent_policy(self):
+        """Average reward of the agent's current greedy policy from the current state's recurrent class; overridden by
+        the batched loop (all instances' GTH eliminations in one device call)."""
+        m = self._mdp
+        return get_average_reward(m.T, m.R, self._agent.current_optimal_stochastic_policy,
+                                  [(m.node_to_index[m.cur_node], 1.0)])
+
     def _get_continuous_regrets(self):
         m = self._mdp
-        self._agent_continuous_average_reward = get_average_reward(
-            m.T, m.R, self._agent.current_optimal_stochastic_policy, [(m.node_to_index[m.cur_node], 1.0)])
+        self._agent_continuous_average_reward = self._average_reward_of_agent_policy()
         r = m.optimal_average_reward - self._agent_continuous_average_reward
         if np.isclose(r, 0.0, atol=1e-3):
             r = 0.0

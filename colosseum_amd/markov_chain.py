@@ -75,6 +75,60 @@ def get_stationary_distribution(tps: np.ndarray,
     return _class_distribution(tps, np.arange(n))
 
 
+def _stationary_plan(tps: np.ndarray, starting_states_and_probs):
+    """Which recurrent classes enter the stationary distribution and with which weight: (result dtype, [(cls, weight)])."""
+    n = len(tps)
+    classes = recurrent_classes(tps)
+    if len(classes) == 1 and len(classes[0]) < n:
+        return np.float32, [(classes[0], None)]
+    if len(classes) > 1:
+        g = csr_matrix(tps > 0)
+        plan = []
+        for ss, p in starting_states_and_probs:
+            reach = set(breadth_first_order(g, ss, directed=True, return_predecessors=False).tolist())
+            for cls in classes:
+                if int(cls[0]) in reach:
+                    plan.append((cls, p))
+                    break
+        return np.float64, plan
+    return None, [(np.arange(n), None)]
+
+
+def get_average_reward_batch(problems) -> List[float]:
+    """`get_average_reward` for many (T, R, policy, starting_states_and_probs) at once: the recurrent-class bookkeeping
+    per problem on the host, ALL GTH eliminations in one device call."""
+    prepared, mats = [], []
+    for T, R, policy, starts in problems:
+        assert np.isclose(policy.sum(-1), 1).all(), "the policy specification is incorrect."
+        ars = get_average_rewards(R, policy)
+        tps = get_transition_probabilities(T, policy)
+        dtype, plan = _stationary_plan(tps, starts)
+        slots = []
+        for cls, w in plan:
+            if len(cls) == 1:
+                slots.append((cls, w, None))
+            else:
+                slots.append((cls, w, len(mats)))
+                mats.append(tps[np.ix_(cls, cls)])
+        prepared.append((ars, len(tps), dtype, slots))
+    sols = gth_batch(mats)
+    out = []
+    for ars, n, dtype, slots in prepared:
+        if dtype is None:
+            cls, _, k = slots[0]
+            sd = np.ones(1) if k is None else sols[k]
+        else:
+            sd = np.zeros(n, dtype)
+            for cls, w, k in slots:
+                x = np.ones(1) if k is None else sols[k]
+                if w is None:
+                    sd[cls] = x
+                else:
+                    sd[cls] += w * x
+        out.append((ars * sd).sum())
+    return out
+
+
 def get_average_reward(T: np.ndarray, R: np.ndarray, policy: np.ndarray, next_states_and_probs) -> float:
     """markov_chain.py:12-31."""
     assert np.isclose(policy.sum(-1), 1).all(), "the policy specification is incorrect."

@@ -236,6 +236,12 @@ typedef struct cmdp_agent cmdp_agent_t;
 int cmdp_qlearning_create(cmdp_agent_t** out, cmdp_t* env, const int32_t* seeds, int64_t optimization_horizon,
                           double p, double c_1, double c_2, double min_at, int ucb_type);
 int cmdp_qlearning_destroy(cmdp_agent_t* a);
+/* The continuous-setting agent, colosseum/agent/agents/infinite_horizon/q_learning.py (QLearningContinuous: optimistic
+   Q-learning for the average-reward setting) on a continuous environment handle; get_span_approx / get_H are the
+   reference defaults.  The returned handle is used with the same cmdp_qlearning_run / _tables / _destroy. */
+int cmdp_qlearning_continuous_create(cmdp_agent_t** out, cmdp_t* env, const int32_t* seeds,
+                                     int64_t optimization_horizon, double min_at, double confidence,
+                                     double span_approx_weight, double h_weight);
 /* MDPLoop.run's loop with the agent in it (colosseum/experiment/agent_mdp_interaction.py:238-298): per step
    select_action -> BaseMDP.step -> step_update -> reset() at the end of an episode.  train_mask [B] (NULL = all
    ones): instances with 0 act but do not update, as after MDPLoop froze their training (:284-288).
@@ -247,10 +253,14 @@ int cmdp_qlearning_run(cmdp_agent_t* a, int64_t n_steps, const uint8_t* train_ma
    (BaseAgent.current_optimal_stochastic_policy = argmax_3d(Q), ties by RandomState(42)): what
    MDPLoop._compute_episodic_regret needs.  The environment handle must carry the DP half.  V0 [state_off[B]]. */
 int cmdp_qlearning_evaluate(cmdp_agent_t* a, float* V0);
+/* argmax_2d (colosseum/dynamic_programming/utils.py:12-25) of the continuous agents' Q tables: one-hot float32
+   policies pi [state_off[B]*A] (BaseAgent.current_optimal_stochastic_policy). */
+int cmdp_qlearning_policy(cmdp_agent_t* a, float* pi);
 /* argmax_3d (colosseum/dynamic_programming/utils.py:28-39) of host tables Q [per instance q_layers*S_b*A, q_layers
    >= H]: one-hot float32 policy of the first H layers, pi [per instance H*S_b*A]. */
 int cmdp_greedy_policy_episodic(cmdp_t* h, int H, int q_layers, const float* Q, float* pi);
-/* Q [B instances concatenated: H*S_b*A floats each], N likewise (int32); either may be NULL. */
+/* Q [B instances concatenated: H*S_b*A float32 each for the episodic agent; S_b*A FLOAT64 each -- pass a double* --
+   for the continuous agent, whose tables are float64], N likewise (int32); either may be NULL. */
 int cmdp_qlearning_tables(cmdp_agent_t* a, float* Q, int32_t* N);
 
 /* ---- Markov chains ------------------------------------------------------------------------------------ */

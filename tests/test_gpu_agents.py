@@ -15,7 +15,7 @@ from colosseum_amd import timestep as ts_
 from colosseum_amd.agents import BatchedQLearningEpisodic
 from colosseum_amd.batched import BatchedMDP
 from colosseum_amd.mdp import make_model
-from helpers_agents import QLearningEpisodic
+from helpers_agents import QLearningContinuous, QLearningEpisodic
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -24,6 +24,13 @@ pytestmark = pytest.mark.gpu
 class _Spec:
     def __init__(self, m):
         self.time_horizon = m.H
+        self.observations = type("o", (), {"num_values": m.n_states})()
+        self.actions = type("a", (), {"num_values": m.n_actions})()
+
+
+class _SpecC(_Spec):
+    def __init__(self, m):
+        self.time_horizon = np.inf
         self.observations = type("o", (), {"num_values": m.n_states})()
         self.actions = type("a", (), {"num_values": m.n_actions})()
 
@@ -111,5 +118,51 @@ def test_batched_episodic_loop_matches_reference_logger_rows(need_gpu):
                     assert float(got[k]) == pytest.approx(v, rel=2e-6, abs=2e-5), (c["mdp_kwargs"], k, got["steps"])
         Q, N = ag.tables()
         np.testing.assert_array_equal(Q[2].astype(np.float64), np.asarray(c["Q_final"]))
+        ag.close()
+        env.close()
+
+
+def test_device_continuous_qlearning_and_batched_loop(need_gpu):
+    """Continuous setting: device QLearningContinuous (float64 tables, as numpy >= 2 makes them) against the reference
+    run (golden G10): action streams, and the logger rows through BatchedContinuousLoop."""
+    from colosseum_amd.agents import BatchedQLearningContinuous
+    from colosseum_amd.experiment.batched_loop import BatchedContinuousLoop
+
+    cases = json.load(open(os.path.join(GOLDEN, "G10_mdploop_continuous.json")))
+    for c in cases:
+        m = make_model(c["mdp_cls"], **c["mdp_kwargs"])
+        kw = dict(c["agent_kwargs"])
+        seed = kw.pop("seed")
+        # (i) plain run: actions equal the reference's as long as its MDPLoop kept training
+        env = BatchedMDP([m], rng_mode=L.RNG_MT_COMPAT, with_dp=False)
+        env.reset()
+        ag = BatchedQLearningContinuous(env, [seed], **kw)
+        ref_rows = c["rows"]
+        acts = ag.run(c["T"], trace_actions=True)["actions"][:, 0]
+        host = QLearningContinuous(mdp_specs=_SpecC(m), seed=seed, **kw)
+        e = O.OracleEnv(m, rng_mode=0)
+        ts, hacts = ts_.restart(e.reset()), []
+        for t in range(c["T"]):
+            a = int(host.select_action(ts, t))
+            hacts.append(a)
+            ty, o, r, _ = e.step(a)
+            nts = ts_.transition(r, o)
+            host.step_update(ts, a, nts, t)
+            ts = nts
+        np.testing.assert_array_equal(acts, np.array(hacts, np.int8))
+        Q, N = ag.tables()
+        np.testing.assert_array_equal(Q[0], host.Q)
+        np.testing.assert_array_equal(N[0], host.N)
+        ag.close()
+        env.close()
+        # (ii) the full loop with logging, twice in one batch
+        env = BatchedMDP([m, m], rng_mode=L.RNG_MT_COMPAT)
+        ag = BatchedQLearningContinuous(env, [seed, seed], **kw)
+        rows = BatchedContinuousLoop(env, ag).run(T=c["T"], log_every=c["log_every"])
+        for inst in rows:
+            assert len(inst) == len(ref_rows)
+            for got, ref in zip(inst, ref_rows):
+                for k, v in ref.items():
+                    assert float(got[k]) == pytest.approx(v, rel=2e-6, abs=2e-5), (c["mdp_kwargs"], k, got["steps"])
         ag.close()
         env.close()
