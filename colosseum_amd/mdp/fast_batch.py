@@ -45,6 +45,8 @@ def deepsea_episodic_tables(seeds: Sequence[int], size: int, with_dp: bool = Fal
         sp_cum=np.ones(R, np.float64),
         sp_reward=np.ascontiguousarray(rew, np.float64).reshape(-1),
         sp_rkind=np.zeros(R, np.uint8),
+        sp_rp0=np.ascontiguousarray(rew, np.float64).reshape(-1),
+        sp_rp1=np.zeros(R, np.float64),
         sp_seed=np.zeros(R, np.int32),  # never read: every row is deterministic (no sampler stream)
         start_off=np.arange(B + 1, dtype=np.int64),
         start_state=np.full(B, tpl.start_states[0], np.int32),
