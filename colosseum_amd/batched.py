@@ -190,6 +190,14 @@ class BatchedMDP:
         L.check(self._lib.cmdp_state(self._h, L.ptr(cur), L.ptr(h), L.ptr(nr)))
         return cur, h, nr.astype(bool)
 
+    def last_start(self) -> np.ndarray:
+        """State index sampled by the latest reset() of every instance (BaseMDP.last_starting_node)."""
+        out = np.zeros(self.B, np.int32)
+        prev = np.zeros(self.B, np.int32)
+        L.check(self._lib.cmdp_last_start(self._h, L.ptr(out), L.ptr(prev)))
+        self.previous_start = prev
+        return out
+
     # -- helpers ------------------------------------------------------------------------------------------
     def split_states(self, flat, lead: int = 1) -> List[np.ndarray]:
         return [flat[lead * self.state_off[b]: lead * self.state_off[b + 1]] for b in range(self.B)]

@@ -1,0 +1,161 @@
+"""Sharded benchmark runner (BASELINE config C4).
+
+The reference enumerates (seed x MDP gin scope x agent gin scope) experiment instances, runs each in its own OS process
+(colosseum/experiment/experiment_instances.py:117-223) and meets the results on the filesystem as one CSV per instance
+(`<folder>/logs/<mdp_scope>-<MDP>____<agent_scope>-<Agent>/seed<n>_logs.csv`, header = sorted indicator names,
+colosseum/utils/acme/csv_logger.py:99, colosseum/experiment/experiment_instance.py:53-82).
+
+Here the same enumeration (seed-major, folder_structuring.py:76-104) is block-partitioned over the ranks (one process per
+GPU, `colosseum_amd.sharding`), each rank groups its instances into device batches (same class, horizon and action
+count), runs them with agents on the device (`colosseum_amd.agents`, `experiment.batched_loop`) and writes the same CSV
+files.  The only communication is the final gather of one summary vector per instance.
+
+Gin files of the benchmark folders only contain `prms_<i>/<Class>.<param> = <literal>` lines; they are parsed with a
+regular expression (no gin dependency)."""
+import ast
+import csv
+import os
+import re
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+from .agents import BatchedQLearningContinuous, BatchedQLearningEpisodic
+from .batched import BatchedMDP
+from .experiment.batched_loop import BatchedContinuousLoop, BatchedEpisodicLoop
+from .mdp import make_model
+from .sharding import shard_range
+
+_GIN_LINE = re.compile(r"^\s*(prms_\d+)/(\w+)\.(\w+)\s*=\s*(.+?)\s*$")
+
+# tuned hyper-parameters shipped with the reference (benchmark/cached_hyperparameters/agent_configs/*.gin)
+DEFAULT_AGENT_CONFIGS = {
+    "QLearningEpisodic": dict(p=0.05, UCB_type="bernstein", c_1=0.9415278732894797, c_2=0.013873778519317169,
+                              min_at=0.07263563483119442),
+    "QLearningContinuous": dict(h_weight=0.942, span_approx_weight=0.014, min_at=0.073),
+}
+
+
+def parse_gin(text: str) -> Dict[str, Dict[str, Dict[str, Any]]]:
+    """{class: {scope: {param: value}}} from `prms_0/DeepSeaEpisodic.size=10` lines."""
+    out: Dict[str, Dict[str, Dict[str, Any]]] = {}
+    for line in text.splitlines():
+        m = _GIN_LINE.match(line)
+        if not m:
+            continue
+        scope, cls, key, val = m.groups()
+        out.setdefault(cls, {}).setdefault(scope, {})[key] = ast.literal_eval(val)
+    return out
+
+
+def load_mdp_configs(folder: str) -> Dict[str, Dict[str, Dict[str, Any]]]:
+    """All `mdp_configs/*.gin` of a benchmark folder laid out like the reference's."""
+    cfg: Dict[str, Dict[str, Dict[str, Any]]] = {}
+    d = os.path.join(folder, "mdp_configs")
+    for f in sorted(os.listdir(d)):
+        if f.endswith(".gin"):
+            for cls, scopes in parse_gin(open(os.path.join(d, f)).read()).items():
+                cfg.setdefault(cls, {}).update(scopes)
+    return cfg
+
+
+@dataclass
+class Instance:
+    seed: int
+    mdp_cls: str
+    mdp_scope: str
+    mdp_kwargs: Dict[str, Any]
+    agent_cls: str
+    agent_scope: str = "prms_0"
+
+    @property
+    def label(self) -> str:  # ExperimentInstance.experiment_label
+        return f"{self.mdp_scope}-{self.mdp_cls}____{self.agent_scope}-{self.agent_cls}"
+
+
+def enumerate_instances(mdp_configs: Dict[str, Dict[str, Dict[str, Any]]], n_seeds: int,
+                        supported_only: bool = True) -> List[Instance]:
+    """Seed-major enumeration of folder_structuring.py:76-104 with one tabular Q-learning agent per setting."""
+    from .mdp.registry import FAMILIES
+
+    out = []
+    for seed in range(n_seeds):
+        for cls, scopes in mdp_configs.items():
+            fam = cls.replace("Episodic", "").replace("Continuous", "")
+            if fam not in FAMILIES:
+                if supported_only:
+                    continue
+                raise KeyError(cls)
+            agent = "QLearningEpisodic" if cls.endswith("Episodic") else "QLearningContinuous"
+            for scope in sorted(scopes, key=lambda s: int(s.split("_")[1])):
+                out.append(Instance(seed, cls, scope, dict(scopes[scope]), agent))
+    return out
+
+
+def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_mode, device):
+    L.check(L.load().cmdp_set_device(device))
+    stochastic = any(not m.deterministic_rewards for m in models)
+    # Beta rewards: sampled on the device in Philox mode (the reference-exact host sampler is a per-step path)
+    env = BatchedMDP(models, rng_mode=L.RNG_PHILOX if stochastic else rng_mode,
+                     philox_keys=np.asarray(seeds, np.uint64) * np.uint64(0x9E3779B1) + np.uint64(17))
+    if agent_cls == "QLearningEpisodic":
+        agent = BatchedQLearningEpisodic(env, seeds, optimization_horizon=n_steps, **agent_kwargs)
+        loop = BatchedEpisodicLoop(env, agent)
+    else:
+        agent = BatchedQLearningContinuous(env, seeds, optimization_horizon=n_steps, **agent_kwargs)
+        loop = BatchedContinuousLoop(env, agent)
+    rows = loop.run(n_steps, log_every)
+    agent.close()
+    env.close()
+    return rows
+
+
+def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, rank: int = 0, world: int = 1,
+                  agent_configs: Optional[Dict[str, Dict[str, Any]]] = None, rng_mode: int = L.RNG_MT_COMPAT,
+                  device: int = 0, max_concurrent_groups: int = 4):
+    """Runs this rank's contiguous shard; returns {global instance index: logger rows}."""
+    agent_configs = agent_configs or DEFAULT_AGENT_CONFIGS
+    lo, hi = shard_range(len(instances), rank, world)
+    mine = list(range(lo, hi))
+    models = {i: make_model(instances[i].mdp_cls, seed=instances[i].seed, **instances[i].mdp_kwargs) for i in mine}
+    groups: Dict[tuple, List[int]] = {}
+    for i in mine:
+        m = models[i]
+        groups.setdefault((instances[i].mdp_cls, m.H, m.n_actions, tuple(m.rewards_range)), []).append(i)
+    results: Dict[int, list] = {}
+
+    def work(idx):
+        ins = instances[idx[0]]
+        rows = _run_group([models[i] for i in idx], [instances[i].seed for i in idx], ins.agent_cls,
+                          agent_configs[ins.agent_cls], n_steps, log_every, rng_mode, device)
+        return idx, rows
+
+    # every group owns a handle with its own HIP stream; the C calls release the GIL, so groups overlap on the device
+    with ThreadPoolExecutor(max_workers=max(1, max_concurrent_groups)) as pool:
+        for idx, rows in pool.map(work, list(groups.values())):
+            for i, r in zip(idx, rows):
+                results[i] = r
+    return results
+
+
+def write_csv_logs(folder: str, instances: Sequence[Instance], results: Dict[int, list]):
+    """The reference's on-disk wire format (CSVLogger with add_uid=False; header = sorted keys)."""
+    for i, rows in results.items():
+        ins = instances[i]
+        d = os.path.join(folder, "logs", ins.label)
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, f"seed{ins.seed}_logs.csv"), "w", newline="") as f:
+            fields = sorted(rows[0].keys())
+            w = csv.DictWriter(f, fieldnames=fields, extrasaction="ignore")
+            w.writeheader()
+            for r in rows:
+                w.writerow({k: np.array(v) for k, v in r.items()})
+
+
+def summary_vector(rows) -> np.ndarray:
+    """What is gathered across ranks at the end: last step, normalized cumulative regret, cumulative reward."""
+    last = rows[-1]
+    return np.array([last["steps"], last["normalized_cumulative_regret"], last["cumulative_reward"]], np.float64)

@@ -81,7 +81,7 @@ struct cmdp {
   DevBuf<int64_t> d_state_off, d_entry_base, d_start_off, d_csr_ptr;
   DevBuf<RowDesc> d_row;
   DevBuf<int32_t> d_sp_next, d_start_state, d_start_slot, d_mt_pos, d_cur, d_h, d_visits_s, d_visits_sa, d_csr_col,
-      d_flag, d_status, d_i32_scratch;
+      d_flag, d_status, d_i32_scratch, d_last_start, d_prev_start;
   DevBuf<double> d_sp_cum, d_sp_reward, d_start_cum, d_f64_scratch, d_sp_rp0, d_sp_rp1;
   DevBuf<uint8_t> d_sp_rkind;
   DevBuf<uint2> d_key;
@@ -116,7 +116,7 @@ struct cmdp {
     t.start_off = d_start_off.p; t.start_state = d_start_state.p; t.start_cum = d_start_cum.p;
     t.start_slot = d_start_slot.p; t.philox_key = d_key.p; t.mt = d_mt.p; t.mt_pos = d_mt_pos.p;
     t.cur = d_cur.p; t.hstep = d_h.p; t.need_reset = d_need_reset.p; t.n_trans = d_ntrans.p; t.n_reset = d_nreset.p;
-    t.visits_s = d_visits_s.p; t.visits_sa = d_visits_sa.p;
+    t.visits_s = d_visits_s.p; t.visits_sa = d_visits_sa.p; t.last_start = d_last_start.p; t.prev_start = d_prev_start.p;
     return t;
   }
 };
@@ -299,6 +299,10 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
     HIP_TRY(h->d_key.upload(keys.data(), B, st));
     HIP_TRY(h->d_cur.alloc(B));
     HIP_TRY(h->d_cur.zero(st));
+    HIP_TRY(h->d_last_start.alloc(B));
+    HIP_TRY(h->d_last_start.zero(st));
+    HIP_TRY(h->d_prev_start.alloc(B));
+    HIP_TRY(h->d_prev_start.zero(st));
     HIP_TRY(h->d_h.alloc(B));
     HIP_TRY(h->d_h.zero(st));
     HIP_TRY(h->d_need_reset.alloc(B));
@@ -655,6 +659,16 @@ int cmdp_reset_visits(cmdp_t* h) {
   if (!h->has_env) return fail(CMDP_ERR_INVALID, "handle was created without the sampler half");
   HIP_TRY(h->d_visits_s.zero(h->stream));
   HIP_TRY(h->d_visits_sa.zero(h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CMDP_OK;
+}
+
+int cmdp_last_start(cmdp_t* h, int32_t* last_start, int32_t* previous_start) {
+  if (int rc = bind(h)) return rc;
+  if (!h->has_env || !last_start) return fail(CMDP_ERR_INVALID, "bad argument");
+  HIP_TRY(hipMemcpyAsync(last_start, h->d_last_start.p, sizeof(int32_t) * h->B, hipMemcpyDeviceToHost, h->stream));
+  if (previous_start)
+    HIP_TRY(hipMemcpyAsync(previous_start, h->d_prev_start.p, sizeof(int32_t) * h->B, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CMDP_OK;
 }

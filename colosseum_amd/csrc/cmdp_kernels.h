@@ -55,6 +55,8 @@ struct EnvTables {
   unsigned long long* n_reset;       // [B]
   int32_t* visits_s;                 // [NSTATES]
   int32_t* visits_sa;                // [R]
+  int32_t* last_start;               // [B] BaseMDP.last_starting_node (index): state of the latest reset()
+  int32_t* prev_start;               // [B] the one before it (MDPLoop logs BEFORE the reset that follows a termination)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -96,6 +98,8 @@ __device__ __forceinline__ int32_t env_reset(const EnvTables& t, int b, int64_t 
   n_reset++;
   const int32_t s = t.start_state[lo + idx];
   bump(t.visits_s + soff + s);
+  t.prev_start[b] = t.last_start[b];
+  t.last_start[b] = s;
   return s;
 }
 

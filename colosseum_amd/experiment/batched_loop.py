@@ -89,7 +89,14 @@ class BatchedEpisodicLoop:
 
     def _log(self, t: int, cum: np.ndarray, n_since: int, T: int, in_loop: bool):
         V0 = self.agent.evaluate()
+        last_start = self.env.last_start()
+        prev_start = self.env.previous_start
+        hstep = self.env.state()[1]
         for b, tr in enumerate(self.trackers):
+            # the reference logs step t before the reset that follows a termination: if step t ended an episode
+            # (in-episode time back at 0), its `last_starting_node` is still the start of the episode that ended
+            ended = in_loop and hstep[b] == 0
+            tr._mdp.last_starting_node = int(prev_start[b] if ended else last_start[b])
             tr.set_evaluation(self.env.split_states(V0)[b])
             tr._cumulative_reward = float(cum[b])
             tr._n_steps_since_last_log = n_since

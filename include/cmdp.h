@@ -188,6 +188,10 @@ int cmdp_reset_visits(cmdp_t* h);
 /* Current state index, in-episode step and needs-reset flag of every instance (BaseMDP.cur_node,
    .h, .necessary_reset); each may be NULL. */
 int cmdp_state(cmdp_t* h, int32_t* cur, int32_t* hstep, uint8_t* needs_reset);
+/* BaseMDP.last_starting_node as a state index: the state the latest reset() of every instance sampled [B], and
+   (nullable) the one the reset before it sampled -- MDPLoop evaluates a log row BEFORE the reset that follows a
+   terminating step, while the fused kernels reset at once. */
+int cmdp_last_start(cmdp_t* h, int32_t* last_start, int32_t* previous_start);
 
 /* ---- dynamic programming ---------------------------------------------------------------------------- */
 /* discounted_value_iteration (colosseum/dynamic_programming/infinite_horizon.py:14-44,121-164).

@@ -498,10 +498,14 @@ def g7():
               min_at=0.07263563483119442)
     cases = []
     hp_h = dict(p=0.05, UCB_type="hoeffding", c_1=0.0031, min_at=0.0)
-    for mdp_kw, T, log_every, hpx in ((dict(seed=0, size=8), 20_000, 1_000, hp), (dict(seed=3, size=5, p_rand=0.2), 6_000, 500, hp),
-                                      (dict(seed=1, size=6, p_rand=0.1), 6_000, 500, hp_h)):
+    for mdp_cls, mdp_kw, T, log_every, hpx in (
+            ("DeepSeaEpisodic", dict(seed=0, size=8), 20_000, 1_000, hp),
+            ("DeepSeaEpisodic", dict(seed=3, size=5, p_rand=0.2), 6_000, 500, hp),
+            ("DeepSeaEpisodic", dict(seed=1, size=6, p_rand=0.1), 6_000, 500, hp_h),
+            # three starting states: the regret of a log row refers to the start state of the CURRENT episode
+            ("MiniGridEmptyEpisodic", dict(seed=0, size=4, p_rand=0.05, n_starting_states=3), 6_000, 500, hp)):
         hp_used = hpx
-        mdp = DeepSeaEpisodic(**mdp_kw)
+        mdp = CLASSES[mdp_cls](**mdp_kw)
         agent = QLearningEpisodic(seed=mdp_kw["seed"], mdp_specs=make_mdp_spec(mdp), optimization_horizon=T, **hp_used)
         actions = []
         sel = agent.select_action
@@ -515,7 +519,7 @@ def g7():
         loop = MDPLoop(mdp, agent)
         last_training_step, last_logs = loop.run(T=T, log_every=log_every)
         rows = [{k: float(v) for k, v in r.items() if k != "steps_per_second"} for r in loop.logger.data]
-        cases.append(dict(mdp_cls="DeepSeaEpisodic", mdp_kwargs=mdp_kw, agent="QLearningEpisodic",
+        cases.append(dict(mdp_cls=mdp_cls, mdp_kwargs=mdp_kw, agent="QLearningEpisodic",
                           agent_kwargs=dict(seed=mdp_kw["seed"], optimization_horizon=T, **hp_used), T=T, log_every=log_every,
                           last_training_step=int(last_training_step), rows=rows, actions=actions,
                           Q_final=np.asarray(agent._mdp_model.Q, np.float64).tolist(),  # float32 values, exact in JSON
@@ -647,7 +651,42 @@ def g10():
         json.dump(cases, f)
 
 
-GROUPS = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10)
+def g11():
+    """Benchmark definitions (data, not code): the MDP parameterisations of the reference's default benchmarks for the
+    four in-scope families, read from benchmark/benchmark_*/mdp_configs/*.gin, plus each folder's experiment_config.yml."""
+    import re
+
+    import yaml
+
+    base = os.path.join(ref_env.REFERENCE, "colosseum", "benchmark")
+    line = re.compile(r"^\s*(prms_\d+)/(\w+)\.(\w+)\s*=\s*(.+?)\s*$")
+    import ast
+
+    out = {}
+    for folder in sorted(os.listdir(base)):
+        d = os.path.join(base, folder, "mdp_configs")
+        if not folder.startswith("benchmark_") or not os.path.isdir(d):
+            continue
+        cfg = {}
+        for f in sorted(os.listdir(d)):
+            cls = f[:-4]
+            if cls not in CLASSES:
+                continue
+            for ln in open(os.path.join(d, f)).read().splitlines():
+                m = line.match(ln)
+                if m:
+                    scope, c, k, v = m.groups()
+                    cfg.setdefault(c, {}).setdefault(scope, {})[k] = ast.literal_eval(v)
+        ec = os.path.join(base, folder, "experiment_config.yml")
+        if not os.path.exists(ec):  # the four default benchmarks share benchmark/experiment_config.yml
+            ec = os.path.join(base, "experiment_config.yml")
+        out[folder] = dict(mdp_configs=cfg, experiment_config=yaml.safe_load(open(ec)))
+        print("   ", folder, {c: len(s) for c, s in cfg.items()})
+    with open(os.path.join(OUT, "G11_benchmark_configs.json"), "w") as f:
+        json.dump(out, f, indent=0)
+
+
+GROUPS = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

@@ -62,6 +62,7 @@ def test_device_qlearning_reproduces_reference_run(need_gpu):
         seed = kw.pop("seed")
         ag = BatchedQLearningEpisodic(env, [seed], **kw)
         n_train = c["n_updates"]
+        assert n_train <= c["T"]
         a1 = ag.run(n_train, train=True, trace_actions=True)["actions"][:, 0]
         Q, N = ag.tables()
         np.testing.assert_array_equal(N[0], np.asarray(c["N_final"], np.int32))
