@@ -23,6 +23,7 @@ class BatchedQLearningEpisodic:
         self._h = C.c_void_p()
         L.check(self._lib.cmdp_qlearning_create(C.byref(self._h), env._h, L.ptr(seeds), int(optimization_horizon), float(p),
                                                 float(c_1), float(c_2 or 0.0), float(min_at), ucb))
+        env._register_agent(self)
 
     def run(self, n_steps: int, train=True, trace_actions: bool = False):
         """n_steps of select_action -> step -> step_update per instance.  `train`: bool or per-instance mask.
@@ -54,7 +55,7 @@ class BatchedQLearningEpisodic:
         return qs, ns
 
     def close(self):
-        if self._h is not None and self._h.value:
+        if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.cmdp_qlearning_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -78,6 +79,7 @@ class BatchedQLearningContinuous(BatchedQLearningEpisodic):
         L.check(self._lib.cmdp_qlearning_continuous_create(C.byref(self._h), env._h, L.ptr(seeds), int(optimization_horizon),
                                                            float(min_at), float(confidence), float(span_approx_weight),
                                                            float(h_weight)))
+        env._register_agent(self)
 
     def tables(self):
         env = self.env

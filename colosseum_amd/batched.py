@@ -104,7 +104,20 @@ class BatchedMDP:
         self._lib = lib
 
     # -- life cycle --------------------------------------------------------------------------------------
+    def _register_agent(self, agent):
+        import weakref
+
+        if not hasattr(self, "_agents"):
+            self._agents = []
+        self._agents.append(weakref.ref(agent))
+
     def close(self):
+        # agents hold device state tied to this handle's stream: they go first
+        for ref in getattr(self, "_agents", []):
+            a = ref()
+            if a is not None:
+                a.close()
+        self._agents = []
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.cmdp_destroy(self._h)
             self._h = C.c_void_p()

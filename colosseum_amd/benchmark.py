@@ -95,6 +95,21 @@ def enumerate_instances(mdp_configs: Dict[str, Dict[str, Dict[str, Any]]], n_see
     return out
 
 
+def _build_one(ins: Instance):
+    return make_model(ins.mdp_cls, seed=ins.seed, **ins.mdp_kwargs)
+
+
+def _build_models(instances: Sequence[Instance], workers: int):
+    """Host-side graph construction (Python) for many instances; a fork()ed pool must be used BEFORE the HIP runtime is
+    initialised in this process, so `workers > 0` is only honoured then (the caller's responsibility)."""
+    if workers and workers > 1 and len(instances) >= 4 * workers:
+        import multiprocessing as mp
+
+        with mp.get_context("fork").Pool(workers) as pool:
+            return pool.map(_build_one, instances, chunksize=max(1, len(instances) // (workers * 8)))
+    return [_build_one(i) for i in instances]
+
+
 def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_mode, device):
     L.check(L.load().cmdp_set_device(device))
     stochastic = any(not m.deterministic_rewards for m in models)
@@ -115,25 +130,39 @@ def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_m
 
 def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, rank: int = 0, world: int = 1,
                   agent_configs: Optional[Dict[str, Dict[str, Any]]] = None, rng_mode: int = L.RNG_MT_COMPAT,
-                  device: int = 0, max_concurrent_groups: int = 4):
+                  device: int = 0, max_concurrent_groups: int = 1, build_workers: int = 0, progress=None):
     """Runs this rank's contiguous shard; returns {global instance index: logger rows}."""
     agent_configs = agent_configs or DEFAULT_AGENT_CONFIGS
     lo, hi = shard_range(len(instances), rank, world)
     mine = list(range(lo, hi))
-    models = {i: make_model(instances[i].mdp_cls, seed=instances[i].seed, **instances[i].mdp_kwargs) for i in mine}
+    models = _build_models([instances[i] for i in mine], build_workers)
+    models = dict(zip(mine, models))
     groups: Dict[tuple, List[int]] = {}
+    from .hardness import _vi_rule
+
     for i in mine:
         m = models[i]
-        groups.setdefault((instances[i].mdp_cls, m.H, m.n_actions, tuple(m.rewards_range)), []).append(i)
+        # continuous baselines use discounted VI under the reference's own scheme rule, which depends on the instance's
+        # size and density: one scheme per device batch
+        scheme = 0 if m.is_episodic else _vi_rule(m.n_states, m.n_actions, len(m.csr()[1]))
+        groups.setdefault((instances[i].mdp_cls, m.H, m.n_actions, tuple(m.rewards_range), scheme), []).append(i)
     results: Dict[int, list] = {}
 
     def work(idx):
+        import time
+
         ins = instances[idx[0]]
+        t0 = time.time()
         rows = _run_group([models[i] for i in idx], [instances[i].seed for i in idx], ins.agent_cls,
                           agent_configs[ins.agent_cls], n_steps, log_every, rng_mode, device)
+        if progress:
+            progress(f"{ins.label}: {len(idx)} instances, S={models[idx[0]].n_states}, H={models[idx[0]].H}, "
+                     f"{time.time() - t0:.1f} s")
         return idx, rows
 
-    # every group owns a handle with its own HIP stream; the C calls release the GIL, so groups overlap on the device
+    # Groups run one after the other by default: a group of 20 instances x 200 000 steps takes 0.6-1.5 s alone, while four
+    # host threads driving four handles concurrently were measured 10-100x SLOWER (every small synchronous copy of one
+    # handle ends up waiting behind the other handles' long kernels).  max_concurrent_groups > 1 is kept for experiments.
     with ThreadPoolExecutor(max_workers=max(1, max_concurrent_groups)) as pool:
         for idx, rows in pool.map(work, list(groups.values())):
             for i, r in zip(idx, rows):

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -38,15 +40,24 @@ int fail(int code, const char* fmt, ...) {
 constexpr int kLdsBudget = 160 * 1024;  // bytes of LDS one workgroup may claim on gfx950
 constexpr int kDpBlock = 256;
 
+// Device buffer that only grows: hipFree (and often hipMalloc) synchronises the WHOLE device, which would serialise
+// handles that run concurrently on their own streams (benchmark runner: one host thread per device batch), so steady-state
+// calls must not allocate.
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
-  size_t n = 0;
+  size_t n = 0;    // logical size of the current contents
+  size_t cap = 0;  // allocated elements
   hipError_t alloc(size_t count) {
+    if (count <= cap) {
+      n = count;
+      return hipSuccess;
+    }
     release();
-    n = count;
     if (count == 0) return hipSuccess;
-    return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e == hipSuccess) { n = count; cap = count; }
+    return e;
   }
   hipError_t upload(const T* src, size_t count, hipStream_t s) {
     hipError_t e = alloc(count);
@@ -58,6 +69,7 @@ struct DevBuf {
     if (p) (void)hipFree(p);
     p = nullptr;
     n = 0;
+    cap = 0;
   }
   ~DevBuf() { release(); }
 };
@@ -100,6 +112,8 @@ struct cmdp {
   int rollout_kernel = 0;  // CMDP_OPT_ROLLOUT_KERNEL
   LdsPlan lds_plan{};
   size_t lds_bytes = 0;
+  DevBuf<float> d_gp_q, d_gp_p;  // cmdp_greedy_policy_episodic workspace
+  DevBuf<uint32_t> d_gp_mt;
   DevBuf<float> d_dense;  // CMDP_LAYOUT_DENSE: [R][dense_spad]
   int dense_spad = 0;
   DevBuf<uint16_t> d_next16;
@@ -1238,8 +1252,8 @@ int cmdp_greedy_policy_episodic(cmdp_t* h, int H, int q_layers, const float* Q, 
   if (int rc = bind(h)) return rc;
   if (!Q || !pi || H < 1 || q_layers < H) return fail(CMDP_ERR_INVALID, "bad argument");
   hipStream_t st = h->stream;
-  DevBuf<float> d_q, d_p;
-  DevBuf<uint32_t> d_mt;
+  DevBuf<float>&d_q = h->d_gp_q, &d_p = h->d_gp_p;
+  DevBuf<uint32_t>& d_mt = h->d_gp_mt;
   HIP_TRY(d_q.upload(Q, (size_t)q_layers * h->n_rows, st));
   HIP_TRY(d_p.alloc((size_t)H * h->n_rows));
   HIP_TRY(d_mt.alloc((size_t)h->B * 624));
@@ -1276,10 +1290,23 @@ int cmdp_gth(int count, const int32_t* dims, const double* mats, double* out) {
     mt += (int64_t)dims[m] * dims[m];
     xt += dims[m];
   }
-  DevBuf<int64_t> d_moff, d_xoff;
-  DevBuf<int32_t> d_dims;
-  DevBuf<double> d_mats, d_x;
-  hipStream_t st = nullptr;  // the device's default stream: this entry point has no handle
+  // Workspace that is reused across calls (no per-call hipMalloc/hipFree: both synchronise the device) and deliberately
+  // leaked at exit; calls are serialised by a mutex.  One workspace per device.
+  struct Ws { DevBuf<int64_t> moff, xoff; DevBuf<int32_t> dims; DevBuf<double> mats, x; hipStream_t st = nullptr; };
+  static std::mutex mu;
+  static std::map<int, Ws*>* all = new std::map<int, Ws*>;
+  std::lock_guard<std::mutex> lock(mu);
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  Ws*& ws = (*all)[dev];
+  if (!ws) {
+    ws = new Ws;
+    HIP_TRY(hipStreamCreateWithFlags(&ws->st, hipStreamNonBlocking));
+  }
+  DevBuf<int64_t>&d_moff = ws->moff, &d_xoff = ws->xoff;
+  DevBuf<int32_t>& d_dims = ws->dims;
+  DevBuf<double>&d_mats = ws->mats, &d_x = ws->x;
+  hipStream_t st = ws->st;
   HIP_TRY(d_moff.upload(moff.data(), count, st));
   HIP_TRY(d_xoff.upload(xoff.data(), count, st));
   HIP_TRY(d_dims.upload(dims, count, st));
@@ -1287,7 +1314,8 @@ int cmdp_gth(int count, const int32_t* dims, const double* mats, double* out) {
   HIP_TRY(d_x.alloc((size_t)xt));
   hipLaunchKernelGGL(k_gth, dim3(count), dim3(256), 0, st, d_moff.p, d_dims.p, d_xoff.p, d_mats.p, d_x.p);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(out, d_x.p, sizeof(double) * (size_t)xt, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(out, d_x.p, sizeof(double) * (size_t)xt, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   return CMDP_OK;
 }
 

@@ -21,7 +21,9 @@ from colosseum_amd.sharding import gather_instances, shard_range  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--folder", required=True)
+    ap.add_argument("--folder", help="benchmark folder laid out like the reference's (mdp_configs/*.gin, experiment_config.yml)")
+    ap.add_argument("--configs-json", help="alternative: JSON of benchmark definitions (tests/golden/G11_benchmark_configs.json)")
+    ap.add_argument("--benchmark", action="append", help="with --configs-json: benchmark name(s), e.g. benchmark_episodic_ergodic")
     ap.add_argument("--out", required=True)
     ap.add_argument("--steps", type=int)
     ap.add_argument("--seeds", type=int)
@@ -29,20 +31,33 @@ def main():
     args = ap.parse_args()
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
     dist = None
+    if args.folder:
+        cfg = yaml.safe_load(open(os.path.join(args.folder, "experiment_config.yml")))
+        benchmarks = [bm.load_mdp_configs(args.folder)]
+    else:
+        allcfg = json.load(open(args.configs_json))
+        cfg = allcfg[args.benchmark[0]]["experiment_config"]
+        benchmarks = [allcfg[b]["mdp_configs"] for b in args.benchmark]
+    n_steps = args.steps or cfg["n_steps"]
+    n_seeds = args.seeds or cfg["n_seeds"]
+    log_every = args.log_every or cfg["log_performance_indicators_every"]
+    instances = []
+    for k, mdp_cfg in enumerate(benchmarks):
+        for ins in bm.enumerate_instances(mdp_cfg, n_seeds):
+            ins.mdp_scope = f"b{k}_{ins.mdp_scope}" if len(benchmarks) > 1 else ins.mdp_scope
+            instances.append(ins)
+    t0 = time.time()
+    # NOTE: run_instances builds the models with a fork()ed pool first; RCCL / HIP are initialised only afterwards
+    results = bm.run_instances(instances, n_steps, log_every, rank, world, device=local,
+                               build_workers=max(1, min(16, (os.cpu_count() or 1) // world)),
+                               progress=lambda msg: print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True))
+    bm.write_csv_logs(args.out, instances, results)
     if world > 1:
         import torch
         import torch.distributed as dist
 
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    cfg = yaml.safe_load(open(os.path.join(args.folder, "experiment_config.yml")))
-    n_steps = args.steps or cfg["n_steps"]
-    n_seeds = args.seeds or cfg["n_seeds"]
-    log_every = args.log_every or cfg["log_performance_indicators_every"]
-    instances = bm.enumerate_instances(bm.load_mdp_configs(args.folder), n_seeds)
-    t0 = time.time()
-    results = bm.run_instances(instances, n_steps, log_every, rank, world, device=local)
-    bm.write_csv_logs(args.out, instances, results)
     lo, hi = shard_range(len(instances), rank, world)
     local_vec = np.stack([bm.summary_vector(results[i]) for i in range(lo, hi)]) if hi > lo else np.zeros((0, 3))
     allv = gather_instances(local_vec, len(instances), dist, device="cuda" if dist is not None else None)
