@@ -172,11 +172,19 @@ def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, r
 
 def write_csv_logs(folder: str, instances: Sequence[Instance], results: Dict[int, list]):
     """The reference's on-disk wire format (CSVLogger with add_uid=False; header = sorted keys)."""
+    from .experiment.vector_tracker import LogTable
+
+    text = {}  # BatchLog -> its columns as text, converted once per device batch
     for i, rows in results.items():
         ins = instances[i]
         d = os.path.join(folder, "logs", ins.label)
         os.makedirs(d, exist_ok=True)
         with open(os.path.join(d, f"seed{ins.seed}_logs.csv"), "w", newline="") as f:
+            if isinstance(rows, LogTable):
+                if id(rows.log) not in text:
+                    text[id(rows.log)] = rows.log.text_columns()
+                f.write(rows.log.csv_text(rows.b, text[id(rows.log)]))
+                continue
             fields = sorted(rows[0].keys())
             w = csv.DictWriter(f, fieldnames=fields, extrasaction="ignore")
             w.writeheader()

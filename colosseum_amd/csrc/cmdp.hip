@@ -113,7 +113,6 @@ struct cmdp {
   LdsPlan lds_plan{};
   size_t lds_bytes = 0;
   DevBuf<float> d_gp_q, d_gp_p;  // cmdp_greedy_policy_episodic workspace
-  DevBuf<uint32_t> d_gp_mt;
   DevBuf<float> d_dense;  // CMDP_LAYOUT_DENSE: [R][dense_spad]
   int dense_spad = 0;
   DevBuf<uint16_t> d_next16;
@@ -1023,7 +1022,7 @@ struct cmdp_agent {
   DevBuf<double> d_rsum;   // MDPLoop._cumulative_reward per instance
   DevBuf<uint8_t> d_mask;
   DevBuf<float> d_pi;      // greedy policy [H][S][A]
-  DevBuf<uint32_t> d_mt42; // scratch streams of the tie-break
+  DevBuf<float> d_v0;      // packed V[0, :] of the evaluated greedy policies
   int64_t n_q = 0, n_v = 0;
 };
 
@@ -1165,9 +1164,8 @@ int cmdp_qlearning_policy(cmdp_agent_t* a, float* pi) {
   if (!a->continuous) return fail(CMDP_ERR_INVALID, "cmdp_qlearning_policy is for the continuous agent; use cmdp_qlearning_evaluate");
   hipStream_t st = h->stream;
   if (a->d_pi.n < (size_t)a->n_q) HIP_TRY(a->d_pi.alloc(a->n_q));
-  if (a->d_mt42.n < (size_t)h->B * 624) HIP_TRY(a->d_mt42.alloc((size_t)h->B * 624));
-  hipLaunchKernelGGL(k_greedy_policy_episodic<double>, dim3(grid_for(h->B, 64)), dim3(64), 0, st, h->B, h->A, 1, 1,
-                     h->d_state_off.p, a->d_Qc.p, a->d_pi.p, a->d_mt42.p);
+  hipLaunchKernelGGL(k_greedy_policy_episodic<double>, dim3(h->B), dim3(64), 0, st, h->B, h->A, 1, 1,
+                     h->d_state_off.p, a->d_Qc.p, a->d_pi.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(pi, a->d_pi.p, sizeof(float) * a->n_q, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
@@ -1226,9 +1224,8 @@ int cmdp_qlearning_evaluate(cmdp_agent_t* a, float* V0) {
   const size_t lds = 2 * sizeof(float) * (size_t)h->max_S;
   if (lds > (size_t)kLdsBudget) return fail(CMDP_ERR_UNSUPPORTED, "instance with %d states does not fit LDS", h->max_S);
   if (a->d_pi.n < (size_t)a->n_q) HIP_TRY(a->d_pi.alloc(a->n_q));
-  if (a->d_mt42.n < (size_t)h->B * 624) HIP_TRY(a->d_mt42.alloc((size_t)h->B * 624));
-  hipLaunchKernelGGL(k_greedy_policy_episodic<float>, dim3(grid_for(h->B, 64)), dim3(64), 0, st, h->B, h->A, H, H,
-                     h->d_state_off.p, a->d_Q.p, a->d_pi.p, a->d_mt42.p);
+  hipLaunchKernelGGL(k_greedy_policy_episodic<float>, dim3(h->B), dim3(64), 0, st, h->B, h->A, H, H,
+                     h->d_state_off.p, a->d_Q.p, a->d_pi.p);
   const size_t nq = (size_t)(H + 1) * h->n_rows, nv = (size_t)(H + 1) * h->n_states;
   if (h->d_Q.n < nq) HIP_TRY(h->d_Q.alloc(nq));
   if (h->d_V.n < nv) HIP_TRY(h->d_V.alloc(nv));
@@ -1239,11 +1236,11 @@ int cmdp_qlearning_evaluate(cmdp_agent_t* a, float* V0) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_episodic<DP_PE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((k_episodic<DP_PE>), dim3(h->B), dim3(kDpBlock), lds, st, t, H, h->d_Q.p, h->d_V.p);
   HIP_TRY(hipGetLastError());
-  // V[0, :] of instance b sits at (H+1)*state_off[b]
-  for (int b = 0; b < h->B; ++b) {
-    const int64_t so = h->state_off[b], S = h->state_off[b + 1] - so;
-    HIP_TRY(hipMemcpyAsync(V0 + so, h->d_V.p + (size_t)(H + 1) * so, sizeof(float) * S, hipMemcpyDeviceToHost, st));
-  }
+  // V[0, :] of instance b sits at (H+1)*state_off[b]: pack, then one copy
+  if (a->d_v0.n < (size_t)h->n_states) HIP_TRY(a->d_v0.alloc(h->n_states));
+  hipLaunchKernelGGL(k_gather_v0, dim3(h->B), dim3(256), 0, st, h->B, H, h->d_state_off.p, h->d_V.p, a->d_v0.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(V0, a->d_v0.p, sizeof(float) * (size_t)h->n_states, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   return CMDP_OK;
 }
@@ -1253,12 +1250,10 @@ int cmdp_greedy_policy_episodic(cmdp_t* h, int H, int q_layers, const float* Q, 
   if (!Q || !pi || H < 1 || q_layers < H) return fail(CMDP_ERR_INVALID, "bad argument");
   hipStream_t st = h->stream;
   DevBuf<float>&d_q = h->d_gp_q, &d_p = h->d_gp_p;
-  DevBuf<uint32_t>& d_mt = h->d_gp_mt;
   HIP_TRY(d_q.upload(Q, (size_t)q_layers * h->n_rows, st));
   HIP_TRY(d_p.alloc((size_t)H * h->n_rows));
-  HIP_TRY(d_mt.alloc((size_t)h->B * 624));
-  hipLaunchKernelGGL(k_greedy_policy_episodic<float>, dim3(grid_for(h->B, 64)), dim3(64), 0, st, h->B, h->A, H, q_layers,
-                     h->d_state_off.p, d_q.p, d_p.p, d_mt.p);
+  hipLaunchKernelGGL(k_greedy_policy_episodic<float>, dim3(h->B), dim3(64), 0, st, h->B, h->A, H, q_layers,
+                     h->d_state_off.p, d_q.p, d_p.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(pi, d_p.p, sizeof(float) * (size_t)H * h->n_rows, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));

@@ -157,43 +157,121 @@ __global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, 
 
 // argmax_3d (reference colosseum/dynamic_programming/utils.py:28-39): one-hot greedy policy of Q[layers >= H][S][A]
 // with ties broken by `np.random.seed(42); np.random.choice(ties)` -- one numpy MT19937(42) stream per table, rows in
-// (h, s) order, a draw only where there is a tie.  One lane per instance; `mt` is scratch [B][624].
+// (h, s) order, a draw only where there is a tie (rejection sampling under the smallest covering bit mask).
+//
+// One WAVE per instance.  The maxima and tie counts of 64 rows are computed lane-parallel from coalesced row loads;
+// MT19937 is advanced a whole 624-word block at a time by the wave (three dependency-free segments) and tempered into
+// LDS; only the consumption of the stream is sequential, and it runs on wave-uniform values: the tied rows of the
+// chunk come from a ballot, their tie counts and the stream words from v_readlane of a 64-word register window.
+struct Mt42Init {
+  uint32_t w[624];
+  constexpr Mt42Init() : w{} {
+    w[0] = 42u;
+    for (int k = 1; k < 624; ++k) w[k] = 1812433253u * (w[k - 1] ^ (w[k - 1] >> 30)) + (uint32_t)k;
+  }
+};
+__constant__ const Mt42Init kMt42 = Mt42Init();
+
+__device__ __forceinline__ uint32_t mt_twist(uint32_t cur, uint32_t nxt, uint32_t far) {
+  const uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
+  return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// next block of 624 outputs: mt[i] <- twist(mt[i], mt[i+1], mt[i+397 mod 624]) in sequential order.  Passes of 64
+// consecutive words are dependency-free: word i needs the OLD mt[i+1] (same pass, read before written, or a later
+// pass), the OLD mt[i+397] for i < 227 (a later pass) and the NEW mt[i-227] for i >= 227 (an earlier pass); i = 623
+// wraps to the new mt[0].  One wave, LDS operations in program order.
+__device__ __forceinline__ void mt_block(uint32_t* mt, uint32_t* out, int lane) {
+  for (int base = 0; base < 624; base += 64) {
+    const int i = base + lane;
+    const bool on = i < 624;
+    uint32_t v = 0;
+    if (on) v = mt_twist(mt[i], mt[i == 623 ? 0 : i + 1], mt[i < 227 ? i + 397 : i - 227]);
+    __builtin_amdgcn_wave_barrier();
+    if (on) mt[i] = v;
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int i = lane; i < 624; i += 64) {
+    uint32_t v = mt[i];
+    v ^= v >> 11;
+    v ^= (v << 7) & 0x9d2c5680u;
+    v ^= (v << 15) & 0xefc60000u;
+    v ^= v >> 18;
+    out[i] = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <typename QT>
 __global__ void __launch_bounds__(64) k_greedy_policy_episodic(int B, int A, int H, int q_layers,
                                                               const int64_t* __restrict__ state_off,
-                                                              const QT* __restrict__ Q, float* __restrict__ pi,
-                                                              uint32_t* __restrict__ mt_all) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+                                                              const QT* __restrict__ Q, float* __restrict__ pi) {
+  __shared__ uint32_t mt[624];
+  __shared__ uint32_t out[624 + 64];  // padded: a 64-word window read may start at any position < 624
+  const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= B) return;
   const int64_t soff = state_off[b];
   const int S = (int)(state_off[b + 1] - soff);
   const QT* q = Q + (int64_t)q_layers * soff * A;
   float* p = pi + (int64_t)H * soff * A;
-  uint32_t* mt = mt_all + (int64_t)b * 624;
-  mt[0] = 42u;
-  for (int k = 1; k < 624; ++k) mt[k] = 1812433253u * (mt[k - 1] ^ (mt[k - 1] >> 30)) + (uint32_t)k;
-  int pos = 0;
-  for (int64_t r = 0; r < (int64_t)H * S; ++r) {
+  for (int i = lane; i < 624; i += 64) mt[i] = kMt42.w[i];
+  out[624 + lane] = 0u;
+  __builtin_amdgcn_wave_barrier();
+  int pos = 624, wbase = -1;  // wave-uniform: stream position inside the block, first word held by the window
+  uint32_t win = 0;
+  const int64_t nrows = (int64_t)H * S;
+  for (int64_t r0 = 0; r0 < nrows; r0 += 64) {
+    const int64_t r = r0 + lane;
+    const bool valid = r < nrows;
     const QT* row = q + r * A;
-    QT m = row[0];
-    for (int a = 1; a < A; ++a) m = (row[a] > m) ? row[a] : m;
     int n_tie = 0;
-    for (int a = 0; a < A; ++a) n_tie += (row[a] == m) ? 1 : 0;
+    QT m = 0;
+    if (valid) {
+      m = row[0];
+      for (int a = 1; a < A; ++a) m = (row[a] > m) ? row[a] : m;
+      for (int a = 0; a < A; ++a) n_tie += (row[a] == m) ? 1 : 0;
+    }
     int pick = 0;
-    if (n_tie > 1) {
-      const uint32_t mx = (uint32_t)(n_tie - 1);
+    unsigned long long need = __ballot(n_tie > 1);
+    while (need) {
+      const int i = __ffsll((long long)need) - 1;
+      need &= need - 1;
+      const uint32_t mx = (uint32_t)__builtin_amdgcn_readlane(n_tie, i) - 1u;
       uint32_t mask = mx;
       mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
       uint32_t v;
-      do { v = mt_next_word(mt, pos) & mask; } while (v > mx);
-      pick = (int)v;
+      do {
+        if (pos == 624) {
+          mt_block(mt, out, lane);
+          pos = 0;
+          wbase = -1;
+        }
+        if (wbase < 0 || pos - wbase >= 64) {
+          wbase = pos;
+          win = out[wbase + lane];
+        }
+        v = (uint32_t)__builtin_amdgcn_readlane((int)win, pos - wbase) & mask;
+        ++pos;
+      } while (v > mx);
+      if (lane == i) pick = (int)v;
     }
-    for (int a = 0, k = 0; a < A; ++a) {
-      const bool tie = row[a] == m;
-      p[r * A + a] = (tie && k == pick) ? 1.0f : 0.0f;
-      k += tie ? 1 : 0;
+    if (valid) {
+      for (int a = 0, k = 0; a < A; ++a) {
+        const bool tie = row[a] == m;
+        p[r * A + a] = (tie && k == pick) ? 1.0f : 0.0f;
+        k += tie ? 1 : 0;
+      }
     }
   }
+}
+
+// V[0, :] of every instance (row 0 of its [H+1][S_b] block) packed contiguously for one device-to-host copy
+__global__ void __launch_bounds__(256) k_gather_v0(int B, int H, const int64_t* __restrict__ state_off,
+                                                   const float* __restrict__ V, float* __restrict__ V0) {
+  const int b = blockIdx.x;
+  const int64_t so = state_off[b];
+  const int S = (int)(state_off[b + 1] - so);
+  for (int s = threadIdx.x; s < S; s += blockDim.x) V0[so + s] = V[(int64_t)(H + 1) * so + s];
 }
 
 

@@ -14,6 +14,7 @@ import numpy as np
 from ..agents import BatchedQLearningEpisodic
 from ..batched import BatchedMDP
 from .mdp_loop import InMemoryLogger, MDPLoop
+from .vector_tracker import MP, ContinuousVectorTracker, EpisodicVectorTracker
 
 
 class _InstanceView:
@@ -67,10 +68,14 @@ class _Tracker(MDPLoop):
 
 
 class BatchedEpisodicLoop:
+    """`vectorized=True` (default): indicators of all instances per numpy call (vector_tracker.py); False: one scalar
+    tracker object per instance running MDPLoop's own indicator code (slow; kept as the cross-check)."""
+
     def __init__(self, env: BatchedMDP, agent: BatchedQLearningEpisodic,
-                 n_log_intervals_to_check_for_agent_optimality: int = 10):
+                 n_log_intervals_to_check_for_agent_optimality: int = 10, vectorized: bool = True):
         assert env.H > 0 and env.models is not None
         self.env, self.agent = env, agent
+        self.vectorized = vectorized
         H, A = env.H, env.A
         # baselines of every instance, batched: optimal values, worst policy values, uniform policy values
         Q, V = env.episodic_value_iteration()
@@ -79,6 +84,12 @@ class BatchedEpisodicLoop:
         _, Vw = env.episodic_policy_evaluation(pi_w)
         _, Vr = env.episodic_policy_evaluation([np.ones((H, m.n_states, A), np.float32) / A for m in env.models])
         self.trackers: List[_Tracker] = []
+        if vectorized:
+            flat0 = [np.concatenate([env.split_states(x, H + 1)[b][:m.n_states] for b, m in enumerate(env.models)])
+                     for x in (V, Vw, Vr)]
+            self.vt = EpisodicVectorTracker(H, env.state_off, *flat0, [(m.start_states, m.start_probs) for m in env.models],
+                                            n_log_intervals_to_check_for_agent_optimality)
+            return
         for b, m in enumerate(env.models):
             S = m.n_states
             v0 = [env.split_states(x, H + 1)[b][:S] for x in (V, Vw, Vr)]
@@ -92,6 +103,10 @@ class BatchedEpisodicLoop:
         last_start = self.env.last_start()
         prev_start = self.env.previous_start
         hstep = self.env.state()[1]
+        if self.vectorized:
+            start = np.where((hstep == 0) & in_loop, prev_start, last_start)
+            self.vt.update(t, T, V0, start, cum, n_since, in_loop)
+            return
         for b, tr in enumerate(self.trackers):
             # the reference logs step t before the reset that follows a termination: if step t ended an episode
             # (in-episode time back at 0), its `last_starting_node` is still the start of the episode that ended
@@ -110,6 +125,8 @@ class BatchedEpisodicLoop:
 
     def run(self, T: int, log_every: int = -1) -> List[List[Dict[str, float]]]:
         env, agent = self.env, self.agent
+        if self.vectorized:
+            self.vt.reset()
         for tr in self.trackers:
             tr._reset_run_variables()
         env.reset_visits()
@@ -127,13 +144,13 @@ class BatchedEpisodicLoop:
             agent.run(1, train=mask)
             done = tl + 1
             self._log(tl, cum, n_since, T, in_loop=True)
-            mask = np.array([tr._is_training for tr in self.trackers])
+            mask = self.vt.is_training.copy() if self.vectorized else np.array([tr._is_training for tr in self.trackers])
             n_since = 1
         if T - done > 0:
             n_since += T - done
         cum = agent.run(T - done, train=mask)["cumulative_reward"]
         self._log(T - 1, cum, n_since, T, in_loop=False)
-        return [tr.logger.data for tr in self.trackers]
+        return self.vt.tables() if self.vectorized else [tr.logger.data for tr in self.trackers]
 
 
 class _ContinuousView:
@@ -165,12 +182,14 @@ class BatchedContinuousLoop:
     regrets from the stationary distributions of the agents' greedy policies (host class bookkeeping, one batched GTH
     call per logging step)."""
 
-    def __init__(self, env: BatchedMDP, agent, n_log_intervals_to_check_for_agent_optimality: int = 10):
+    def __init__(self, env: BatchedMDP, agent, n_log_intervals_to_check_for_agent_optimality: int = 10,
+                 vectorized: bool = True):
         from ..dynamic_programming import get_policy_from_q_values
-        from ..markov_chain import get_average_reward_batch
+        from ..markov_chain import AverageRewardCache, get_average_reward_batch
 
         assert env.H == 0 and env.models is not None
         self.env, self.agent = env, agent
+        self.vectorized = vectorized
         self._batch = get_average_reward_batch
         A = env.A
         self._TR = [m.dense() for m in env.models]
@@ -188,6 +207,11 @@ class BatchedContinuousLoop:
             probs += [(T, R, pi_o, starts), (T, R, pi_w, starts), (T, R, pi_r, None)]
         vals = self._batch(probs)
         self.trackers = []
+        if vectorized:
+            self.cache = AverageRewardCache(self._TR)
+            self.vt = ContinuousVectorTracker(*(MP.from_scalars(vals[j::3]) for j in range(3)),
+                                              n_log_intervals_to_check_for_agent_optimality)
+            return
         for b, m in enumerate(env.models):
             # `sum(sd * ars)` of the reference is a left-to-right Python sum; the batched helper uses ndarray.sum --
             # the difference is below 1e-15 relative and far below the 5-decimal rounding of the logger
@@ -195,6 +219,14 @@ class BatchedContinuousLoop:
             self.trackers.append(_ContinuousTracker(view, n_log_intervals_to_check_for_agent_optimality))
 
     def _log(self, t, cum, n_since, T, in_loop):
+        if self.vectorized:
+            def averages(need):
+                policies = self.agent.policy()
+                cur, _, _ = self.env.state()
+                return self.cache(need, policies, cur)
+
+            self.vt.update(t, T, averages, cum, n_since, in_loop)
+            return
         policies = self.agent.policy()
         cur, _, _ = self.env.state()
         avgs = self._batch([(self._TR[b][0], self._TR[b][1], policies[b], [(int(cur[b]), 1.0)]) for b in range(self.env.B)])

@@ -136,3 +136,92 @@ def get_average_reward(T: np.ndarray, R: np.ndarray, policy: np.ndarray, next_st
     tps = get_transition_probabilities(T, policy)
     sd = get_stationary_distribution(tps, next_states_and_probs)
     return (average_rewards * sd).sum()
+
+
+class AverageRewardCache:
+    """`get_average_reward(T, R, policy, [(current state, 1.0)])` for the B instances of a batch at every logging step
+    of the continuous loop, memoised per instance on the policy: late in a run the greedy policy of a Q-learning agent
+    changes rarely, and a chain with one recurrent class gives the same value from every state.
+
+    Per new policy: the chain (rows of one-hot policy states are plain gathers T[s, a(s), :] -- exactly what the einsum
+    of the reference produces for them), its recurrent classes, ONE batched GTH call for all missing classes of all
+    instances, and the average reward of every class.  Chains with several recurrent classes additionally memoise, per
+    current state, the first class (in class-list order) that state reaches."""
+
+    def __init__(self, TR: Sequence[Tuple[np.ndarray, np.ndarray]], max_entries: int = 4096):
+        self.TR = TR
+        self.max_entries = max_entries
+        self.memo: List[dict] = [dict() for _ in TR]
+        self.hits = self.misses = 0
+
+    @staticmethod
+    def _chain(T, R, policy):
+        onehot = (policy == 1).any(-1)
+        if onehot.all():
+            a = policy.argmax(-1)
+            idx = np.arange(len(policy))
+            return R[idx, a] * np.float32(1.0), np.minimum(1.0, T[idx, a])
+        return get_average_rewards(R, policy), get_transition_probabilities(T, policy)
+
+    def __call__(self, need: np.ndarray, policies: Sequence[np.ndarray], current: Sequence[int]) -> list:
+        todo, mats = [], []
+        for b in np.flatnonzero(need):
+            key = policies[b].tobytes()
+            e = self.memo[b].get(key)
+            if e is not None:
+                self.hits += 1
+                continue
+            self.misses += 1
+            T, R = self.TR[b]
+            policy = policies[b]
+            assert np.isclose(policy.sum(-1), 1).all(), "the policy specification is incorrect."
+            ars, tps = self._chain(T, R, policy)
+            n = len(tps)
+            classes = recurrent_classes(tps)
+            if len(classes) == 1:
+                mode = "sub" if len(classes[0]) < n else "all"
+            else:
+                mode = "multi"
+            slots = []
+            for cls in classes:
+                if len(cls) == 1:
+                    slots.append(None)
+                else:
+                    slots.append(len(mats))
+                    mats.append(tps[np.ix_(cls, cls)])
+            if len(self.memo[b]) >= self.max_entries:
+                self.memo[b].clear()
+            e = dict(mode=mode, classes=classes, graph=csr_matrix(tps > 0) if mode == "multi" else None, first={})
+            self.memo[b][key] = e
+            todo.append((e, ars, n, slots))
+        if todo:
+            sols = gth_batch(mats)
+            for e, ars, n, slots in todo:
+                vals = []
+                for cls, k in zip(e["classes"], slots):
+                    x = np.ones(1) if k is None else sols[k]
+                    if e["mode"] == "all":
+                        sd = x
+                    else:
+                        sd = np.zeros(n, np.float32 if e["mode"] == "sub" else np.float64)
+                        if e["mode"] == "sub":
+                            sd[cls] = x
+                        else:
+                            sd[cls] += 1.0 * x
+                    vals.append((ars * sd).sum())
+                e["values"] = vals
+        out = []
+        for b in np.flatnonzero(need):
+            e = self.memo[b][policies[b].tobytes()]
+            if e["mode"] != "multi":
+                out.append(e["values"][0])
+                continue
+            cur = int(current[b])
+            k = e["first"].get(cur)
+            if k is None:
+                reach = set(breadth_first_order(e["graph"], cur, directed=True, return_predecessors=False).tolist())
+                k = next((i for i, cls in enumerate(e["classes"]) if int(cls[0]) in reach), -1)
+                e["first"][cur] = k
+            # no class reached cannot happen in a finite chain; the reference would return an all-zero distribution
+            out.append(e["values"][k] if k >= 0 else np.float64(0.0))
+        return out
