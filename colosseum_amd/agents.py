@@ -91,6 +91,17 @@ class BatchedQLearningContinuous(BatchedQLearningEpisodic):
     def evaluate(self):
         raise NotImplementedError("use policy(): continuous regrets come from the stationary distribution")
 
+    def average_reward(self, mask=None) -> list:
+        """`get_average_reward` of the current greedy policies from the current states, on the device (kernel K9): a
+        list of numpy scalars (np.float32 where the reference's value is one) for the instances selected by `mask`."""
+        B = self.env.B
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        avg = np.zeros(B, np.float64)
+        kind = np.zeros(B, np.int32)
+        L.check(self._lib.cmdp_qlearning_average_reward(self._h, L.ptr(m), L.ptr(avg), L.ptr(kind)))
+        sel = range(B) if m is None else np.flatnonzero(m)
+        return [np.float32(avg[b]) if kind[b] else np.float64(avg[b]) for b in sel]
+
     def policy(self):
         """argmax_2d greedy policies (RandomState(42) tie-break), per instance [S, A]."""
         env = self.env

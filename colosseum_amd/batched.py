@@ -211,6 +211,21 @@ class BatchedMDP:
         self.previous_start = prev
         return out
 
+    def average_reward(self, actions, start_states, mask=None):
+        """`get_average_reward(T, R, one_hot(actions), [(start, 1.0)])` for every (continuous) instance on the device
+        (kernel K9).  actions: per-instance arrays [S_b] (or one flat array); returns (values, n_recurrent_classes) with
+        values a list of numpy scalars typed as the reference's results (np.float32 / np.float64)."""
+        acts = np.ascontiguousarray(np.concatenate([np.asarray(a).ravel() for a in actions])
+                                    if isinstance(actions, (list, tuple)) else actions, np.int32)
+        assert acts.size == self.state_off[-1]
+        st = np.ascontiguousarray(start_states, np.int32)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        avg = np.zeros(self.B, np.float64)
+        kind = np.zeros(self.B, np.int32)
+        ncls = np.zeros(self.B, np.int32)
+        L.check(self._lib.cmdp_average_reward(self._h, L.ptr(acts), L.ptr(st), L.ptr(m), L.ptr(avg), L.ptr(kind), L.ptr(ncls)))
+        return [np.float32(avg[b]) if kind[b] else np.float64(avg[b]) for b in range(self.B)], ncls
+
     # -- helpers ------------------------------------------------------------------------------------------
     def split_states(self, flat, lead: int = 1) -> List[np.ndarray]:
         return [flat[lead * self.state_off[b]: lead * self.state_off[b + 1]] for b in range(self.B)]

@@ -16,6 +16,7 @@
 
 #include "cmdp_kernels.h"
 #include "cmdp_agent.h"
+#include "cmdp_chain.h"
 
 namespace {
 
@@ -113,6 +114,11 @@ struct cmdp {
   LdsPlan lds_plan{};
   size_t lds_bytes = 0;
   DevBuf<float> d_gp_q, d_gp_p;  // cmdp_greedy_policy_episodic workspace
+  // cmdp_average_reward workspace (K9)
+  DevBuf<double> d_ch_work, d_ch_avg;
+  DevBuf<int64_t> d_ch_off;
+  DevBuf<int32_t> d_ch_kind, d_ch_ncls, d_ch_act, d_ch_start;
+  DevBuf<uint8_t> d_ch_mask;
   DevBuf<float> d_dense;  // CMDP_LAYOUT_DENSE: [R][dense_spad]
   int dense_spad = 0;
   DevBuf<uint16_t> d_next16;
@@ -1170,6 +1176,84 @@ int cmdp_qlearning_policy(cmdp_agent_t* a, float* pi) {
   HIP_TRY(hipMemcpyAsync(pi, a->d_pi.p, sizeof(float) * a->n_q, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   return CMDP_OK;
+}
+
+// K9 launch shared by cmdp_average_reward / cmdp_qlearning_average_reward: policy either as device one-hot rows
+// (`d_pi`) or device actions (`d_act`); start states on the device.
+static int chain_launch(cmdp_t* h, const float* d_pi, const int32_t* d_act, const int32_t* d_start, const uint8_t* mask,
+                        double* avg, int32_t* kind, int32_t* n_classes) {
+  if (!h->has_dp) return fail(CMDP_ERR_INVALID, "the handle was created without the DP half (CSR transition matrices)");
+  if (h->H != 0) return fail(CMDP_ERR_INVALID, "average rewards are defined for continuous instances (horizon 0)");
+  const size_t lds = chain_lds_bytes(h->max_S, h->max_row_nnz);
+  if (lds > (size_t)kLdsBudget)
+    return fail(CMDP_ERR_UNSUPPORTED, "instance with %d states (max %d successors per row) exceeds the LDS budget of K9",
+                h->max_S, h->max_row_nnz);
+  hipStream_t st = h->stream;
+  const int B = h->B;
+  if (h->d_ch_off.n < (size_t)B + 1) {
+    std::vector<int64_t> off(B + 1, 0);
+    for (int b = 0; b < B; ++b) {
+      const int64_t S = h->state_off[b + 1] - h->state_off[b];
+      off[b + 1] = off[b] + S * S;
+    }
+    HIP_TRY(h->d_ch_off.upload(off.data(), off.size(), st));
+    HIP_TRY(hipStreamSynchronize(st));  // `off` is a local
+    HIP_TRY(h->d_ch_work.alloc((size_t)off[B]));
+    HIP_TRY(h->d_ch_avg.alloc(B));
+    HIP_TRY(h->d_ch_kind.alloc(B));
+    HIP_TRY(h->d_ch_ncls.alloc(B));
+  }
+  const uint8_t* dmask = nullptr;
+  if (mask) {
+    HIP_TRY(h->d_ch_mask.upload(mask, B, st));
+    dmask = h->d_ch_mask.p;
+  }
+  ChainArgs c{};
+  c.B = B; c.A = h->A; c.max_deg = h->max_row_nnz;
+  c.state_off = h->d_state_off.p; c.csr_ptr = h->d_csr_ptr.p; c.csr_col = h->d_csr_col.p; c.csr_val = h->d_csr_val.p;
+  c.R = h->d_R.p; c.pi = d_pi; c.act = d_act; c.start = d_start; c.mask = dmask;
+  c.work_off = h->d_ch_off.p; c.work = h->d_ch_work.p; c.avg = h->d_ch_avg.p; c.kind = h->d_ch_kind.p;
+  c.n_classes = h->d_ch_ncls.p;
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_average_reward<4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_chain_average_reward<4>, dim3(B), dim3(256), lds, st, c);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(avg, h->d_ch_avg.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(kind, h->d_ch_kind.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+  if (n_classes) HIP_TRY(hipMemcpyAsync(n_classes, h->d_ch_ncls.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return CMDP_OK;
+}
+
+int cmdp_average_reward(cmdp_t* h, const int32_t* actions, const int32_t* start_states, const uint8_t* mask, double* avg,
+                        int32_t* kind, int32_t* n_classes) {
+  if (int rc = bind(h)) return rc;
+  if (!actions || !start_states || !avg || !kind) return fail(CMDP_ERR_INVALID, "null argument");
+  for (int b = 0; b < h->B; ++b) {
+    const int64_t S = h->state_off[b + 1] - h->state_off[b];
+    if (start_states[b] < 0 || start_states[b] >= S) return fail(CMDP_ERR_INVALID, "start state of instance %d out of range", b);
+    if (mask && !mask[b]) continue;
+    for (int64_t s = h->state_off[b]; s < h->state_off[b + 1]; ++s)
+      if (actions[s] < 0 || actions[s] >= h->A) return fail(CMDP_ERR_INVALID, "action of state %lld out of range", (long long)s);
+  }
+  hipStream_t st = h->stream;
+  HIP_TRY(h->d_ch_act.upload(actions, (size_t)h->n_states, st));
+  HIP_TRY(h->d_ch_start.upload(start_states, (size_t)h->B, st));
+  return chain_launch(h, nullptr, h->d_ch_act.p, h->d_ch_start.p, mask, avg, kind, n_classes);
+}
+
+int cmdp_qlearning_average_reward(cmdp_agent_t* a, const uint8_t* mask, double* avg, int32_t* kind) {
+  if (!a || !avg || !kind) return fail(CMDP_ERR_INVALID, "null argument");
+  cmdp_t* h = a->env;
+  if (int rc = bind(h)) return rc;
+  if (!a->continuous) return fail(CMDP_ERR_INVALID, "cmdp_qlearning_average_reward is for the continuous agent");
+  hipStream_t st = h->stream;
+  if (a->d_pi.n < (size_t)a->n_q) HIP_TRY(a->d_pi.alloc(a->n_q));
+  hipLaunchKernelGGL(k_greedy_policy_episodic<double>, dim3(h->B), dim3(64), 0, st, h->B, h->A, 1, 1,
+                     h->d_state_off.p, a->d_Qc.p, a->d_pi.p);
+  HIP_TRY(hipGetLastError());
+  return chain_launch(h, a->d_pi.p, nullptr, h->d_cur.p, mask, avg, kind, nullptr);
 }
 
 int cmdp_qlearning_destroy(cmdp_agent_t* a) {

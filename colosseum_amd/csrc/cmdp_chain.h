@@ -1,0 +1,393 @@
+// cmdp_chain.h -- K9: long-run average reward of a deterministic stationary policy from a given state, one
+// workgroup per instance (gfx950 / CDNA4 only).
+//
+// Reference: colosseum/mdp/utils/markov_chain.py:12-31 (`get_average_reward`), :64-136 (`get_stationary_distribution`)
+// and :139-166 (`_gth_solve_numba`), as called at every logging step of the continuous-setting loop
+// (colosseum/experiment/agent_mdp_interaction.py:518-532).  For a one-hot policy the chain is
+// tps[s, :] = min(1, T[s, a(s), :]), rewards ars[s] = R[s, a(s)].  The reference then
+//   1. lists the recurrent classes in networkx's `attracting_components` order;
+//   2. one class smaller than the chain  -> float32 distribution, zero outside the class          (kind F32)
+//      one class == the whole chain      -> float64 distribution                                   (kind F64)
+//      several classes                   -> float64, the FIRST class (list order) the start state reaches, weight 1;
+//   3. solves the class by GTH elimination in float64 and returns (ars * sd).sum() (numpy's pairwise summation).
+//
+// Phases of the kernel (LDS holds the adjacency and all index arrays; the dense class matrix is a float64 work
+// copy in HBM/L2):
+//   A  actions, out-degrees (wave scan), adjacency lists in column order                       -- all threads
+//   B  networkx's non-recursive Tarjan/Nuutila search, verbatim (sources in node order, neighbours in adjacency
+//      order), giving every state its component in EMISSION order                               -- one lane, LDS only
+//   C  components with an edge leaving them are transient; the others are the recurrent classes in list order;
+//      with several classes, forward reachability from the start state by frontier relaxation  -- all threads
+//   D  members of the chosen class in ascending state order (ballot compaction), dense matrix  -- all threads
+//   E  GTH: per pivot i the non-zeros of row i (wave 0) and column i (wave 1) are compacted in index order, the
+//      scale is their index-ordered sum (v_readlane chain: the reference's order without a serial memory walk),
+//      the rank-1 update touches |col| x |row| entries only -- adding the skipped zero products is exact, so the
+//      result is bit-identical to the dense elimination
+//   F  back-substitution, normalisation (index-ordered sums over the non-zero lanes), then the reward sum in
+//      numpy's pairwise order (float32 products for kind F32).
+#pragma once
+#include "cmdp_device.h"
+
+struct ChainArgs {
+  int32_t B, A, max_deg;
+  const int64_t* state_off;  // [B+1]
+  const int64_t* csr_ptr;    // [R+1] global offsets, row = state * A + action
+  const int32_t* csr_col;    // instance-relative state indices, ascending inside a row
+  const float* csr_val;
+  const float* R;            // [R]
+  const float* pi;           // [R] one-hot rows; used when act == null
+  const int32_t* act;        // [NSTATES] action of every state, or null
+  const int32_t* start;      // [B] instance-relative start state
+  const uint8_t* mask;       // [B] instances to evaluate, or null = all
+  const int64_t* work_off;   // [B+1] prefix of S_b^2
+  double* work;              // class matrices
+  double* avg;               // [B]
+  int32_t* kind;             // [B] 0 = float64 result, 1 = float32 result
+  int32_t* n_classes;        // [B] number of recurrent classes of the chain
+};
+
+enum { CHAIN_F64 = 0, CHAIN_F32 = 1 };
+
+__host__ __device__ inline size_t chain_lds_bytes(int S, int max_deg) {
+  return sizeof(double) * 4 * (size_t)S + sizeof(int) * (12 * (size_t)S + 1 + (size_t)S * max_deg);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// acc + v[t0] + v[t1] + ... over the set lanes of `m` in lane order (wave-uniform result)
+__device__ __forceinline__ double ordered_add(double acc, double v, unsigned long long m) {
+  while (m) {
+    const int t = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    acc = __dadd_rn(acc, readlane_f64(v, t));
+  }
+  return acc;
+}
+
+// numpy's pairwise_sum (numpy/_core/src/umath/loops_utils.h.src): < 8 plain, <= 128 eight accumulators, else halves
+template <typename T, int D>
+__device__ T np_pairwise(const T* a, int n) {
+  if (n < 8) {
+    T r = (T)-0.0;
+    for (int i = 0; i < n; ++i) r = r + a[i];
+    return r;
+  }
+  if (D == 0 || n <= 128) {
+    T r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] = r[j] + a[i + j];
+    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res = res + a[i];
+    return res;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise<T, (D > 0 ? D - 1 : 0)>(a, n2) + np_pairwise<T, (D > 0 ? D - 1 : 0)>(a + n2, n - n2);
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) k_chain_average_reward(ChainArgs c) {
+  extern __shared__ unsigned char chain_smem[];
+  __shared__ int s_i[8];
+  __shared__ double s_scale;
+  constexpr int NT = NW * 64;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (c.mask && !c.mask[b]) return;
+  const int64_t soff = c.state_off[b];
+  const int S = (int)(c.state_off[b + 1] - soff);
+  const int A = c.A;
+  const int64_t row0 = soff * A;
+  double* xs = reinterpret_cast<double*>(chain_smem);
+  double* rowv = xs + S;
+  double* colv = rowv + S;
+  double* ev = colv + S;
+  int* act = reinterpret_cast<int*>(ev + S);
+  int* adjp = act + S;  // [S+1]
+  int* pre = adjp + S + 1;
+  int* low = pre + S;
+  int* it = low + S;
+  int* comp = it + S;
+  int* queue = comp + S;
+  int* sccq = queue + S;
+  int* members = sccq + S;
+  int* pos = members + S;
+  int* rowk = pos + S;
+  int* colj = rowk + S;
+  int* adj = colj + S;  // [<= S * max_deg]
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+  // ---- A: actions, degrees, adjacency ------------------------------------------------------------------------------
+  for (int s = tid; s < S; s += NT) {
+    int a = 0;
+    if (c.act) {
+      a = c.act[soff + s];
+    } else {
+      const float* p = c.pi + row0 + (int64_t)s * A;
+      for (int k = 0; k < A; ++k) a = (p[k] == 1.0f) ? k : a;
+    }
+    act[s] = a;
+    const int64_t r = row0 + (int64_t)s * A + a;
+    int d = 0;
+    for (int64_t k = c.csr_ptr[r]; k < c.csr_ptr[r + 1]; ++k) d += (c.csr_val[k] > 0.0f) ? 1 : 0;
+    pre[s] = d;
+  }
+  __syncthreads();
+  if (wave == 0) {  // exclusive scan of the degrees
+    int carry = 0;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+      const int s = s0 + lane;
+      int v = (s < S) ? pre[s] : 0;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+      }
+      if (s < S) adjp[s + 1] = carry + v;
+      carry += __shfl(v, 63, 64);
+    }
+    if (lane == 0) adjp[0] = 0;
+  }
+  __syncthreads();
+  for (int s = tid; s < S; s += NT) {
+    const int64_t r = row0 + (int64_t)s * A + act[s];
+    int o = adjp[s];
+    for (int64_t k = c.csr_ptr[r]; k < c.csr_ptr[r + 1]; ++k)
+      if (c.csr_val[k] > 0.0f) adj[o++] = c.csr_col[k];
+    pre[s] = 0;  // 0 = not visited (networkx numbers the preorder from 1)
+    comp[s] = -1;
+    it[s] = adjp[s];
+  }
+  __syncthreads();
+
+  // ---- B: strongly connected components in networkx's emission order ----------------------------------------------
+  if (tid == 0) {
+    int cnt = 0, ncomp = 0, sq = 0;
+    for (int src = 0; src < S; ++src) {
+      if (comp[src] >= 0) continue;
+      int qn = 0;
+      queue[qn++] = src;
+      while (qn) {
+        const int v = queue[qn - 1];
+        int pv = pre[v];
+        if (pv == 0) { pv = ++cnt; pre[v] = pv; }
+        bool done = true;
+        int k = it[v];
+        const int kend = adjp[v + 1];
+        while (k < kend) {
+          const int w = adj[k++];
+          if (pre[w] == 0) { queue[qn++] = w; done = false; break; }
+        }
+        it[v] = k;
+        if (!done) continue;
+        int lw = pv;
+        for (int e = adjp[v]; e < kend; ++e) {
+          const int w = adj[e];
+          if (comp[w] < 0) {
+            const int pw = pre[w];
+            const int cand = (pw > pv) ? low[w] : pw;
+            lw = cand < lw ? cand : lw;
+          }
+        }
+        low[v] = lw;
+        --qn;
+        if (lw == pv) {
+          comp[v] = ncomp;
+          while (sq && pre[sccq[sq - 1]] > pv) comp[sccq[--sq]] = ncomp;
+          ++ncomp;
+        } else {
+          sccq[sq++] = v;
+        }
+      }
+    }
+    s_i[0] = ncomp;
+  }
+  __syncthreads();
+  const int ncomp = s_i[0];
+
+  // ---- C: recurrent classes (no edge leaves them), the class taken -------------------------------------------------
+  int* leak = it;     // [ncomp]
+  int* reach = queue; // [S]
+  int* rcomp = sccq;  // [ncomp]
+  for (int i = tid; i < S; i += NT) { leak[i] = 0; reach[i] = 0; rcomp[i] = 0; }
+  __syncthreads();
+  for (int s = tid; s < S; s += NT) {
+    const int cs = comp[s];
+    for (int e = adjp[s]; e < adjp[s + 1]; ++e)
+      if (comp[adj[e]] != cs) leak[cs] = 1;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int n_attr = 0, first = -1;
+    for (int q = 0; q < ncomp; ++q)
+      if (!leak[q]) { if (!n_attr) first = q; ++n_attr; }
+    s_i[1] = n_attr;
+    s_i[2] = first;
+    reach[c.start[b]] = 1;
+  }
+  __syncthreads();
+  const int n_attr = s_i[1];
+  int chosen = s_i[2];
+  if (n_attr > 1) {
+    for (;;) {
+      __syncthreads();
+      if (tid == 0) s_i[3] = 0;
+      __syncthreads();
+      bool ch = false;
+      for (int s = tid; s < S; s += NT) {
+        if (!reach[s]) continue;
+        for (int e = adjp[s]; e < adjp[s + 1]; ++e) {
+          const int w = adj[e];
+          if (!reach[w]) { reach[w] = 1; ch = true; }
+        }
+      }
+      if (ch) s_i[3] = 1;
+      __syncthreads();
+      if (!s_i[3]) break;
+    }
+    for (int s = tid; s < S; s += NT)
+      if (reach[s]) rcomp[comp[s]] = 1;
+    __syncthreads();
+    if (tid == 0) {
+      int pick = -1;
+      for (int q = 0; q < ncomp && pick < 0; ++q)
+        if (!leak[q] && rcomp[q]) pick = q;
+      s_i[2] = pick;
+    }
+    __syncthreads();
+    chosen = s_i[2];
+  }
+
+  // ---- D: members in ascending state order, dense matrix ----------------------------------------------------------
+  if (wave == 0) {
+    int m = 0;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+      const int s = s0 + lane;
+      const bool in = s < S && chosen >= 0 && comp[s] == chosen;
+      const unsigned long long bm = __ballot(in);
+      if (in) {
+        const int p = m + __popcll(bm & lt);
+        members[p] = s;
+        pos[s] = p;
+      } else if (s < S) {
+        pos[s] = -1;
+      }
+      m += __popcll(bm);
+    }
+    if (lane == 0) s_i[4] = m;
+  }
+  __syncthreads();
+  const int m = s_i[4];
+  double* a = c.work + c.work_off[b];
+  for (int64_t e = tid; e < (int64_t)m * m; e += NT) a[e] = 0.0;
+  __syncthreads();
+  for (int i = tid; i < m; i += NT) {
+    const int s = members[i];
+    const int64_t r = row0 + (int64_t)s * A + act[s];
+    for (int64_t k = c.csr_ptr[r]; k < c.csr_ptr[r + 1]; ++k) {
+      const float v = c.csr_val[k];
+      if (v > 0.0f) a[(int64_t)i * m + pos[c.csr_col[k]]] = (double)fminf(1.0f, v);
+    }
+  }
+  __syncthreads();
+
+  // ---- E: GTH elimination -------------------------------------------------------------------------------------------
+  int n_eff = m;
+  for (int i = 0; i < m - 1; ++i) {
+    if (wave == 0) {  // row i, columns k > i: ordered compaction + ordered sum
+      int cntr = 0;
+      double sc = 0.0;
+      for (int k0 = i + 1; k0 < m; k0 += 64) {
+        const int k = k0 + lane;
+        const double v = (k < m) ? a[(int64_t)i * m + k] : 0.0;
+        const unsigned long long bm = __ballot(v != 0.0);
+        if (v != 0.0) {
+          const int p = cntr + __popcll(bm & lt);
+          rowk[p] = k;
+          rowv[p] = v;
+        }
+        cntr += __popcll(bm);
+        sc = ordered_add(sc, v, bm);
+      }
+      if (lane == 0) { s_i[5] = cntr; s_scale = sc; }
+    }
+    if (wave == 1 % NW) {  // column i, rows j > i
+      int cntc = 0;
+      for (int j0 = i + 1; j0 < m; j0 += 64) {
+        const int j = j0 + lane;
+        const double v = (j < m) ? a[(int64_t)j * m + i] : 0.0;
+        const unsigned long long bm = __ballot(v != 0.0);
+        if (v != 0.0) {
+          const int p = cntc + __popcll(bm & lt);
+          colj[p] = j;
+          colv[p] = v;
+        }
+        cntc += __popcll(bm);
+      }
+      if (lane == 0) s_i[6] = cntc;
+    }
+    __syncthreads();
+    const double sc = s_scale;
+    if (sc <= 0.0) { n_eff = i + 1; break; }
+    const int nrow = s_i[5], ncol = s_i[6];
+    for (int pj = wave; pj < ncol; pj += NW) {
+      const int j = colj[pj];
+      const double l = colv[pj] / sc;
+      if (lane == 0) a[(int64_t)j * m + i] = l;
+      for (int pk = lane; pk < nrow; pk += 64) {
+        const int64_t at = (int64_t)j * m + rowk[pk];
+        a[at] = __dadd_rn(a[at], __dmul_rn(l, rowv[pk]));
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- F: back-substitution, normalisation, reward sum -------------------------------------------------------------
+  if (wave == 0 && m > 0) {
+    for (int i = lane; i < m; i += 64) xs[i] = 0.0;
+    if (lane == 0) xs[n_eff - 1] = 1.0;
+    for (int i = n_eff - 2; i >= 0; --i) {
+      double acc = 0.0;
+      for (int j0 = i + 1; j0 < n_eff; j0 += 64) {
+        const int j = j0 + lane;
+        double pr = 0.0;
+        if (j < n_eff) {
+          const double l = a[(int64_t)j * m + i];
+          if (l != 0.0) pr = __dmul_rn(xs[j], l);
+        }
+        acc = ordered_add(acc, pr, __ballot(pr != 0.0));
+      }
+      if (lane == 0) xs[i] = acc;
+    }
+    double tot = 0.0;
+    for (int i0 = 0; i0 < n_eff; i0 += 64) {
+      const int i = i0 + lane;
+      const double v = (i < n_eff) ? xs[i] : 0.0;
+      tot = ordered_add(tot, v, __ballot(v != 0.0));
+    }
+    for (int i = lane; i < n_eff; i += 64) xs[i] = xs[i] / tot;
+  }
+  __syncthreads();
+  const bool f32 = (n_attr == 1 && m < S);
+  float* ev32 = reinterpret_cast<float*>(ev);
+  for (int s = tid; s < S; s += NT) {
+    const float ar = c.R[row0 + (int64_t)s * A + act[s]];
+    const int p = pos[s];
+    if (f32) ev32[s] = __fmul_rn(ar, p >= 0 ? (float)xs[p] : 0.0f);
+    else ev[s] = __dmul_rn((double)ar, p >= 0 ? xs[p] : 0.0);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double out;
+    if (m == 0) out = 0.0;
+    else if (f32) out = (double)__fadd_rn(0.0f, np_pairwise<float, 12>(ev32, S));
+    else out = __dadd_rn(0.0, np_pairwise<double, 12>(ev, S));
+    c.avg[b] = out;
+    c.kind[b] = f32 ? CHAIN_F32 : CHAIN_F64;
+    if (c.n_classes) c.n_classes[b] = n_attr;
+  }
+}

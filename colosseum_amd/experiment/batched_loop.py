@@ -12,6 +12,7 @@ from typing import Dict, List
 import numpy as np
 
 from ..agents import BatchedQLearningEpisodic
+from .. import _lib as L
 from ..batched import BatchedMDP
 from .mdp_loop import InMemoryLogger, MDPLoop
 from .vector_tracker import MP, ContinuousVectorTracker, EpisodicVectorTracker
@@ -190,6 +191,7 @@ class BatchedContinuousLoop:
         assert env.H == 0 and env.models is not None
         self.env, self.agent = env, agent
         self.vectorized = vectorized
+        self._device_chain = True
         self._batch = get_average_reward_batch
         A = env.A
         self._TR = [m.dense() for m in env.models]
@@ -221,6 +223,13 @@ class BatchedContinuousLoop:
     def _log(self, t, cum, n_since, T, in_loop):
         if self.vectorized:
             def averages(need):
+                if self._device_chain:
+                    try:
+                        return self.agent.average_reward(need)
+                    except L.CmdpError as e:  # instance too large for the kernel's LDS budget: host bookkeeping + GTH kernel
+                        if e.code != L.ERR_UNSUPPORTED:
+                            raise
+                        self._device_chain = False
                 policies = self.agent.policy()
                 cur, _, _ = self.env.state()
                 return self.cache(need, policies, cur)

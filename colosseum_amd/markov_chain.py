@@ -36,15 +36,52 @@ def gth_batch(mats: Sequence[np.ndarray]) -> List[np.ndarray]:
     return [out[off[i]: off[i + 1]] for i in range(len(mats))]
 
 
+def _dfs_preorder(indptr: np.ndarray, indices: np.ndarray, n: int) -> np.ndarray:
+    """Preorder numbers of the depth-first search networkx's `strongly_connected_components` performs: sources in node
+    order, neighbours in adjacency (= column) order."""
+    pre = np.full(n, -1, np.int64)
+    nxt = indptr[:-1].copy()
+    cnt = 0
+    for src in range(n):
+        if pre[src] >= 0:
+            continue
+        pre[src] = cnt
+        cnt += 1
+        stack = [src]
+        while stack:
+            v = stack[-1]
+            k, end = nxt[v], indptr[v + 1]
+            while k < end and pre[indices[k]] >= 0:
+                k += 1
+            if k < end:
+                w = indices[k]
+                nxt[v] = k + 1
+                pre[w] = cnt
+                cnt += 1
+                stack.append(w)
+            else:
+                nxt[v] = k
+                stack.pop()
+    return pre
+
+
 def recurrent_classes(tps: np.ndarray) -> List[np.ndarray]:
-    """Closed communicating classes (the attracting components of the chain's digraph), each in ascending order."""
+    """Closed communicating classes (networkx's `attracting_components` of the chain's digraph), each in ascending
+    state order, listed in the reference's order (markov_chain.py:95): networkx emits strongly connected components as
+    its depth-first search completes them, and a component without outgoing edges is completed before the search leaves
+    it -- so the attracting components come in the order in which that search first touches them."""
     n = len(tps)
     g = csr_matrix(tps > 0)
     ncomp, label = connected_components(g, directed=True, connection="strong")
     src, dst = g.nonzero()
     leaks = np.zeros(ncomp, bool)
     leaks[label[src[label[src] != label[dst]]]] = True
-    return [np.flatnonzero(label == c) for c in range(ncomp) if not leaks[c]]
+    classes = [np.flatnonzero(label == c) for c in range(ncomp) if not leaks[c]]
+    if len(classes) > 1:
+        g.sort_indices()
+        pre = _dfs_preorder(g.indptr, g.indices, n)
+        classes.sort(key=lambda cls: pre[cls].min())
+    return classes
 
 
 def _class_distribution(tps: np.ndarray, cls: np.ndarray) -> np.ndarray:

@@ -260,6 +260,13 @@ int cmdp_qlearning_evaluate(cmdp_agent_t* a, float* V0);
 /* argmax_2d (colosseum/dynamic_programming/utils.py:12-25) of the continuous agents' Q tables: one-hot float32
    policies pi [state_off[B]*A] (BaseAgent.current_optimal_stochastic_policy). */
 int cmdp_qlearning_policy(cmdp_agent_t* a, float* pi);
+/* BaseMDP-side `get_average_reward(T, R, policy, [(state, 1.0)])` (colosseum/mdp/utils/markov_chain.py:12-31, the
+   regret of every continuous-setting log row, agent_mdp_interaction.py:518-532) for the agents' current greedy
+   policies from the environments' current states, all on the device: recurrent classes in networkx's
+   attracting_components order, GTH elimination of the class taken, numpy's summation order.  avg[b] is the value;
+   kind[b] = 1 when the reference's result is a numpy float32 (one recurrent class smaller than the chain), else 0
+   (float64).  mask [B] selects the instances to evaluate (NULL = all; the others' outputs are left untouched). */
+int cmdp_qlearning_average_reward(cmdp_agent_t* a, const uint8_t* mask, double* avg, int32_t* kind);
 /* argmax_3d (colosseum/dynamic_programming/utils.py:28-39) of host tables Q [per instance q_layers*S_b*A, q_layers
    >= H]: one-hot float32 policy of the first H layers, pi [per instance H*S_b*A]. */
 int cmdp_greedy_policy_episodic(cmdp_t* h, int H, int q_layers, const float* Q, float* pi);
@@ -268,6 +275,13 @@ int cmdp_greedy_policy_episodic(cmdp_t* h, int H, int q_layers, const float* Q, 
 int cmdp_qlearning_tables(cmdp_agent_t* a, float* Q, int32_t* N);
 
 /* ---- Markov chains ------------------------------------------------------------------------------------ */
+/* get_average_reward (colosseum/mdp/utils/markov_chain.py:12-31) of deterministic stationary policies: actions
+   [state_off[B]] gives the action of every state of every (continuous, horizon 0) instance, start_states [B] the
+   instance-relative state the chain starts from.  Outputs as cmdp_qlearning_average_reward; n_classes [B] (may be
+   NULL) receives the number of recurrent classes of each chain.  CMDP_ERR_UNSUPPORTED when an instance exceeds the
+   kernel's LDS budget (80 bytes per state + 4 per successor). */
+int cmdp_average_reward(cmdp_t* h, const int32_t* actions, const int32_t* start_states, const uint8_t* mask, double* avg,
+                        int32_t* kind, int32_t* n_classes);
 /* _gth_solve_numba (colosseum/mdp/utils/markov_chain.py:139-166): stationary distributions of `count` chains with a
    single recurrent class each, float64 GTH elimination on the current device.  Chain m is the dims[m] x dims[m]
    row-major matrix at mats + sum_{i<m} dims[i]^2 (not modified); its distribution goes to

@@ -79,3 +79,26 @@ def test_constructor_checks():
         make_model("TaxiEpisodic", seed=0, size=5)
     with pytest.raises(NotImplementedError):
         make_model("DeepSeaEpisodic", seed=0)
+
+
+def test_recurrent_class_order_is_networkx_attracting_components_order():
+    """markov_chain.py:95 of the reference lists the recurrent classes in networkx's `attracting_components` order and
+    keeps the FIRST one the start state reaches: the order is part of the result (networkx 3.4.2 is the checker here)."""
+    nx = pytest.importorskip("networkx")
+    from colosseum_amd.markov_chain import recurrent_classes
+
+    rng = np.random.default_rng(5)
+    seen_multi = 0
+    for trial in range(300):
+        n = int(rng.integers(3, 40))
+        tps = np.zeros((n, n), np.float32)
+        for s in range(n):  # sparse random chain: 1-3 successors, biased to nearby states so that several classes form
+            k = int(rng.integers(1, 4))
+            succ = np.clip(s + rng.integers(-3, 4, k), 0, n - 1)
+            for j in succ:
+                tps[s, j] += 1.0 / k
+        want = [sorted(c) for c in nx.attracting_components(nx.DiGraph(tps))]
+        got = [c.tolist() for c in recurrent_classes(tps)]
+        assert got == want, trial
+        seen_multi += len(want) > 1
+    assert seen_multi > 50

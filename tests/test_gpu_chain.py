@@ -1,0 +1,61 @@
+"""K9 (cmdp_average_reward): average reward of deterministic policies, fully on the device, against the host
+restatement of colosseum/mdp/utils/markov_chain.py:12-136 (recurrent classes by scipy + networkx-order DFS, GTH by the
+dense kernel K7): same value, same numpy type, same number of recurrent classes."""
+import numpy as np
+import pytest
+
+from colosseum_amd import _lib as L
+from colosseum_amd.batched import BatchedMDP
+from colosseum_amd.markov_chain import (get_average_reward, get_transition_probabilities, recurrent_classes)
+from colosseum_amd.mdp import make_model
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("FrozenLakeContinuous", dict(seed=3, size=5, p_frozen=0.8)),
+    ("DeepSeaContinuous", dict(seed=1, size=8)),
+    ("DeepSeaContinuous", dict(seed=2, size=12, p_rand=0.1)),
+    ("MiniGridEmptyContinuous", dict(seed=4, size=6, n_starting_states=2)),
+    ("MiniGridRoomsContinuous", dict(seed=5, room_size=3, n_rooms=4)),
+    ("FrozenLakeContinuous", dict(seed=6, size=12, p_frozen=0.9)),
+]
+
+
+@pytest.mark.parametrize("cls,kw", CASES)
+def test_average_reward_kernel_matches_host_restatement(need_gpu, cls, kw):
+    m = make_model(cls, **kw)
+    S, A = m.n_states, m.n_actions
+    T, R = m.dense()
+    rng = np.random.default_rng(S)
+    n_pol = 24
+    acts, starts = [], []
+    for i in range(n_pol):
+        if i % 3 == 0:   # fully random action per state: usually several recurrent classes
+            a = rng.integers(0, A, S)
+        elif i % 3 == 1:  # one action nearly everywhere
+            a = np.full(S, rng.integers(0, A))
+            a[rng.integers(0, S, max(1, S // 10))] = rng.integers(0, A)
+        else:            # greedy w.r.t. a noisy reward table
+            a = (R + rng.normal(size=R.shape) * 0.3).argmax(1)
+        acts.append(a.astype(np.int32))
+        starts.append(int(rng.integers(0, S)))
+    env = BatchedMDP([m] * n_pol, rng_mode=L.RNG_PHILOX, with_env=False)
+    vals, ncls = env.average_reward(acts, starts)
+    multi = 0
+    for i in range(n_pol):
+        pol = np.zeros((S, A), np.float32)
+        pol[np.arange(S), acts[i]] = 1
+        want = get_average_reward(T, R, pol, [(starts[i], 1.0)])
+        nc = len(recurrent_classes(get_transition_probabilities(T, pol)))
+        multi += nc > 1
+        assert ncls[i] == nc, (cls, i)
+        assert type(vals[i]) is type(want), (cls, i, type(vals[i]), type(want), nc)
+        assert vals[i] == want, (cls, i, vals[i], want, nc)
+    # a masked call leaves the other instances alone and returns the same values
+    mask = np.zeros(n_pol, bool)
+    mask[::2] = True
+    vals2, _ = env.average_reward(acts, starts, mask=mask)
+    assert [vals2[i] for i in range(0, n_pol, 2)] == [vals[i] for i in range(0, n_pol, 2)]
+    env.close()
+    if cls.startswith("MiniGrid"):  # turning on the spot for ever: random policies split the grid into many classes
+        assert multi >= 4
