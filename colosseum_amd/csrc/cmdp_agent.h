@@ -202,12 +202,62 @@ __device__ __forceinline__ void mt_block(uint32_t* mt, uint32_t* out, int lane) 
   __builtin_amdgcn_wave_barrier();
 }
 
+// Tie-breaks of one chunk of 64 rows (lane = row, n_tie = number of maximal entries of the row).  Sequentially every
+// tied row draws words until (word & mask) <= n_tie - 1.  For a RUN of consecutive tied rows with the same n_tie the
+// acceptance of a word does not depend on the row, so the k-th row of the run gets the k-th accepted word after the
+// run's start and the stream continues just past the last word used: a run costs one wave step per 64-word window
+// instead of one scalar loop iteration per draw.
+__device__ __forceinline__ int tie_break_chunk(int n_tie, uint32_t* mt, uint32_t* out, uint32_t* tmp, int& pos, int lane) {
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const unsigned long long me = 1ull << lane;
+  int pick = 0;
+  unsigned long long need = __ballot(n_tie > 1);
+  while (need) {
+    const int i = __ffsll((long long)need) - 1;
+    const int n = __builtin_amdgcn_readlane(n_tie, i);
+    const unsigned long long same = __ballot(n_tie == n) & need;
+    const unsigned long long diff = need & ~same;
+    const unsigned long long run = diff ? (same & ((1ull << (__ffsll((long long)diff) - 1)) - 1ull)) : same;
+    need &= ~run;
+    const uint32_t mx = (uint32_t)n - 1u;
+    uint32_t mask = mx;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    unsigned long long remaining = run;
+    while (remaining) {
+      if (pos == 624) {
+        mt_block(mt, out, lane);
+        pos = 0;
+      }
+      const uint32_t w = out[pos + lane] & mask;
+      const unsigned long long ok = __ballot(pos + lane < 624 && w <= mx);
+      const int nacc = __popcll(ok), R = __popcll(remaining);
+      const int arank = __popcll(ok & lt);
+      if (ok & me) tmp[arank] = w;
+      __builtin_amdgcn_wave_barrier();
+      const int rrank = __popcll(remaining & lt);
+      const bool mine = (remaining & me) != 0;
+      if (mine && rrank < nacc) pick = (int)tmp[rrank];
+      __builtin_amdgcn_wave_barrier();
+      if (R <= nacc) {
+        const unsigned long long last = __ballot((ok & me) != 0 && arank == R - 1);
+        pos += __ffsll((long long)last);  // lane index of the R-th accepted word + 1
+        remaining = 0;
+      } else {
+        pos = (pos + 64 < 624) ? pos + 64 : 624;
+        remaining = __ballot(mine && rrank >= nacc);
+      }
+    }
+  }
+  return pick;
+}
+
 template <typename QT>
 __global__ void __launch_bounds__(64) k_greedy_policy_episodic(int B, int A, int H, int q_layers,
                                                               const int64_t* __restrict__ state_off,
                                                               const QT* __restrict__ Q, float* __restrict__ pi) {
   __shared__ uint32_t mt[624];
   __shared__ uint32_t out[624 + 64];  // padded: a 64-word window read may start at any position < 624
+  __shared__ uint32_t tmp[64];
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= B) return;
   const int64_t soff = state_off[b];
@@ -217,9 +267,46 @@ __global__ void __launch_bounds__(64) k_greedy_policy_episodic(int B, int A, int
   for (int i = lane; i < 624; i += 64) mt[i] = kMt42.w[i];
   out[624 + lane] = 0u;
   __builtin_amdgcn_wave_barrier();
-  int pos = 624, wbase = -1;  // wave-uniform: stream position inside the block, first word held by the window
-  uint32_t win = 0;
+  int pos = 624;  // wave-uniform: stream position inside the current block (624 = exhausted)
   const int64_t nrows = (int64_t)H * S;
+  // rows live in registers (A <= 8: all loads of a row in flight together) and the NEXT chunk is fetched before the
+  // current one is walked, so the single wave never waits for HBM inside the sequential part
+  constexpr int AR = 8;
+  if (A <= AR) {
+    QT cur[AR], nxt[AR];
+    auto fetch = [&](int64_t r, QT (&dst)[AR]) {
+#pragma unroll
+      for (int a = 0; a < AR; ++a) dst[a] = (r < nrows && a < A) ? q[r * A + a] : (QT)0;
+    };
+    fetch(lane, cur);
+    for (int64_t r0 = 0; r0 < nrows; r0 += 64) {
+      const int64_t r = r0 + lane;
+      const bool valid = r < nrows;
+      fetch(r + 64, nxt);
+      QT m = cur[0];
+#pragma unroll
+      for (int a = 1; a < AR; ++a) m = (a < A && cur[a] > m) ? cur[a] : m;
+      int n_tie = 0;
+#pragma unroll
+      for (int a = 0; a < AR; ++a) n_tie += (a < A && cur[a] == m) ? 1 : 0;
+      if (!valid) n_tie = 0;
+      const int pick = tie_break_chunk(n_tie, mt, out, tmp, pos, lane);
+      if (valid) {
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < AR; ++a) {
+          if (a < A) {
+            const bool tie = cur[a] == m;
+            p[r * A + a] = (tie && k == pick) ? 1.0f : 0.0f;
+            k += tie ? 1 : 0;
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < AR; ++a) cur[a] = nxt[a];
+    }
+    return;
+  }
   for (int64_t r0 = 0; r0 < nrows; r0 += 64) {
     const int64_t r = r0 + lane;
     const bool valid = r < nrows;
@@ -231,30 +318,7 @@ __global__ void __launch_bounds__(64) k_greedy_policy_episodic(int B, int A, int
       for (int a = 1; a < A; ++a) m = (row[a] > m) ? row[a] : m;
       for (int a = 0; a < A; ++a) n_tie += (row[a] == m) ? 1 : 0;
     }
-    int pick = 0;
-    unsigned long long need = __ballot(n_tie > 1);
-    while (need) {
-      const int i = __ffsll((long long)need) - 1;
-      need &= need - 1;
-      const uint32_t mx = (uint32_t)__builtin_amdgcn_readlane(n_tie, i) - 1u;
-      uint32_t mask = mx;
-      mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-      uint32_t v;
-      do {
-        if (pos == 624) {
-          mt_block(mt, out, lane);
-          pos = 0;
-          wbase = -1;
-        }
-        if (wbase < 0 || pos - wbase >= 64) {
-          wbase = pos;
-          win = out[wbase + lane];
-        }
-        v = (uint32_t)__builtin_amdgcn_readlane((int)win, pos - wbase) & mask;
-        ++pos;
-      } while (v > mx);
-      if (lane == i) pick = (int)v;
-    }
+    const int pick = tie_break_chunk(n_tie, mt, out, tmp, pos, lane);
     if (valid) {
       for (int a = 0, k = 0; a < A; ++a) {
         const bool tie = row[a] == m;

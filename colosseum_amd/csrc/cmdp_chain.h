@@ -298,35 +298,54 @@ __global__ void __launch_bounds__(NW * 64) k_chain_average_reward(ChainArgs c) {
   // ---- E: GTH elimination -------------------------------------------------------------------------------------------
   int n_eff = m;
   for (int i = 0; i < m - 1; ++i) {
+    // both scans fetch up to PF chunks (64 * PF entries) before looking at any of them: one memory round trip per
+    // pivot instead of one per chunk
+    constexpr int PF = 8;
     if (wave == 0) {  // row i, columns k > i: ordered compaction + ordered sum
       int cntr = 0;
       double sc = 0.0;
-      for (int k0 = i + 1; k0 < m; k0 += 64) {
-        const int k = k0 + lane;
-        const double v = (k < m) ? a[(int64_t)i * m + k] : 0.0;
-        const unsigned long long bm = __ballot(v != 0.0);
-        if (v != 0.0) {
-          const int p = cntr + __popcll(bm & lt);
-          rowk[p] = k;
-          rowv[p] = v;
+      for (int k0 = i + 1; k0 < m; k0 += 64 * PF) {
+        double v[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          const int k = k0 + 64 * u + lane;
+          v[u] = (k < m) ? a[(int64_t)i * m + k] : 0.0;
         }
-        cntr += __popcll(bm);
-        sc = ordered_add(sc, v, bm);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          if (k0 + 64 * u >= m) break;
+          const unsigned long long bm = __ballot(v[u] != 0.0);
+          if (v[u] != 0.0) {
+            const int p = cntr + __popcll(bm & lt);
+            rowk[p] = k0 + 64 * u + lane;
+            rowv[p] = v[u];
+          }
+          cntr += __popcll(bm);
+          sc = ordered_add(sc, v[u], bm);
+        }
       }
       if (lane == 0) { s_i[5] = cntr; s_scale = sc; }
     }
     if (wave == 1 % NW) {  // column i, rows j > i
       int cntc = 0;
-      for (int j0 = i + 1; j0 < m; j0 += 64) {
-        const int j = j0 + lane;
-        const double v = (j < m) ? a[(int64_t)j * m + i] : 0.0;
-        const unsigned long long bm = __ballot(v != 0.0);
-        if (v != 0.0) {
-          const int p = cntc + __popcll(bm & lt);
-          colj[p] = j;
-          colv[p] = v;
+      for (int j0 = i + 1; j0 < m; j0 += 64 * PF) {
+        double v[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          const int j = j0 + 64 * u + lane;
+          v[u] = (j < m) ? a[(int64_t)j * m + i] : 0.0;
         }
-        cntc += __popcll(bm);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          if (j0 + 64 * u >= m) break;
+          const unsigned long long bm = __ballot(v[u] != 0.0);
+          if (v[u] != 0.0) {
+            const int p = cntc + __popcll(bm & lt);
+            colj[p] = j0 + 64 * u + lane;
+            colv[p] = v[u];
+          }
+          cntc += __popcll(bm);
+        }
       }
       if (lane == 0) s_i[6] = cntc;
     }
