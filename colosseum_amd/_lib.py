@@ -18,6 +18,7 @@ FLAG_REWARD_MEANS = 1
 OPT_ROLLOUT_KERNEL = 1
 OPT_DP_KERNEL = 2
 OPT_LDS_GROUPS_PER_CU = 3
+OPT_DIAMETER_WORKSPACE_MB = 4
 DP_AUTO, DP_WORKGROUP, DP_REGISTER = 0, 1, 2
 ROLLOUT_AUTO, ROLLOUT_GLOBAL, ROLLOUT_LDS = 0, 1, 2
 
@@ -27,7 +28,7 @@ EXPORTS = [
     "cmdp_visits", "cmdp_reset_visits", "cmdp_state", "cmdp_last_start", "cmdp_vi_discounted", "cmdp_pe_discounted",
     "cmdp_vi_episodic", "cmdp_pe_episodic", "cmdp_diameter", "cmdp_diameter_episodic", "cmdp_value_norm", "cmdp_gth", "cmdp_qlearning_create", "cmdp_qlearning_destroy", "cmdp_qlearning_run",
     "cmdp_qlearning_tables", "cmdp_qlearning_evaluate", "cmdp_greedy_policy_episodic", "cmdp_qlearning_continuous_create",
-    "cmdp_qlearning_policy", "cmdp_qlearning_average_reward", "cmdp_average_reward",
+    "cmdp_qlearning_policy", "cmdp_qlearning_average_reward", "cmdp_average_reward", "cmdp_diameter_range",
 ]
 
 
@@ -101,6 +102,7 @@ def load():
         L.cmdp_qlearning_policy.argtypes = [vp, vp]
         L.cmdp_qlearning_average_reward.argtypes = [vp, vp, vp, vp]
         L.cmdp_average_reward.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.cmdp_diameter_range.argtypes = [vp, C.c_double, i64, i64, i64, vp]
         L.cmdp_greedy_policy_episodic.argtypes = [vp, i32, i32, vp, vp]
         L.cmdp_qlearning_tables.argtypes = [vp, vp, vp]
         _lib = L

@@ -294,6 +294,15 @@ class BatchedMDP:
         L.check(self._lib.cmdp_diameter(self._h, epsilon, scheme, max_sweeps, L.ptr(per), L.ptr(diam)))
         return diam, per
 
+    def diameter_range(self, target_lo: int, target_hi: int, epsilon=1e-3, max_sweeps=1_000_000) -> np.ndarray:
+        """Optimal expected hitting times (max over start states) of the targets [target_lo, target_hi) of the flat
+        state space, Jacobi scheme, 64 targets per workgroup (kernel K5S): the shard of `diameter()` one GPU takes
+        when one large MDP is split over ranks (config C5)."""
+        per = np.zeros(int(target_hi) - int(target_lo), np.float32)
+        L.check(self._lib.cmdp_diameter_range(self._h, float(epsilon), int(max_sweeps), int(target_lo), int(target_hi),
+                                              L.ptr(per)))
+        return per
+
     def diameter_episodic(self, epsilon=1e-3, max_sweeps=1_000_000):
         """Episodic diameter of every instance (needs the batch to have been built from TabularModels or tables
         that carry the starting states)."""

@@ -114,6 +114,11 @@ struct cmdp {
   LdsPlan lds_plan{};
   size_t lds_bytes = 0;
   DevBuf<float> d_gp_q, d_gp_p;  // cmdp_greedy_policy_episodic workspace
+  // K5S workspace (large-instance diameter)
+  DevBuf<float> d_dl_v;
+  DevBuf<int32_t> d_dl_inst, d_dl_t0, d_dl_cnt;
+  DevBuf<int64_t> d_dl_voff;
+  size_t dl_ws_bytes = (size_t)24 << 30;  // value arrays of the target groups in flight per launch
   // cmdp_average_reward workspace (K9)
   DevBuf<double> d_ch_work, d_ch_avg;
   DevBuf<int64_t> d_ch_off;
@@ -640,8 +645,12 @@ int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
     h->lds_bytes = (size_t)K1L_FIXED + (size_t)g * (h->lds_plan.slot_bytes + 2 * K1L_CH);
     return CMDP_OK;
   }
-  if (option == CMDP_OPT_DP_KERNEL && value >= 0 && value <= 2) {
+  if (option == CMDP_OPT_DP_KERNEL && value >= 0 && value <= 3) {
     h->dp_kernel = (int)value;
+    return CMDP_OK;
+  }
+  if (option == CMDP_OPT_DIAMETER_WORKSPACE_MB && value >= 1) {
+    h->dl_ws_bytes = (size_t)value << 20;
     return CMDP_OK;
   }
   return fail(CMDP_ERR_INVALID, "unknown option %d / value %lld", option, (long long)value);
@@ -912,6 +921,50 @@ int cmdp_pe_episodic(cmdp_t* h, int H, const float* pi, const float* R_override,
   return episodic(h, DP_PE, H, pi, R_override, Q, V);
 }
 
+// K5S driver: targets [unit_lo, unit_hi) of the flat state space in groups of 64 consecutive targets of one instance;
+// as many groups per launch as the value-array workspace allows.
+static int diameter_lanes(cmdp_t* h, DpTables t, int64_t unit_lo, int64_t unit_hi) {
+  hipStream_t st = h->stream;
+  std::vector<int32_t> inst, t0, cnt;
+  std::vector<int64_t> vfl;  // floats per group
+  for (int b = 0; b < h->B; ++b) {
+    const int64_t so = h->state_off[b], S = h->state_off[b + 1] - so;
+    const int64_t lo = std::max<int64_t>(unit_lo, so) - so, hi = std::min<int64_t>(unit_hi, so + S) - so;
+    for (int64_t x = lo; x < hi; x += 64) {
+      inst.push_back(b);
+      t0.push_back((int32_t)x);
+      cnt.push_back((int32_t)std::min<int64_t>(64, hi - x));
+      vfl.push_back(2 * S * 64);
+    }
+  }
+  const size_t G = inst.size();
+  size_t g0 = 0;
+  while (g0 < G) {
+    size_t g1 = g0, floats = 0;
+    std::vector<int64_t> voff;
+    while (g1 < G && (g1 == g0 || (floats + (size_t)vfl[g1]) * sizeof(float) <= h->dl_ws_bytes)) {
+      voff.push_back((int64_t)floats);
+      floats += (size_t)vfl[g1];
+      ++g1;
+    }
+    const size_t n = g1 - g0;
+    if (h->d_dl_v.n < floats) {
+      if (hipError_t e = h->d_dl_v.alloc(floats); e != hipSuccess)
+        return fail(CMDP_ERR_HIP, "K5S workspace of %zu bytes: %s", floats * sizeof(float), hipGetErrorString(e));
+    }
+    HIP_TRY(h->d_dl_inst.upload(inst.data() + g0, n, st));
+    HIP_TRY(h->d_dl_t0.upload(t0.data() + g0, n, st));
+    HIP_TRY(h->d_dl_cnt.upload(cnt.data() + g0, n, st));
+    HIP_TRY(h->d_dl_voff.upload(voff.data(), n, st));
+    DiamLanesArgs g{h->d_dl_inst.p, h->d_dl_t0.p, h->d_dl_cnt.p, h->d_dl_voff.p, h->d_dl_v.p};
+    hipLaunchKernelGGL(k_diam_lanes<8>, dim3((unsigned)n), dim3(512), 0, st, t, g);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));  // the upload staging vectors die at the end of this iteration
+    g0 = g1;
+  }
+  return CMDP_OK;
+}
+
 int cmdp_diameter(cmdp_t* h, double epsilon, int scheme, int64_t max_sweeps, float* per_target, float* diameter) {
   if (int rc = bind(h)) return rc;
   if (!h->has_dp) return fail(CMDP_ERR_INVALID, "handle was created without the DP half");
@@ -928,7 +981,11 @@ int cmdp_diameter(cmdp_t* h, double epsilon, int scheme, int64_t max_sweeps, flo
   t.csr_val = h->d_csr_val.p; t.R = h->d_R.p; t.pi = nullptr; t.unit_off = h->d_state_off.p;
   t.gamma = 1.0f; t.eps = epsilon; t.max_abs = 0.0; t.max_sweeps = max_sweeps;
   t.Q = nullptr; t.V = nullptr; t.sweeps = nullptr; t.per_target = h->d_per_target.p; t.status = h->d_status.p;
-  if (int rc = run_sweeps(h, DP_VI, true, sch, t, NS)) return rc;
+  const size_t v_need = 2 * sizeof(float) * (size_t)h->max_S + sizeof(float) * 4 * (kDpBlock / 64);
+  const bool lanes = sch == CMDP_SCHEME_JACOBI && (h->dp_kernel == 3 || v_need > (size_t)kLdsBudget);
+  if (lanes) {
+    if (int rc = diameter_lanes(h, t, 0, NS)) return rc;
+  } else if (int rc = run_sweeps(h, DP_VI, true, sch, t, NS)) return rc;
   std::vector<float> per((size_t)NS);
   HIP_TRY(hipMemcpyAsync(per.data(), h->d_per_target.p, sizeof(float) * NS, hipMemcpyDeviceToHost, st));
   if (int rc = check_status(h, NS)) return rc;
@@ -939,6 +996,30 @@ int cmdp_diameter(cmdp_t* h, double epsilon, int scheme, int64_t max_sweeps, flo
   }
   if (per_target) std::memcpy(per_target, per.data(), sizeof(float) * NS);
   return CMDP_OK;
+}
+
+int cmdp_diameter_range(cmdp_t* h, double epsilon, int64_t max_sweeps, int64_t target_lo, int64_t target_hi,
+                        float* per_target) {
+  if (int rc = bind(h)) return rc;
+  if (!h->has_dp) return fail(CMDP_ERR_INVALID, "handle was created without the DP half");
+  if (!per_target) return fail(CMDP_ERR_INVALID, "null output");
+  if (max_sweeps < 1) return fail(CMDP_ERR_INVALID, "max_sweeps < 1");
+  const int64_t NS = h->n_states;
+  if (target_lo < 0 || target_hi > NS || target_lo > target_hi) return fail(CMDP_ERR_INVALID, "target range outside [0, %lld]", (long long)NS);
+  if (target_lo == target_hi) return CMDP_OK;
+  hipStream_t st = h->stream;
+  if (h->d_per_target.n < (size_t)NS) HIP_TRY(h->d_per_target.alloc(NS));
+  if (h->d_status.n < (size_t)NS) HIP_TRY(h->d_status.alloc(NS));
+  HIP_TRY(hipMemsetAsync(h->d_status.p, 0, sizeof(int32_t) * NS, st));
+  DpTables t{};
+  t.B = h->B; t.A = h->A; t.state_off = h->d_state_off.p; t.csr_ptr = h->d_csr_ptr.p; t.csr_col = h->d_csr_col.p;
+  t.csr_val = h->d_csr_val.p; t.R = h->d_R.p; t.pi = nullptr; t.unit_off = h->d_state_off.p;
+  t.gamma = 1.0f; t.eps = epsilon; t.max_abs = 0.0; t.max_sweeps = max_sweeps;
+  t.per_target = h->d_per_target.p; t.status = h->d_status.p;
+  if (int rc = diameter_lanes(h, t, target_lo, target_hi)) return rc;
+  HIP_TRY(hipMemcpyAsync(per_target, h->d_per_target.p + target_lo, sizeof(float) * (target_hi - target_lo),
+                         hipMemcpyDeviceToHost, st));
+  return check_status(h, NS);
 }
 
 int cmdp_diameter_episodic(cmdp_t* h, int H, const int64_t* start_off, const int32_t* start_state,

@@ -1298,3 +1298,96 @@ __global__ void __launch_bounds__(256) k_gth(const int64_t* __restrict__ mat_off
     for (int i = 0; i < nn; ++i) x[i] = x[i] / tot;
   }
 }
+
+
+// ===================================================================================================
+// K5S: diameter of LARGE instances (config C5: S ~ 50 000, the value vector of one target no longer fits LDS).
+// Same arithmetic as K2 in DIAM mode -- per target es the Jacobi value iteration of
+// `_continuous_diam_calculation` (reference colosseum/hardness/measures/diameter.py:76-96) on T_es / R_es with
+// gamma = 1, float32 in-order accumulation, stop at max|dV| < eps -- but organised for HBM:
+//   * one workgroup solves 64 consecutive targets AT ONCE, lane = target.  All 64 value vectors live interleaved
+//     in HBM as V[state][lane] (two copies, Jacobi), so the gather V[col] of every non-zero is one fully
+//     coalesced 256-byte row for the whole wave, whatever the column is;
+//   * the CSR walk is the same for all 64 targets: row pointers, columns and values are wave-uniform (scalar
+//     loads through the constant cache), read once per 64 targets instead of once per target;
+//   * the NW waves of the workgroup split the states; max|dV| and min V are lane-private running values, reduced
+//     across the waves through LDS once per sweep (one barrier per sweep);
+//   * a target that has converged keeps its result (-min V of ITS final sweep) while the others continue.
+// Algorithmic HBM bytes per (target, sweep): 4 B read + 4 B written per state (the CSR is shared by 64 targets).
+// ===================================================================================================
+struct DiamLanesArgs {
+  const int32_t* grp_inst;     // [groups] instance of the group
+  const int32_t* grp_target0;  // [groups] first target (instance-relative)
+  const int32_t* grp_count;    // [groups] targets in the group (<= 64)
+  const int64_t* grp_voff;     // [groups] offset of the group's two value arrays in `vbuf` (floats)
+  float* vbuf;
+};
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) k_diam_lanes(DpTables t, DiamLanesArgs g) {
+  __shared__ float red_d[2][NW][64];
+  __shared__ float red_m[2][NW][64];
+  const int grp = blockIdx.x;
+  const int b = g.grp_inst[grp];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int A = t.A;
+  const int64_t soff = t.state_off[b];
+  const int S = (int)(t.state_off[b + 1] - soff);
+  const int64_t row0 = soff * A;
+  const int64_t* ptr = t.csr_ptr + row0;
+  const int target = g.grp_target0[grp] + lane;
+  const bool active = lane < g.grp_count[grp];
+  float* Vold = g.vbuf + g.grp_voff[grp];
+  float* Vnew = Vold + (int64_t)S * 64;
+  for (int64_t i = threadIdx.x; i < (int64_t)S * 128; i += NW * 64) Vold[i] = 0.0f;
+  __syncthreads();
+
+  bool done = !active;
+  float result = 0.0f;
+  int status = active ? -5 : 0;
+  int64_t it = 0;
+  while (it < t.max_sweeps) {
+    ++it;
+    float dmax = 0.0f, vmin = 3.0e38f;
+    for (int s = wave; s < S; s += NW) {
+      float v = 0.0f;
+      for (int a = 0; a < A; ++a) {
+        const int64_t lo = ptr[(int64_t)s * A + a], hi = ptr[(int64_t)s * A + a + 1];
+        float acc = 0.0f;
+        for (int64_t k = lo; k < hi; ++k)
+          acc = __fadd_rn(acc, __fmul_rn(t.csr_val[k], Vold[(int64_t)t.csr_col[k] * 64 + lane]));
+        const float q = __fadd_rn(-1.0f, __fmul_rn(t.gamma, acc));
+        v = (a == 0) ? q : fmaxf(v, q);
+      }
+      const float vo = Vold[(int64_t)s * 64 + lane];
+      if (s == target) {  // absorbing row {target: 1}, R = 0: every action gives 0 + gamma * (0 + 1 * V[target])
+        v = __fadd_rn(0.0f, __fmul_rn(t.gamma, __fadd_rn(0.0f, __fmul_rn(1.0f, vo))));
+      }
+      Vnew[(int64_t)s * 64 + lane] = v;
+      dmax = fmaxf(dmax, fabsf(vo - v));
+      vmin = fminf(vmin, v);
+    }
+    const int par = (int)(it & 1);
+    red_d[par][wave][lane] = dmax;
+    red_m[par][wave][lane] = vmin;
+    __syncthreads();
+    float diff = 0.0f, mn = 3.0e38f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      diff = fmaxf(diff, red_d[par][w][lane]);
+      mn = fminf(mn, red_m[par][w][lane]);
+    }
+    float* tmp = Vold; Vold = Vnew; Vnew = tmp;
+    if (!done && (double)diff < t.eps) {
+      done = true;
+      result = -mn;
+      status = 0;
+    }
+    if (__all(done)) break;
+  }
+  if (wave == 0 && active) {
+    t.per_target[soff + target] = result;
+    t.status[soff + target] = status;
+  }
+}

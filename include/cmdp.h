@@ -175,10 +175,14 @@ int cmdp_synchronize(cmdp_t* h);
    values, at least 8 instances per 160 KiB of LDS).
    CMDP_OPT_DP_KERNEL (Jacobi sweeps): 0 = automatic, 1 = workgroup kernel with the CSR in LDS or HBM,
    2 = register-resident CSR kernel (CMDP_ERR_UNSUPPORTED when no compiled shape fits: A in 2..4, <= 8
-   non-zeros per row, <= 1024 states).
+   non-zeros per row, <= 1024 states), 3 = (cmdp_diameter only) the 64-targets-per-workgroup kernel K5S that is
+   otherwise taken when the value vector of an instance does not fit LDS.
+   CMDP_OPT_DIAMETER_WORKSPACE_MB: HBM the value arrays of K5S may take per launch (default 24576; 512 bytes per
+   state per group of 64 targets; more groups in flight = more of the GPU busy).
    CMDP_OPT_LDS_GROUPS_PER_CU: 1 or 2 workgroups of the LDS-resident rollout kernel per CU (default 2 when
    each still holds >= 12 instances). */
-enum { CMDP_OPT_ROLLOUT_KERNEL = 1, CMDP_OPT_DP_KERNEL = 2, CMDP_OPT_LDS_GROUPS_PER_CU = 3 };
+enum { CMDP_OPT_ROLLOUT_KERNEL = 1, CMDP_OPT_DP_KERNEL = 2, CMDP_OPT_LDS_GROUPS_PER_CU = 3,
+       CMDP_OPT_DIAMETER_WORKSPACE_MB = 4 };
 int cmdp_set_option(cmdp_t* h, int option, int64_t value);
 
 /* BaseMDP.get_visitation_counts / reset_visitation_counts (colosseum/mdp/base.py:1357-1382).
@@ -219,6 +223,13 @@ int cmdp_pe_episodic(cmdp_t* h, int H, const float* pi, const float* R_override,
    NULL.  scheme as in cmdp_vi_discounted (AUTO = the rule applied to the instance's T). */
 int cmdp_diameter(cmdp_t* h, double epsilon, int scheme, int64_t max_sweeps,
                   float* per_target, float* diameter);
+/* The per-target hitting-time solves of cmdp_diameter for the targets [target_lo, target_hi) of the flat state
+   space [0, state_off[B]) only (Jacobi scheme, kernel K5S; any instance size): per_target[i] belongs to target
+   target_lo + i.  This is how config C5 (one MDP with ~50 000 states) is split over GPUs: every rank takes a
+   contiguous range of targets and the diameter is the maximum over all ranks
+   (colosseum/hardness/measures/diameter.py:108-124 does the same with a process pool). */
+int cmdp_diameter_range(cmdp_t* h, double epsilon, int64_t max_sweeps, int64_t target_lo, int64_t target_hi,
+                        float* per_target);
 /* get_diameter, episodic setting (colosseum/hardness/measures/diameter.py:193-234,285-318) on the
    time-augmented transition array of get_episodic_transition_matrix_and_rewards
    (colosseum/mdp/utils/mdp_creation.py:98-128), which is never materialised: H, the starting states

@@ -535,3 +535,34 @@ def test_suboptimality_gaps_vs_reference(need_gpu):
         # every term 1/(gap + 0.1) amplifies a value difference by up to 1/0.1^2 = 100: values within 1e-6 (the
         # Gauss-Seidel path is not bit-reproducible against BLAS) => the sum within ~1e-5 relative
         assert g == pytest.approx(r["suboptimal_gaps"], rel=2e-5), r
+
+
+def test_diameter_lanes_kernel_equals_workgroup_kernel_and_oracle(need_gpu):
+    """K5S (64 targets per workgroup, value vectors in HBM -- what instances too large for LDS get, config C5) forced
+    on small instances: hitting times bit-equal to the LDS-resident Jacobi kernel and to the oracle; target ranges
+    (the multi-GPU split) reassemble to the full vector."""
+    ms = [make_model("FrozenLakeContinuous", seed=1, size=9, p_frozen=0.8),
+          make_model("MiniGridRoomsContinuous", seed=2, room_size=4, n_rooms=4, p_lazy=0.1),
+          make_model("DeepSeaContinuous", seed=3, size=11, p_rand=0.2)]
+    ms = [m for m in ms if m.n_actions == ms[0].n_actions] + [m for m in ms if m.n_actions != ms[0].n_actions]
+    by_A = {}
+    for m in ms:
+        by_A.setdefault(m.n_actions, []).append(m)
+    for A, group in by_A.items():
+        dp = BatchedMDP(group, with_env=False)
+        diam0, per0 = dp.diameter(1e-3, L.SCHEME_JACOBI)
+        dp.set_option(L.OPT_DP_KERNEL, 3)
+        dp.set_option(L.OPT_DIAMETER_WORKSPACE_MB, 1)  # several launches
+        diam1, per1 = dp.diameter(1e-3, L.SCHEME_JACOBI)
+        np.testing.assert_array_equal(per1, per0)
+        np.testing.assert_array_equal(diam1, diam0)
+        off = 0
+        for m in group:
+            _, oper = O.diameter_continuous(m.n_states, m.n_actions, m.csr(), scheme=1)
+            np.testing.assert_array_equal(per1[off:off + m.n_states], oper)
+            off += m.n_states
+        n = int(dp.state_off[-1])
+        cuts = sorted({0, min(5, n), min(64, n), min(70, n), n // 2, n})
+        parts = [dp.diameter_range(a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+        np.testing.assert_array_equal(np.concatenate(parts), per0)
+        dp.close()
