@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--eps", type=float, default=1e-3)
     ap.add_argument("--workspace-mb", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses device 0 (gloo backend)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -44,6 +45,8 @@ def main():
         import torch.distributed as dist
 
         dist.init_process_group(args.dist_backend)
+    if args.share_gpu:
+        local = 0
     L.check(L.load().cmdp_set_device(local))
     dp = BatchedMDP([m], with_env=False)
     if args.workspace_mb:
@@ -68,6 +71,7 @@ def main():
         ptr, col, val = m.csr()
         ok = True
         sweeps = []
+        t_or = time.time()
         for es in np.linspace(lo, hi - 1, args.check).astype(int):
             p2, c2, v2 = [0], [], []
             for s in range(S):
@@ -89,7 +93,8 @@ def main():
                               n_states=S, n_actions=A, nnz=int(len(m.csr()[1])), world=world, targets_this_rank=int(hi - lo),
                               build_s=round(t_build, 2), solve_s=round(t_solve, 3),
                               targets_per_s=round((hi - lo) / t_solve, 1), diameter=diameter, oracle_check=ok,
-                              oracle_sweeps=(sweeps if args.check else None))))
+                              oracle_sweeps=(sweeps if args.check else None),
+                              oracle_s_per_target=(round((time.time() - t_or) / args.check, 2) if args.check else None))))
     dp.close()
     if world > 1:
         dist.destroy_process_group()
