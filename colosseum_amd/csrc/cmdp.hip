@@ -115,7 +115,9 @@ struct cmdp {
   size_t lds_bytes = 0;
   DevBuf<float> d_gp_q, d_gp_p;  // cmdp_greedy_policy_episodic workspace
   // K5S workspace (large-instance diameter)
-  DevBuf<float> d_dl_v;
+  DevBuf<float> d_dl_v, d_ell_val;
+  DevBuf<int32_t> d_ell_col;
+  int ell_K = 0;
   DevBuf<int32_t> d_dl_inst, d_dl_t0, d_dl_cnt;
   DevBuf<int64_t> d_dl_voff;
   size_t dl_ws_bytes = (size_t)24 << 30;  // value arrays of the target groups in flight per launch
@@ -645,7 +647,7 @@ int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
     h->lds_bytes = (size_t)K1L_FIXED + (size_t)g * (h->lds_plan.slot_bytes + 2 * K1L_CH);
     return CMDP_OK;
   }
-  if (option == CMDP_OPT_DP_KERNEL && value >= 0 && value <= 3) {
+  if (option == CMDP_OPT_DP_KERNEL && value >= 0 && value <= 4) {
     h->dp_kernel = (int)value;
     return CMDP_OK;
   }
@@ -957,7 +959,30 @@ static int diameter_lanes(cmdp_t* h, DpTables t, int64_t unit_lo, int64_t unit_h
     HIP_TRY(h->d_dl_cnt.upload(cnt.data() + g0, n, st));
     HIP_TRY(h->d_dl_voff.upload(voff.data(), n, st));
     DiamLanesArgs g{h->d_dl_inst.p, h->d_dl_t0.p, h->d_dl_cnt.p, h->d_dl_voff.p, h->d_dl_v.p};
-    hipLaunchKernelGGL(k_diam_lanes<8>, dim3((unsigned)n), dim3(512), 0, st, t, g);
+    // fixed-width-row kernel when a compiled (A, K) shape fits; option value 4 keeps the generic CSR walker
+    const int A = h->A, K = h->max_row_nnz <= 2 ? 2 : (h->max_row_nnz <= 4 ? 4 : (h->max_row_nnz <= 8 ? 8 : 0));
+    bool ell = false;
+    if (K && h->dp_kernel != 4 && A >= 2 && A <= 4 && A * K <= 32) {
+      if (h->ell_K != K) {
+        const size_t rows_p = (size_t)h->n_rows + 64 / K + 1;
+        HIP_TRY(h->d_ell_col.alloc(rows_p * K));
+        HIP_TRY(h->d_ell_val.alloc(rows_p * K));
+        hipLaunchKernelGGL(k_build_ell, dim3(grid_for((int64_t)rows_p, 256)), dim3(256), 0, st, h->n_rows, K,
+                           h->d_csr_ptr.p, h->d_csr_col.p, h->d_csr_val.p, h->d_ell_col.p, h->d_ell_val.p);
+        HIP_TRY(hipGetLastError());
+        h->ell_K = K;
+      }
+      ell = true;
+#define ELL_CASE(AT, KT)                                                                                        \
+  if (A == AT && K == KT)                                                                                       \
+    hipLaunchKernelGGL((k_diam_lanes_ell<8, AT, KT>), dim3((unsigned)n), dim3(512), 0, st, t, g, h->d_ell_col.p, \
+                       h->d_ell_val.p);                                                                         \
+  else
+      ELL_CASE(2, 2) ELL_CASE(2, 4) ELL_CASE(2, 8) ELL_CASE(3, 2) ELL_CASE(3, 4) ELL_CASE(3, 8) ELL_CASE(4, 2)
+      ELL_CASE(4, 4) ELL_CASE(4, 8) { ell = false; }
+#undef ELL_CASE
+    }
+    if (!ell) hipLaunchKernelGGL(k_diam_lanes<8>, dim3((unsigned)n), dim3(512), 0, st, t, g);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));  // the upload staging vectors die at the end of this iteration
     g0 = g1;
@@ -982,7 +1007,7 @@ int cmdp_diameter(cmdp_t* h, double epsilon, int scheme, int64_t max_sweeps, flo
   t.gamma = 1.0f; t.eps = epsilon; t.max_abs = 0.0; t.max_sweeps = max_sweeps;
   t.Q = nullptr; t.V = nullptr; t.sweeps = nullptr; t.per_target = h->d_per_target.p; t.status = h->d_status.p;
   const size_t v_need = 2 * sizeof(float) * (size_t)h->max_S + sizeof(float) * 4 * (kDpBlock / 64);
-  const bool lanes = sch == CMDP_SCHEME_JACOBI && (h->dp_kernel == 3 || v_need > (size_t)kLdsBudget);
+  const bool lanes = sch == CMDP_SCHEME_JACOBI && (h->dp_kernel >= 3 || v_need > (size_t)kLdsBudget);
   if (lanes) {
     if (int rc = diameter_lanes(h, t, 0, NS)) return rc;
   } else if (int rc = run_sweeps(h, DP_VI, true, sch, t, NS)) return rc;

@@ -1391,3 +1391,134 @@ __global__ void __launch_bounds__(NW * 64) k_diam_lanes(DpTables t, DiamLanesArg
     t.status[soff + target] = status;
   }
 }
+
+
+// K5S, fixed-width rows.  The CSR rows are padded to K entries (column = the row's first column, coefficient +0.0:
+// acc + 0*V == acc exactly, as in K2R) and stored state-major, so the A*K entries of U = 64/(A*K) consecutive states
+// are ONE coalesced 64-lane load; every entry reaches the whole wave as a scalar through v_readlane.  A wave keeps
+// U states in flight: all U*A*K gathers (one 256-byte row each) are issued
+// before any of them is consumed, and the next chunk's entries are fetched meanwhile -- one memory round trip per U
+// states instead of three dependent ones per state.
+__global__ void __launch_bounds__(256) k_build_ell(int64_t n_rows, int K, const int64_t* __restrict__ ptr,
+                                                   const int32_t* __restrict__ col, const float* __restrict__ val,
+                                                   int32_t* __restrict__ ecol, float* __restrict__ eval_) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows + 64 / K + 1) return;  // tail padding so that a 64-entry load past the last state stays inside
+  if (r >= n_rows) {
+    for (int k = 0; k < K; ++k) { ecol[r * K + k] = 0; eval_[r * K + k] = 0.0f; }
+    return;
+  }
+  const int64_t lo = ptr[r], hi = ptr[r + 1];
+  const int32_t c0 = hi > lo ? col[lo] : 0;
+  for (int k = 0; k < K; ++k) {
+    const bool in = lo + k < hi;
+    ecol[r * K + k] = in ? col[lo + k] : c0;
+    eval_[r * K + k] = in ? val[lo + k] : 0.0f;
+  }
+}
+
+template <int NW, int A, int K>
+__global__ void __launch_bounds__(NW * 64) k_diam_lanes_ell(DpTables t, DiamLanesArgs g, const int32_t* __restrict__ ecol,
+                                                           const float* __restrict__ eval_) {
+  constexpr int AK = A * K, U = 64 / AK;
+  static_assert(U >= 1, "A*K must not exceed 64");
+  __shared__ float red_d[2][NW][64];
+  __shared__ float red_m[2][NW][64];
+  const int grp = blockIdx.x;
+  const int b = g.grp_inst[grp];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t soff = t.state_off[b];
+  const int S = (int)(t.state_off[b + 1] - soff);
+  const int32_t* ec = ecol + soff * AK;
+  const float* ev = eval_ + soff * AK;
+  const int target = g.grp_target0[grp] + lane;
+  const bool active = lane < g.grp_count[grp];
+  float* Vold = g.vbuf + g.grp_voff[grp];
+  float* Vnew = Vold + (int64_t)S * 64;
+  for (int64_t i = threadIdx.x; i < (int64_t)S * 128; i += NW * 64) Vold[i] = 0.0f;
+  __syncthreads();
+  // chunks of U states are dealt round-robin to the waves: the NW waves of the workgroup walk NW adjacent chunks at
+  // the same time, so the value rows neighbouring states share are fetched once and hit in L1/L2 for the others
+  const int s_begin = wave * U;
+  const int s_end = S;
+  constexpr int STRIDE = NW * U;
+
+  bool done = !active;
+  float result = 0.0f;
+  int status = active ? -5 : 0;
+  int64_t it = 0;
+  while (it < t.max_sweeps) {
+    ++it;
+    float dmax = 0.0f, vmin = 3.0e38f;
+    if (s_begin < s_end) {
+      // entries past the instance's last state belong to the next instance (or the tail padding): column 0 keeps
+      // their (discarded) gathers inside this group's value array
+      const int sl = lane / AK;
+      int ccol = (s_begin + sl < S) ? ec[(int64_t)s_begin * AK + lane] : 0;
+      float cval = ev[(int64_t)s_begin * AK + lane];
+      for (int s0 = s_begin; s0 < s_end; s0 += STRIDE) {
+        const int sn = (s0 + STRIDE < s_end) ? s0 + STRIDE : s0;  // next chunk (re-reads the current one at the very end)
+        const int ncol = (sn + sl < S) ? ec[(int64_t)sn * AK + lane] : 0;
+        const float nval = ev[(int64_t)sn * AK + lane];
+        float x[U * AK], vo[U];
+#pragma unroll
+        for (int e = 0; e < U * AK; ++e) {
+          const int c = __builtin_amdgcn_readlane(ccol, e);
+          x[e] = Vold[(int64_t)c * 64 + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int s = (s0 + u < s_end) ? s0 + u : s0;
+          vo[u] = Vold[(int64_t)s * 64 + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int s = s0 + u;
+          if (s < s_end) {
+            float v = 0.0f;
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+              float acc = 0.0f;
+#pragma unroll
+              for (int k = 0; k < K; ++k) {
+                const int e = (u * A + a) * K + k;
+                const float coef = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cval), e));
+                acc = __fadd_rn(acc, __fmul_rn(coef, x[e]));
+              }
+              const float q = __fadd_rn(-1.0f, __fmul_rn(t.gamma, acc));
+              v = (a == 0) ? q : fmaxf(v, q);
+            }
+            if (s == target) v = __fadd_rn(0.0f, __fmul_rn(t.gamma, __fadd_rn(0.0f, __fmul_rn(1.0f, vo[u]))));
+            Vnew[(int64_t)s * 64 + lane] = v;
+            dmax = fmaxf(dmax, fabsf(vo[u] - v));
+            vmin = fminf(vmin, v);
+          }
+        }
+        ccol = ncol;
+        cval = nval;
+      }
+    }
+    const int par = (int)(it & 1);
+    red_d[par][wave][lane] = dmax;
+    red_m[par][wave][lane] = vmin;
+    __syncthreads();
+    float diff = 0.0f, mn = 3.0e38f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      diff = fmaxf(diff, red_d[par][w][lane]);
+      mn = fminf(mn, red_m[par][w][lane]);
+    }
+    float* tmp = Vold; Vold = Vnew; Vnew = tmp;
+    if (!done && (double)diff < t.eps) {
+      done = true;
+      result = -mn;
+      status = 0;
+    }
+    if (__all(done)) break;
+  }
+  if (wave == 0 && active) {
+    t.per_target[soff + target] = result;
+    t.status[soff + target] = status;
+  }
+}

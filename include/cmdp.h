@@ -176,7 +176,8 @@ int cmdp_synchronize(cmdp_t* h);
    CMDP_OPT_DP_KERNEL (Jacobi sweeps): 0 = automatic, 1 = workgroup kernel with the CSR in LDS or HBM,
    2 = register-resident CSR kernel (CMDP_ERR_UNSUPPORTED when no compiled shape fits: A in 2..4, <= 8
    non-zeros per row, <= 1024 states), 3 = (cmdp_diameter only) the 64-targets-per-workgroup kernel K5S that is
-   otherwise taken when the value vector of an instance does not fit LDS.
+   otherwise taken when the value vector of an instance does not fit LDS (4 = the same with its generic CSR walker
+   instead of the fixed-width-row variant).
    CMDP_OPT_DIAMETER_WORKSPACE_MB: HBM the value arrays of K5S may take per launch (default 24576; 512 bytes per
    state per group of 64 targets; more groups in flight = more of the GPU busy).
    CMDP_OPT_LDS_GROUPS_PER_CU: 1 or 2 workgroups of the LDS-resident rollout kernel per CU (default 2 when

@@ -556,6 +556,9 @@ def test_diameter_lanes_kernel_equals_workgroup_kernel_and_oracle(need_gpu):
         diam1, per1 = dp.diameter(1e-3, L.SCHEME_JACOBI)
         np.testing.assert_array_equal(per1, per0)
         np.testing.assert_array_equal(diam1, diam0)
+        dp.set_option(L.OPT_DP_KERNEL, 4)  # generic CSR walker instead of the fixed-width-row variant
+        np.testing.assert_array_equal(dp.diameter(1e-3, L.SCHEME_JACOBI)[1], per0)
+        dp.set_option(L.OPT_DP_KERNEL, 3)
         off = 0
         for m in group:
             _, oper = O.diameter_continuous(m.n_states, m.n_actions, m.csr(), scheme=1)
