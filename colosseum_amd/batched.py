@@ -294,6 +294,18 @@ class BatchedMDP:
         L.check(self._lib.cmdp_diameter(self._h, epsilon, scheme, max_sweeps, L.ptr(per), L.ptr(diam)))
         return diam, per
 
+    def mixing_time(self, stationary, policy=None, threshold: float = 0.25, max_steps: int = 1_000_000):
+        """Build-defined (the reference has none): smallest t with max_s TV(P^t(s, .), stationary) <= threshold for the
+        chain of `policy` (per-instance [S_b, A] arrays; None = uniform).  stationary: per-instance float64 vectors.
+        Returns (t_mix int64 [B] (-1: not reached within max_steps), total variation at that step)."""
+        st = np.ascontiguousarray(np.concatenate([np.asarray(x, np.float64).ravel() for x in stationary]))
+        assert st.size == self.state_off[-1]
+        pi = None if policy is None else self._flat_rows(policy)
+        t = np.zeros(self.B, np.int64)
+        tv = np.zeros(self.B, np.float64)
+        L.check(self._lib.cmdp_mixing_time(self._h, L.ptr(pi), L.ptr(st), float(threshold), int(max_steps), L.ptr(t), L.ptr(tv)))
+        return t, tv
+
     def diameter_range(self, target_lo: int, target_hi: int, epsilon=1e-3, max_sweeps=1_000_000) -> np.ndarray:
         """Optimal expected hitting times (max over start states) of the targets [target_lo, target_hi) of the flat
         state space, Jacobi scheme, 64 targets per workgroup (kernel K5S): the shard of `diameter()` one GPU takes

@@ -1362,6 +1362,112 @@ int cmdp_qlearning_average_reward(cmdp_agent_t* a, const uint8_t* mask, double* 
   return chain_launch(h, a->d_pi.p, nullptr, h->d_cur.p, mask, avg, kind, nullptr);
 }
 
+int cmdp_mixing_time(cmdp_t* h, const float* pi, const double* stationary, double threshold, int64_t max_steps,
+                     int64_t* t_mix, double* tv_at) {
+  if (int rc = bind(h)) return rc;
+  if (!h->has_dp) return fail(CMDP_ERR_INVALID, "handle was created without the DP half");
+  if (!stationary || !t_mix) return fail(CMDP_ERR_INVALID, "null argument");
+  if (!(threshold > 0.0) || max_steps < 1) return fail(CMDP_ERR_INVALID, "threshold <= 0 or max_steps < 1");
+  if (sizeof(double) * (size_t)h->max_S > (size_t)kLdsBudget - 1024)
+    return fail(CMDP_ERR_UNSUPPORTED, "a row of X (%d states, float64) does not fit LDS", h->max_S);
+  hipStream_t st = h->stream;
+  const int B = h->B, A = h->A;
+  const int64_t NS = h->n_states, NR = h->n_rows;
+  std::vector<int64_t> ptr((size_t)NR + 1);
+  std::vector<int32_t> col((size_t)h->n_csr);
+  std::vector<float> val((size_t)h->n_csr);
+  HIP_TRY(hipMemcpyAsync(ptr.data(), h->d_csr_ptr.p, sizeof(int64_t) * ptr.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(col.data(), h->d_csr_col.p, sizeof(int32_t) * col.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(val.data(), h->d_csr_val.p, sizeof(float) * val.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  // P[s, j] = sum_a pi[s, a] * T[s, a, j] (float64, actions in order), then its CSC with predecessors in index order
+  std::vector<int64_t> cptr((size_t)NS + 1, 0), xoff((size_t)B + 1, 0);
+  std::vector<int32_t> crow;
+  std::vector<double> cval;
+  {
+    std::vector<std::vector<std::pair<int32_t, double>>> incoming((size_t)NS);
+    std::vector<double> rowacc;
+    std::vector<int32_t> touched;
+    for (int b = 0; b < B; ++b) {
+      const int64_t so = h->state_off[b], S = h->state_off[b + 1] - so;
+      xoff[b + 1] = xoff[b] + S * S;
+      rowacc.assign((size_t)S, 0.0);
+      for (int64_t s = 0; s < S; ++s) {
+        touched.clear();
+        for (int a = 0; a < A; ++a) {
+          const int64_t r = (so + s) * A + a;
+          const double w = pi ? (double)pi[r] : 1.0 / A;
+          if (w == 0.0) continue;
+          for (int64_t k = ptr[r]; k < ptr[r + 1]; ++k) {
+            if (rowacc[col[k]] == 0.0) touched.push_back(col[k]);
+            rowacc[col[k]] += w * (double)val[k];
+          }
+        }
+        for (int32_t j : touched) {
+          if (rowacc[j] != 0.0) incoming[(size_t)(so + j)].push_back({(int32_t)s, rowacc[j]});
+          rowacc[j] = 0.0;
+        }
+      }
+    }
+    for (int64_t j = 0; j < NS; ++j) {
+      cptr[j + 1] = cptr[j] + (int64_t)incoming[j].size();
+      for (auto& e : incoming[j]) { crow.push_back(e.first); cval.push_back(e.second); }  // s ascending by construction
+    }
+  }
+  constexpr int CH = 256;
+  DevBuf<int64_t> d_cptr, d_xoff;
+  DevBuf<int32_t> d_crow;
+  DevBuf<double> d_cval, d_stat, d_X, d_Xn;
+  DevBuf<unsigned long long> d_dl;
+  HIP_TRY(d_cptr.upload(cptr.data(), cptr.size(), st));
+  HIP_TRY(d_xoff.upload(xoff.data(), xoff.size(), st));
+  HIP_TRY(d_crow.upload(crow.data(), crow.size(), st));
+  HIP_TRY(d_cval.upload(cval.data(), cval.size(), st));
+  HIP_TRY(d_stat.upload(stationary, (size_t)NS, st));
+  HIP_TRY(d_X.alloc((size_t)xoff[B]));
+  HIP_TRY(d_Xn.alloc((size_t)xoff[B]));
+  HIP_TRY(d_dl.alloc((size_t)B * CH));
+  MixArgs m{};
+  m.B = B; m.state_off = h->d_state_off.p; m.x_off = d_xoff.p; m.csc_ptr = d_cptr.p; m.csc_row = d_crow.p;
+  m.csc_val = d_cval.p; m.stationary = d_stat.p; m.X = d_X.p; m.Xnew = d_Xn.p; m.dlist = d_dl.p; m.chunk = CH;
+  hipLaunchKernelGGL(k_mix_init, dim3((unsigned)NS), dim3(256), 0, st, m);
+  HIP_TRY(hipGetLastError());
+  const size_t lds = sizeof(double) * (size_t)h->max_S;
+  if (int rc = set_lds(k_mix_step, lds)) return rc;
+  std::vector<unsigned long long> dl((size_t)B * CH);
+  std::vector<char> found((size_t)B, 0);
+  for (int b = 0; b < B; ++b) { t_mix[b] = -1; if (tv_at) tv_at[b] = 0.0; }
+  int remaining = B;
+  for (int64_t t0 = 0; t0 < max_steps && remaining > 0; t0 += CH) {
+    const int n = (int)std::min<int64_t>(CH, max_steps - t0);
+    HIP_TRY(hipMemsetAsync(d_dl.p, 0, sizeof(unsigned long long) * dl.size(), st));
+    for (int k = 0; k < n; ++k) {
+      m.k = k;
+      hipLaunchKernelGGL(k_mix_step, dim3((unsigned)NS), dim3(256), lds, st, m);
+      std::swap(m.X, m.Xnew);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(dl.data(), d_dl.p, sizeof(unsigned long long) * dl.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int b = 0; b < B; ++b) {
+      if (found[b]) continue;
+      for (int k = 0; k < n; ++k) {
+        double tv;
+        std::memcpy(&tv, &dl[(size_t)b * CH + k], sizeof(double));
+        if (tv <= threshold) {
+          t_mix[b] = t0 + k + 1;  // X after (t0 + k + 1) steps
+          if (tv_at) tv_at[b] = tv;
+          found[b] = 1;
+          --remaining;
+          break;
+        }
+        if (tv_at) tv_at[b] = tv;
+      }
+    }
+  }
+  return CMDP_OK;
+}
+
 int cmdp_qlearning_destroy(cmdp_agent_t* a) {
   if (!a) return CMDP_OK;
   if (a->env) { (void)hipSetDevice(a->env->device); (void)hipStreamSynchronize(a->env->stream); }

@@ -410,3 +410,75 @@ __global__ void __launch_bounds__(NW * 64) k_chain_average_reward(ChainArgs c) {
     if (c.n_classes) c.n_classes[b] = n_attr;
   }
 }
+
+
+// ===================================================================================================
+// K10: mixing time of the chain of a stationary policy (BUILD-DEFINED: the reference has no mixing time; SURVEY
+// section 8 f2 defines it as the smallest t with max_s TV(P^t(s, .), pi) <= threshold, threshold 1/4).
+// X_t[s, :] = distribution after t steps from state s (X_0 = I), float64, one workgroup per (instance, start state):
+// the row of X_t sits in LDS, column j gathers its predecessors through the CSC of P (index order), the total
+// variation to the stationary distribution is block-reduced and max-reduced over the start states with an integer
+// atomicMax on the bit pattern (non-negative doubles order like their bits).
+// ===================================================================================================
+struct MixArgs {
+  int32_t B;
+  const int64_t* state_off;  // [B+1]
+  const int64_t* x_off;      // [B+1] prefix of S_b^2
+  const int64_t* csc_ptr;    // [NSTATES+1] global offsets, column = flat state index
+  const int32_t* csc_row;    // instance-relative predecessor
+  const double* csc_val;
+  const double* stationary;  // [NSTATES]
+  double* X;
+  double* Xnew;
+  unsigned long long* dlist; // [B][chunk] bit patterns of max_s TV
+  int32_t chunk, k;
+};
+
+__global__ void __launch_bounds__(256) k_mix_init(MixArgs m) {
+  int lo = 0, hi = m.B;
+  const int64_t unit = blockIdx.x;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (m.state_off[mid] <= unit) lo = mid; else hi = mid;
+  }
+  const int b = lo;
+  const int S = (int)(m.state_off[b + 1] - m.state_off[b]);
+  const int s = (int)(unit - m.state_off[b]);
+  double* x = m.X + m.x_off[b] + (int64_t)s * S;
+  for (int j = threadIdx.x; j < S; j += blockDim.x) x[j] = (j == s) ? 1.0 : 0.0;
+}
+
+__global__ void __launch_bounds__(256) k_mix_step(MixArgs m) {
+  extern __shared__ double mix_xs[];
+  __shared__ double red[4];
+  int lo = 0, hi = m.B;
+  const int64_t unit = blockIdx.x;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (m.state_off[mid] <= unit) lo = mid; else hi = mid;
+  }
+  const int b = lo;
+  const int64_t soff = m.state_off[b];
+  const int S = (int)(m.state_off[b + 1] - soff);
+  const int s = (int)(unit - soff);
+  const double* x = m.X + m.x_off[b] + (int64_t)s * S;
+  double* xn = m.Xnew + m.x_off[b] + (int64_t)s * S;
+  for (int i = threadIdx.x; i < S; i += 256) mix_xs[i] = x[i];
+  __syncthreads();
+  double part = 0.0;
+  for (int j = threadIdx.x; j < S; j += 256) {
+    double acc = 0.0;
+    for (int64_t k = m.csc_ptr[soff + j]; k < m.csc_ptr[soff + j + 1]; ++k)
+      acc = __dadd_rn(acc, __dmul_rn(mix_xs[m.csc_row[k]], m.csc_val[k]));
+    xn[j] = acc;
+    part += fabs(acc - m.stationary[soff + j]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tv = 0.5 * (((red[0] + red[1]) + red[2]) + red[3]);
+    atomicMax(m.dlist + (int64_t)b * m.chunk + m.k, (unsigned long long)__double_as_longlong(tv));
+  }
+}

@@ -96,3 +96,43 @@ def value_norm(models: Sequence[TabularModel]) -> np.ndarray:
         for j, v in zip(js, vn):
             out[owner[j]] = v
     return out
+
+
+def mixing_time(models: Sequence[TabularModel], policies=None, threshold: float = 0.25, max_steps: int = 1_000_000):
+    """BUILD-DEFINED hardness measure (the reference has no mixing time, parity unpinned): for the
+    chain of `policies[i]` ([S, A] action probabilities; default the uniform policy) on `models[i]`, the smallest t with
+    max_s TV(P^t(s, .), pi) <= threshold, where pi is the stationary distribution of the chain's single recurrent class
+    (GTH kernel).  Returns (t_mix, tv): t_mix = -1 when the chain has several recurrent classes or does not get below
+    the threshold within max_steps (periodic chains)."""
+    from ..markov_chain import gth_batch, recurrent_classes
+
+    n = len(models)
+    t_out = np.full(n, -1, np.int64)
+    tv_out = np.full(n, np.nan)
+    groups = {}
+    for i, m in enumerate(models):
+        groups.setdefault(m.n_actions, []).append(i)
+    for A, idx in groups.items():
+        stats, keep, pols = [], [], []
+        for i in idx:
+            m = models[i]
+            T, _ = m.dense()
+            pol = np.full((m.n_states, A), 1.0 / A, np.float32) if policies is None else np.asarray(policies[i], np.float32)
+            P = np.einsum("saj,sa->sj", T.astype(np.float64), pol.astype(np.float64))
+            classes = recurrent_classes(P)
+            if len(classes) != 1:
+                continue
+            cls = classes[0]
+            sd = np.zeros(m.n_states)
+            sd[cls] = np.ones(1) if len(cls) == 1 else gth_batch([P[np.ix_(cls, cls)]])[0]
+            stats.append(sd)
+            keep.append(i)
+            pols.append(pol)
+        if not keep:
+            continue
+        dp = BatchedMDP([models[i] for i in keep], with_env=False)
+        t, tv = dp.mixing_time(stats, None if policies is None else pols, threshold, max_steps)
+        dp.close()
+        t_out[keep] = t
+        tv_out[keep] = tv
+    return t_out, tv_out

@@ -287,6 +287,13 @@ int cmdp_greedy_policy_episodic(cmdp_t* h, int H, int q_layers, const float* Q, 
 int cmdp_qlearning_tables(cmdp_agent_t* a, float* Q, int32_t* N);
 
 /* ---- Markov chains ------------------------------------------------------------------------------------ */
+/* BUILD-DEFINED (the reference has no mixing time): t_mix[b] = smallest t >= 1 with
+   max_s TV(P^t(s, .), stationary) <= threshold for the chain P[s, j] = sum_a pi[s, a] T[s, a, j] of instance b
+   (pi [state_off[B]*A] float32, NULL = the uniform policy; stationary [state_off[B]] float64, e.g. from cmdp_gth),
+   float64 on the device; -1 when max_steps is reached first (periodic chains never get there).  tv_at [B] (may be
+   NULL) receives the total variation at t_mix (or after the last step taken).  Parity unpinned by construction. */
+int cmdp_mixing_time(cmdp_t* h, const float* pi, const double* stationary, double threshold, int64_t max_steps,
+                     int64_t* t_mix, double* tv_at);
 /* get_average_reward (colosseum/mdp/utils/markov_chain.py:12-31) of deterministic stationary policies: actions
    [state_off[B]] gives the action of every state of every (continuous, horizon 0) instance, start_states [B] the
    instance-relative state the chain starts from.  Outputs as cmdp_qlearning_average_reward; n_classes [B] (may be

@@ -59,3 +59,33 @@ def test_average_reward_kernel_matches_host_restatement(need_gpu, cls, kw):
     env.close()
     if cls.startswith("MiniGrid"):  # turning on the spot for ever: random policies split the grid into many classes
         assert multi >= 4
+
+
+def test_mixing_time_against_dense_float64_powers(need_gpu):
+    """Build-defined measure (no reference counterpart): the device evolution X_{t+1} = X_t P with the TV test must
+    give the t and the total variation of a plain numpy float64 evaluation; a periodic chain reports -1."""
+    from colosseum_amd.hardness import mixing_time
+    from colosseum_amd.markov_chain import gth_batch
+
+    ms = [make_model("FrozenLakeContinuous", seed=3, size=5, p_frozen=0.8),
+          make_model("MiniGridEmptyContinuous", seed=4, size=5, n_starting_states=2, p_lazy=0.2),
+          make_model("FrozenLakeContinuous", seed=6, size=8, p_frozen=0.9),
+          make_model("DeepSeaContinuous", seed=1, size=6)]       # period = size under any policy
+    t, tv = mixing_time(ms, threshold=0.25, max_steps=3000)
+    for i, m in enumerate(ms):
+        T, _ = m.dense()
+        P = T.astype(np.float64).mean(1)
+        if i == 3:
+            assert t[i] == -1
+            continue
+        sd = gth_batch([P])[0]
+        X = np.eye(m.n_states)
+        want = None
+        for step in range(1, 3001):
+            X = X @ P
+            d = 0.5 * np.abs(X - sd).sum(1).max()
+            if d <= 0.25:
+                want = (step, d)
+                break
+        assert want is not None and t[i] == want[0], (i, t[i], want)
+        assert tv[i] == pytest.approx(want[1], rel=1e-10)
