@@ -9,6 +9,9 @@ the reward-distribution rule.  Reference anchors:
   FrozenLake     colosseum/mdp/frozen_lake/base.py:145-182,285-311
   MiniGridEmpty  colosseum/mdp/minigrid_empty/base.py:153-235
   MiniGridRooms  colosseum/mdp/minigrid_rooms/base.py:165-269
+  RiverSwim      colosseum/mdp/river_swim/base.py:152-284          
+  SimpleGrid     colosseum/mdp/simple_grid/base.py:172-268,300-414
+  Taxi           colosseum/mdp/taxi/base.py:124-199,229-330,380-494
 
 Reward distributions are ("deterministic", loc) or ("beta", a, b) tuples, the two
 kinds the reference constructs (colosseum/utils/miscellanea.py:253-270).
@@ -347,3 +350,259 @@ class MiniGridRooms(_MiniGrid):
         if nc in self.admissible:
             return (((nc[0], nc[1], d), 1.0),)
         return ((node, 1.0),)
+
+
+# ------------------------------------------------------------------------------------------------------
+def _three_dists(given, stochastic, betas, deterministic):
+    """The families' common rule: all three distributions given -> taken as they are; otherwise Beta parameters
+    when make_reward_stochastic, else the family's deterministic defaults."""
+    assert given.count(None) in (0, 3)
+    if given.count(None) == 0:
+        return tuple(_dist(d) for d in given)
+    if stochastic:
+        return tuple(("beta", float(a), float(b)) for a, b in betas)
+    return tuple(("deterministic", float(v)) for v in deterministic)
+
+
+class RiverSwim(Family):
+    """river_swim/base.py.  Node = (X,); actions LEFT=0, RIGHT=1; the chain is deterministic, its stochasticity is the
+    base class's p_rand / p_lazy."""
+
+    name = "RiverSwim"
+    n_actions = 2
+
+    def __init__(self, size, optimal_mean_reward=0.9, sub_optimal_mean_reward=0.2, sub_optimal_distribution=None,
+                 optimal_distribution=None, other_distribution=None, make_reward_stochastic=False,
+                 reward_variance_multiplier=1.0, episodic=False):
+        assert size > 1 and optimal_mean_reward - 0.1 > sub_optimal_mean_reward  # :262-263 (on the given means)
+        self.size = size
+        m = reward_variance_multiplier
+        sub_mean = sub_optimal_mean_reward / size if episodic else sub_optimal_mean_reward  # :214-215
+        self.sub, self.opt, self.other = _three_dists(
+            [sub_optimal_distribution, optimal_distribution, other_distribution], make_reward_stochastic,
+            [(m, m * (1 / sub_mean - 1)), (m, m * (1 / optimal_mean_reward - 1)), (m, m * (10 / sub_mean - 1))],
+            [5 / 1000, 1.0, 0.0])
+
+    def possible_starting_nodes(self):
+        return [(0,)]
+
+    def start(self, rng, fast_rng):
+        return StartSpec(self.possible_starting_nodes(), None, False)
+
+    def next_nodes(self, node, action):
+        x = node[0]
+        return (((min(x + 1, self.size - 1) if action == 1 else max(x - 1, 0),), 1.0),)
+
+    def reward_dist(self, node, action, next_node):
+        if node[0] == self.size - 1 and action == 1:
+            return self.opt
+        return self.sub if node[0] == 0 and action == 0 else self.other
+
+
+class SimpleGrid(Family):
+    """simple_grid/base.py.  Node = (X, Y); actions UP, RIGHT, DOWN, LEFT, NO_OP; the corners' self-loops carry the
+    AND / NAND / OR / XOR reward."""
+
+    name = "SimpleGrid"
+    n_actions = 5
+    AND, NAND, OR, XOR = 0, 1, 2, 3
+
+    def __init__(self, size, reward_type=3, n_starting_states=1, optimal_mean_reward=0.9, sub_optimal_mean_reward=0.2,
+                 optimal_distribution=None, sub_optimal_distribution=None, other_distribution=None,
+                 make_reward_stochastic=False, reward_variance_multiplier=1.0):
+        assert n_starting_states <= (size - 1) ** 2 and optimal_mean_reward - 0.1 > sub_optimal_mean_reward
+        self.size, self.reward_type, self.n_starting_states = size, int(reward_type), n_starting_states
+        m = reward_variance_multiplier
+        self.sub, self.opt, self.other = _three_dists(
+            [sub_optimal_distribution, optimal_distribution, other_distribution], make_reward_stochastic,
+            [(m, m * (10 / sub_optimal_mean_reward - 1)), (m, m * (1 / optimal_mean_reward - 1)),
+             (m, m * (1 / sub_optimal_mean_reward - 1))],
+            [0.0, 1.0, 0.5])
+
+    def _starting_nodes_by_distance(self, rng):
+        """`_calculate_starting_nodes` (:225-241): cells by distance from the centre, ties in np.where order, only the
+        innermost batch shuffled."""
+        n = self.size
+        center = np.array(((n - 1) / 2, (n - 1) / 2))
+        distances = np.empty((n, n))
+        for x in range(n):
+            for y in range(n):
+                distances[x, y] = ((np.array((x, y)) - center) ** 2).sum()
+        batch = np.array(np.where(distances == distances.min())).T.tolist()
+        rng.shuffle(batch)
+        while not np.all(distances == np.inf):
+            distances[batch[0][0], batch[0][1]] = np.inf
+            yield batch[0]
+            batch.pop(0)
+            if len(batch) == 0:
+                batch = np.array(np.where(distances == distances.min())).T.tolist()
+
+    def start(self, rng, fast_rng):
+        it = self._starting_nodes_by_distance(rng)
+        self._possible = [tuple(int(v) for v in next(it)) for _ in range((self.size - 1) ** 2)]
+        chosen = self._possible[: self.n_starting_states]
+        rng.shuffle(chosen)
+        if len(chosen) == 1:
+            return StartSpec(chosen, None, False)
+        return StartSpec(chosen, [1 / self.n_starting_states for _ in range(self.n_starting_states)], True)
+
+    def possible_starting_nodes(self):
+        return list(self._possible)
+
+    def next_nodes(self, node, action):
+        x, y = node
+        n = self.size
+        if action == 0:
+            return (((x, min(y + 1, n - 1)), 1.0),)
+        if action == 1:
+            return (((min(x + 1, n - 1), y), 1.0),)
+        if action == 2:
+            return (((x, max(y - 1, 0)), 1.0),)
+        if action == 3:
+            return (((max(x - 1, 0), y), 1.0),)
+        return (((x, y), 1.0),)
+
+    def reward_dist(self, node, action, next_node):
+        x, y = node
+        corner = node == next_node and x in (0, self.size - 1) and y in (0, self.size - 1)
+        if not corner:
+            return self.other
+        t = self.reward_type
+        good = ((t == self.AND and (x and y)) or (t == self.NAND and not (x and y)) or (t == self.OR and (x | y))
+                or (t == self.XOR and (x ^ y)))
+        return self.opt if good else self.sub
+
+
+class Taxi(Family):
+    """taxi/base.py.  Node = (X, Y, XPass, YPass, XDest, YDest); actions South, North, East, West, PickUp, DropOff.
+    The reference forces randomize_actions=False for this family (:488-490)."""
+
+    name = "Taxi"
+    n_actions = 6
+    force_randomize_actions = False
+
+    def __init__(self, size, length=2, width=1, space=1, n_locations=2 ** 2, optimal_mean_reward=0.9,
+                 sub_optimal_mean_reward=0.2, default_r=None, successfully_delivery_r=None, failure_delivery_r=None,
+                 make_reward_stochastic=False, reward_variance_multiplier=1.0, episodic=False):
+        self.size, self.length, self.width, self.space = size, length, width, space
+        self.n_locations_arg = n_locations
+        self.n_locations = int(np.ceil(n_locations ** 0.5) ** 2)
+        m = reward_variance_multiplier
+        self.default_r, self.success_r, self.failure_r = _three_dists(
+            [default_r, successfully_delivery_r, failure_delivery_r], make_reward_stochastic,
+            [(m, m * (1 / sub_optimal_mean_reward - 1)), (m, m * (1 / optimal_mean_reward - 1)),
+             (m, m * (10 / sub_optimal_mean_reward - 1))],
+            [0.1, 1, 0])
+        assert dist_mean(self.failure_r) < dist_mean(self.default_r) < dist_mean(self.success_r)  # :349-353
+        assert size > 3 and n_locations > (1 if episodic else 2)
+        assert size > length and size > width and size > space / 2 and size > 2 * n_locations ** 0.5
+        assert optimal_mean_reward - 0.1 > sub_optimal_mean_reward
+        self.admissible = self._admissible_coordinate()
+        self._adm_set = {tuple(c) for c in self.admissible}
+        self._locations = None
+
+    def _admissible_coordinate(self):
+        """:128-155, the wall pattern; cells with 0 are free."""
+        n, rows, j = self.size, [], 0
+        while len(rows) < n:
+            row = [] if j % 2 != 0 else [0] * int((self.width + self.space) // 2)
+            i = 0
+            while len(row) < n:
+                row.append(int(i % (1 + self.space) == 0))
+                if row[-1] == 1:
+                    for _ in range(self.width - 1):
+                        if len(row) == n:
+                            break
+                        row.append(1)
+                i += 1
+            for _ in range(self.length):
+                if len(rows) == n:
+                    break
+                rows.append(row)
+            if len(rows) < n:
+                rows.append([0] * n)
+            j += 1
+        return np.vstack(np.where(np.array(rows) == 0)).T.tolist()
+
+    def _quadrants(self):
+        n, k = self.size, int(self.n_locations ** 0.5)
+        quadrants = np.zeros((n, n))
+        split = np.array_split(range(n), k)
+        for i, (xs, ys) in enumerate(product(split, split)):
+            for qx, qy in product(xs, ys):
+                quadrants[qx, qy] = i
+        out = [[c for c in np.vstack(np.where(quadrants == i)).T.tolist() if tuple(c) in self._adm_set]
+               for i in range(self.n_locations)]
+        assert all(len(q) != 0 for q in out)
+        return out
+
+    def locations(self, rng):
+        """:181-199: one location per quadrant, re-drawn until all are further apart than the quadrant width, then
+        shuffled and cut to the requested number."""
+        if self._locations is None:
+            quadrants = self._quadrants()
+            min_distance = max(self.size / int(self.n_locations ** 0.5) / 2, 2)
+            while True:
+                locs = [quadrants[i][rng.randint(len(quadrants[i]))] for i in range(self.n_locations)]
+                npl = np.array(locs)
+                again = False
+                for i in range(self.n_locations):
+                    for j in range(1 + i, self.n_locations):
+                        if np.sqrt(((npl[i] - npl[j]) ** 2).sum()) <= min_distance:
+                            again = True
+                            break
+                    if again:
+                        break
+                if not again:
+                    break
+            rng.shuffle(locs)
+            self._locations = [tuple(int(v) for v in c) for c in locs[: self.n_locations_arg]]
+        return self._locations
+
+    def start(self, rng, fast_rng):
+        locs = self.locations(rng)
+        nodes = []
+        for (px, py), (dx, dy), (tx, ty) in product(locs, locs, self.admissible):
+            if (px, py) == (dx, dy):
+                continue
+            nodes.append((int(tx), int(ty), px, py, dx, dy))
+        rng.shuffle(nodes)
+        self._start_nodes = nodes
+        return StartSpec(nodes, [1 / len(nodes) for _ in nodes], True)
+
+    def possible_starting_nodes(self):
+        return list(self._start_nodes)
+
+    def next_nodes(self, node, action):
+        x, y, xp, yp, xd, yd = node
+        locs = self._locations
+        if action == 5 and xp == -1 and x == xd and y == yd:
+            # successful drop-off: a new passenger anywhere but here, a destination anywhere but at the passenger
+            pairs = [(pl, de) for pl in locs if pl != (x, y) for de in locs if de != pl]
+            p = 1.0 / len(pairs)
+            return tuple(((x, y, pl[0], pl[1], de[0], de[1]), p) for pl, de in pairs)
+        if action == 4 and xp != -1 and x == xp and y == yp:
+            xp, yp = -1, -1
+        if action == 1:
+            nc = (x, y + 1)
+        elif action == 2:
+            nc = (x + 1, y)
+        elif action == 0:
+            nc = (x, y - 1)
+        elif action == 3:
+            nc = (x - 1, y)
+        else:
+            nc = (x, y)
+        if nc in self._adm_set:
+            x, y = nc
+        return (((x, y, xp, yp, xd, yd), 1.0),)
+
+    def reward_dist(self, node, action, next_node):
+        if action == 4 and (next_node[2] != -1 or node[2] == -1):
+            return self.failure_r
+        if action == 5:
+            if next_node[2] == -1 or node[2] != -1:
+                return self.failure_r
+            if node[2] == -1 and next_node[2] != -1:
+                return self.success_r
+        return self.default_r

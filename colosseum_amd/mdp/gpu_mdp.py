@@ -295,3 +295,9 @@ MiniGridEmptyEpisodic = _make_class("MiniGridEmptyEpisodic")
 MiniGridEmptyContinuous = _make_class("MiniGridEmptyContinuous")
 MiniGridRoomsEpisodic = _make_class("MiniGridRoomsEpisodic")
 MiniGridRoomsContinuous = _make_class("MiniGridRoomsContinuous")
+RiverSwimEpisodic = _make_class("RiverSwimEpisodic")
+RiverSwimContinuous = _make_class("RiverSwimContinuous")
+SimpleGridEpisodic = _make_class("SimpleGridEpisodic")
+SimpleGridContinuous = _make_class("SimpleGridContinuous")
+TaxiEpisodic = _make_class("TaxiEpisodic")
+TaxiContinuous = _make_class("TaxiContinuous")

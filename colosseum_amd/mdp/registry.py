@@ -6,7 +6,7 @@ configuration written for the reference can be fed here unchanged."""
 from typing import Any, Dict
 
 from .builder import TabularModel, build_model
-from .families import DeepSea, FrozenLake, MiniGridEmpty, MiniGridRooms
+from .families import DeepSea, FrozenLake, MiniGridEmpty, MiniGridRooms, RiverSwim, SimpleGrid, Taxi
 
 _BASE_KEYS = ("randomize_actions", "p_lazy", "p_rand", "rewards_range")
 _IGNORED = ("emission_map", "emission_map_kwargs", "noise", "noise_kwargs", "instantiate_mdp",
@@ -17,6 +17,9 @@ FAMILIES = {
     "FrozenLake": FrozenLake,
     "MiniGridEmpty": MiniGridEmpty,
     "MiniGridRooms": MiniGridRooms,
+    "RiverSwim": RiverSwim,
+    "SimpleGrid": SimpleGrid,
+    "Taxi": Taxi,
 }
 
 
@@ -46,8 +49,12 @@ def make_model(cls_name: str, **kwargs: Any) -> TabularModel:
         H = kw["size"]  # deep_sea/finite_horizon.py:28-36
     if fam_name == "FrozenLake":
         family = FrozenLake(seed=seed, **kw)
+    elif fam_name in ("RiverSwim", "Taxi"):  # their reward defaults / checks depend on the setting
+        family = FAMILIES[fam_name](episodic=episodic, **kw)
     else:
         family = FAMILIES[fam_name](**kw)
+    if getattr(family, "force_randomize_actions", None) is not None:
+        base["randomize_actions"] = family.force_randomize_actions  # taxi/base.py:488-490
     model = build_model(family, seed, episodic, H=H, **base)
     model.extra["family"] = family
     model.extra["cls_name"] = cls_name

@@ -21,6 +21,7 @@ Fixture groups:
   G5  hardness known-answer table lifted from benchmark/cached_hardness_measures/*.txt
   G6  episodic/continuous diameter + value-norm recomputed by the reference here (small cases)
   G7  MDPLoop + QLearningEpisodic logger rows and action stream (config C1, plumbing)
+  G12 RiverSwim / SimpleGrid / Taxi: structure, DP values, trajectories
   G10 MDPLoop + QLearningContinuous logger rows (continuous-setting regret via stationary distributions)
   G9  stationary distributions / average rewards of the continuous setting
   G8  trajectories with Beta rewards (the MDP's numpy stream, 5000-sample caches per visited triple)
@@ -45,6 +46,9 @@ from colosseum.mdp.deep_sea import DeepSeaContinuous, DeepSeaEpisodic  # noqa: E
 from colosseum.mdp.frozen_lake import FrozenLakeContinuous, FrozenLakeEpisodic  # noqa: E402
 from colosseum.mdp.minigrid_empty import MiniGridEmptyContinuous, MiniGridEmptyEpisodic  # noqa: E402
 from colosseum.mdp.minigrid_rooms import MiniGridRoomsContinuous, MiniGridRoomsEpisodic  # noqa: E402
+from colosseum.mdp.river_swim import RiverSwimContinuous, RiverSwimEpisodic  # noqa: E402
+from colosseum.mdp.simple_grid import SimpleGridContinuous, SimpleGridEpisodic  # noqa: E402
+from colosseum.mdp.taxi import TaxiContinuous, TaxiEpisodic  # noqa: E402
 
 ref_config.disable_multiprocessing()
 
@@ -59,6 +63,12 @@ CLASSES = {
         MiniGridEmptyEpisodic,
         MiniGridRoomsContinuous,
         MiniGridRoomsEpisodic,
+        RiverSwimContinuous,
+        RiverSwimEpisodic,
+        SimpleGridContinuous,
+        SimpleGridEpisodic,
+        TaxiContinuous,
+        TaxiEpisodic,
     )
 }
 
@@ -686,7 +696,47 @@ def g11():
         json.dump(out, f, indent=0)
 
 
-GROUPS = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11)
+
+def g12():
+    specs = [
+        ("RiverSwimContinuous", dict(seed=0, size=10, p_rand=0.1, p_lazy=0.05)),
+        ("RiverSwimContinuous", dict(seed=3, size=25, p_rand=0.3, randomize_actions=False)),
+        ("RiverSwimEpisodic", dict(seed=1, size=6, p_lazy=0.2)),
+        ("RiverSwimEpisodic", dict(seed=2, size=8, p_rand=0.05, make_reward_stochastic=True, reward_variance_multiplier=2.0)),
+        ("SimpleGridContinuous", dict(seed=0, size=5, n_starting_states=3, p_rand=0.1)),
+        ("SimpleGridContinuous", dict(seed=4, size=8, reward_type=0, n_starting_states=1, p_lazy=0.1)),
+        ("SimpleGridContinuous", dict(seed=5, size=6, reward_type=2, n_starting_states=4, p_rand=0.2, p_lazy=0.1)),
+        ("SimpleGridEpisodic", dict(seed=2, size=4, reward_type=1, n_starting_states=2)),
+        ("TaxiContinuous", dict(seed=0, size=5, p_rand=0.05)),
+        ("TaxiContinuous", dict(seed=7, size=6, p_lazy=0.1)),
+        ("TaxiEpisodic", dict(seed=3, size=5, p_rand=0.1)),
+    ]
+    cases = []
+    arrays = {}
+    for cls, kw in specs:
+        mdp = CLASSES[cls](**kw)
+        key = f"c{len(cases)}_"
+        st = structure(mdp)
+        st.pop("T_idx"), st.pop("T_val")  # implied by the sampler tables; Taxi's would dominate the file
+        arrays.update(flat(key, st))
+        dv = dp_values(mdp)
+        for k in ("V_opt", "V_rand"):
+            if k in dv:
+                arrays[key + k] = dv[k]
+        acts = np.random.RandomState(500 + len(cases)).randint(0, mdp.n_actions, 6000)
+        tr = trajectory(mdp, acts)
+        tr["actions"] = tr["actions"].astype(np.int8)
+        tr["obs"] = tr["obs"].astype(np.int16)
+        tr["state"] = tr["state"].astype(np.int16)
+        tr.pop("visits_sa")
+        arrays.update(flat(key, tr))
+        cases.append(dict(cls=cls, kwargs=kw, extra={}))
+        print("   ", cls, kw, "S=", mdp.n_states, "H=", mdp.H if mdp.is_episodic() else 0)
+    arrays["cases"] = np.array(json.dumps(cases))
+    save("G12_families", **arrays)
+
+
+GROUPS = dict(G12=g12, G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

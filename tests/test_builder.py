@@ -9,7 +9,7 @@ from colosseum_amd.mdp import make_model
 from colosseum_amd.mdp.fast_batch import deepsea_episodic_tables
 
 
-@pytest.mark.parametrize("name", ["G1_deepsea8", "G2_deepsea30", "G3_stochastic", "G4_frozenlake20_vi"])
+@pytest.mark.parametrize("name", ["G1_deepsea8", "G2_deepsea30", "G3_stochastic", "G4_frozenlake20_vi", "G12_families"])
 def test_structure_matches_reference(name):
     z, cases = load_golden(name)
     for i, c in enumerate(cases):
@@ -44,7 +44,13 @@ def test_first_samples_of_every_sampler_match_reference():
     reference's cached_states (custom_samplers.py:55-57)."""
     import random
 
-    z, cases = load_golden("G3_stochastic")
+    for name in ("G3_stochastic", "G12_families"):
+        _check_first_samples(*load_golden(name))
+
+
+def _check_first_samples(z, cases):
+    import random
+
     for i, c in enumerate(cases):
         m = make_model(c["cls"], **c["kwargs"])
         first = z[f"c{i}_sp_first"]
@@ -76,7 +82,7 @@ def test_constructor_checks():
     with pytest.raises(AssertionError):
         make_model("DeepSeaEpisodic", seed=0, size=5, p_lazy=0.1)  # no lazy mechanic for DeepSea
     with pytest.raises(KeyError):
-        make_model("TaxiEpisodic", seed=0, size=5)
+        make_model("CustomEpisodic", seed=0, size=5)  # CustomMDP is not built
     with pytest.raises(NotImplementedError):
         make_model("DeepSeaEpisodic", seed=0)
 

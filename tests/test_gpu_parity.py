@@ -46,10 +46,16 @@ def test_trajectories_vs_reference_batched(need_gpu, name):
 def test_trajectories_stochastic_mt_compat(need_gpu):
     """Stochastic dynamics: per-(s,a) MT19937 streams on the device reproduce the reference draw for draw
     (12 000 steps, crossing the reference's 5000-sample refills).  Ragged: one handle per case."""
-    z, cases = load_golden("G3_stochastic")
+    for name in ("G3_stochastic", "G12_families"):
+        _check_mt_compat_trajectories(*load_golden(name))
+
+
+def _check_mt_compat_trajectories(z, cases):
     for i, c in enumerate(cases):
         k = f"c{i}_"
         m = make_model(c["cls"], **c["kwargs"])
+        if not m.deterministic_rewards:  # Beta rewards: host sampler, tests/test_rewards.py
+            continue
         env = BatchedMDP([m], rng_mode=L.RNG_MT_COMPAT, with_dp=False)
         first = env.reset()
         acts = z[k + "actions"][:, None]
@@ -60,7 +66,8 @@ def test_trajectories_stochastic_mt_compat(need_gpu):
         np.testing.assert_array_equal(out["rew"][:, 0], z[k + "rew"])
         np.testing.assert_array_equal(out["stype"][:, 0], z[k + "stype"])
         np.testing.assert_array_equal(vs, z[k + "visits_s"])
-        np.testing.assert_array_equal(vsa.reshape(-1, env.A), z[k + "visits_sa"])
+        if k + "visits_sa" in z:
+            np.testing.assert_array_equal(vsa.reshape(-1, env.A), z[k + "visits_sa"])
         env.close()
 
 
@@ -268,11 +275,11 @@ def test_register_resident_sweeps_equal_workgroup_kernel_and_oracle(need_gpu):
 
 
 def test_episodic_dp_vs_reference(need_gpu):
-    for name in ("G1_deepsea8", "G3_stochastic"):
+    for name in ("G1_deepsea8", "G3_stochastic", "G12_families"):
         z, cases = load_golden(name)
         for i, c in enumerate(cases):
             k = f"c{i}_"
-            if k + "Q_opt" not in z:
+            if k + "V_opt" not in z:
                 continue
             m = make_model(c["cls"], **c["kwargs"])
             S, A, H = m.n_states, m.n_actions, m.H
@@ -282,11 +289,13 @@ def test_episodic_dp_vs_reference(need_gpu):
             pi = np.ones((H, S, A), np.float32) / A
             Qr, Vr = dp.episodic_policy_evaluation([pi, pi])
             for b in range(2):
-                np.testing.assert_allclose(dp.split_rows(Q, H + 1)[b].reshape(H + 1, S, A), z[k + "Q_opt"], **VTOL)
                 np.testing.assert_allclose(dp.split_states(V, H + 1)[b].reshape(H + 1, S), z[k + "V_opt"], **VTOL)
+                np.testing.assert_allclose(dp.split_states(Vr, H + 1)[b].reshape(H + 1, S), z[k + "V_rand"], **VTOL)
+                if k + "Q_opt" not in z:  # G12 keeps the value functions only
+                    continue
+                np.testing.assert_allclose(dp.split_rows(Q, H + 1)[b].reshape(H + 1, S, A), z[k + "Q_opt"], **VTOL)
                 np.testing.assert_allclose(dp.split_rows(Qw, H + 1)[b].reshape(H + 1, S, A), z[k + "Q_worst"], **VTOL)
                 np.testing.assert_allclose(dp.split_rows(Qr, H + 1)[b].reshape(H + 1, S, A), z[k + "Q_rand"], **VTOL)
-                np.testing.assert_allclose(dp.split_states(Vr, H + 1)[b].reshape(H + 1, S), z[k + "V_rand"], **VTOL)
             oQ, oV = O.episodic(S, A, H, m.csr(), m.reward_matrix())
             np.testing.assert_array_equal(dp.split_rows(Q, H + 1)[0].reshape(H + 1, S, A), oQ)
             oQr, oVr = O.episodic(S, A, H, m.csr(), m.reward_matrix(), pi)

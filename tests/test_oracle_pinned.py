@@ -31,12 +31,14 @@ def test_philox_known_answers():
                                   np.array([0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1], np.uint32))
 
 
-@pytest.mark.parametrize("name", ["G1_deepsea8", "G2_deepsea30", "G3_stochastic"])
+@pytest.mark.parametrize("name", ["G1_deepsea8", "G2_deepsea30", "G3_stochastic", "G12_families"])
 def test_trajectories_and_visits(name):
     z, cases = load_golden(name)
     for i, c in enumerate(cases):
         m = make_model(c["cls"], **c["kwargs"])
         k = f"c{i}_"
+        if not m.deterministic_rewards:  # Beta rewards: the reference-exact sampler is host side (tests/test_rewards.py)
+            continue
         e = O.OracleEnv(m, rng_mode=0)
         assert e.reset() == z[k + "resets"][0]
         acts = z[k + "actions"]
@@ -46,7 +48,8 @@ def test_trajectories_and_visits(name):
         np.testing.assert_array_equal(out["stype"], z[k + "stype"])
         vs, vsa = e.visits()
         np.testing.assert_array_equal(vs, z[k + "visits_s"])
-        np.testing.assert_array_equal(vsa, z[k + "visits_sa"])
+        if k + "visits_sa" in z:
+            np.testing.assert_array_equal(vsa, z[k + "visits_sa"])
 
 
 def test_step_needs_reset():
