@@ -2,6 +2,7 @@
 #include "../../include/cmdp.h"
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstdarg>
@@ -1321,9 +1322,26 @@ static int chain_launch(cmdp_t* h, const float* d_pi, const int32_t* d_act, cons
   c.work_off = h->d_ch_off.p; c.work = h->d_ch_work.p; c.avg = h->d_ch_avg.p; c.kind = h->d_ch_kind.p;
   c.n_classes = h->d_ch_ncls.p;
   if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_average_reward<4>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_average_reward<16>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_chain_average_reward<4>, dim3(B), dim3(256), lds, st, c);
+  static const bool chain_debug = std::getenv("CMDP_CHAIN_DEBUG") != nullptr;
+  DevBuf<long long> d_dbg;
+  if (chain_debug) {
+    HIP_TRY(d_dbg.alloc((size_t)B * 8));
+    HIP_TRY(d_dbg.zero(st));
+    c.dbg = d_dbg.p;
+  }
+  hipLaunchKernelGGL(k_chain_average_reward<16>, dim3(B), dim3(1024), lds, st, c);
+  if (chain_debug) {
+    std::vector<long long> t((size_t)B * 8);
+    HIP_TRY(hipMemcpyAsync(t.data(), d_dbg.p, sizeof(long long) * t.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    double ph[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < B; ++b)
+      for (int k = 0; k < 7; ++k) ph[k] = std::max(ph[k], (double)(t[(size_t)b * 8 + k + 1] - t[(size_t)b * 8 + k]) / 100.0);
+    std::fprintf(stderr, "[K9 us, max over instances] A %.0f  B(tarjan) %.0f  C %.0f  D %.0f  E(gth) %.0f  F(backsub) %.0f  sum %.0f\n",
+                 ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(avg, h->d_ch_avg.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(kind, h->d_ch_kind.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));

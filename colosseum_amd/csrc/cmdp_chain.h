@@ -44,6 +44,7 @@ struct ChainArgs {
   double* avg;               // [B]
   int32_t* kind;             // [B] 0 = float64 result, 1 = float32 result
   int32_t* n_classes;        // [B] number of recurrent classes of the chain
+  long long* dbg;            // [B][8] wall-clock stamps (100 MHz) at the phase boundaries, or null (tuning aid)
 };
 
 enum { CHAIN_F64 = 0, CHAIN_F32 = 1 };
@@ -122,6 +123,7 @@ __global__ void __launch_bounds__(NW * 64) k_chain_average_reward(ChainArgs c) {
   int* adj = colj + S;  // [<= S * max_deg]
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
+  if (c.dbg && tid == 0) c.dbg[(int64_t)b * 8 + 0] = (long long)wall_clock64();
   // ---- A: actions, degrees, adjacency ------------------------------------------------------------------------------
   for (int s = tid; s < S; s += NT) {
     int a = 0;
@@ -164,6 +166,7 @@ __global__ void __launch_bounds__(NW * 64) k_chain_average_reward(ChainArgs c) {
   }
   __syncthreads();
 
+  if (c.dbg && tid == 0) c.dbg[(int64_t)b * 8 + 1] = (long long)wall_clock64();
   // ---- B: strongly connected components in networkx's emission order ----------------------------------------------
   if (tid == 0) {
     int cnt = 0, ncomp = 0, sq = 0;
@@ -209,6 +212,7 @@ __global__ void __launch_bounds__(NW * 64) k_chain_average_reward(ChainArgs c) {
   __syncthreads();
   const int ncomp = s_i[0];
 
+  if (c.dbg && tid == 0) c.dbg[(int64_t)b * 8 + 2] = (long long)wall_clock64();
   // ---- C: recurrent classes (no edge leaves them), the class taken -------------------------------------------------
   int* leak = it;     // [ncomp]
   int* reach = queue; // [S]
@@ -262,6 +266,7 @@ __global__ void __launch_bounds__(NW * 64) k_chain_average_reward(ChainArgs c) {
     chosen = s_i[2];
   }
 
+  if (c.dbg && tid == 0) c.dbg[(int64_t)b * 8 + 3] = (long long)wall_clock64();
   // ---- D: members in ascending state order, dense matrix ----------------------------------------------------------
   if (wave == 0) {
     int m = 0;
@@ -295,6 +300,7 @@ __global__ void __launch_bounds__(NW * 64) k_chain_average_reward(ChainArgs c) {
   }
   __syncthreads();
 
+  if (c.dbg && tid == 0) c.dbg[(int64_t)b * 8 + 4] = (long long)wall_clock64();
   // ---- E: GTH elimination -------------------------------------------------------------------------------------------
   int n_eff = m;
   for (int i = 0; i < m - 1; ++i) {
@@ -353,32 +359,59 @@ __global__ void __launch_bounds__(NW * 64) k_chain_average_reward(ChainArgs c) {
     const double sc = s_scale;
     if (sc <= 0.0) { n_eff = i + 1; break; }
     const int nrow = s_i[5], ncol = s_i[6];
-    for (int pj = wave; pj < ncol; pj += NW) {
-      const int j = colj[pj];
+    for (int pj = tid; pj < ncol; pj += NT) {  // a[j, i] /= scale
       const double l = colv[pj] / sc;
-      if (lane == 0) a[(int64_t)j * m + i] = l;
-      for (int pk = lane; pk < nrow; pk += 64) {
-        const int64_t at = (int64_t)j * m + rowk[pk];
-        a[at] = __dadd_rn(a[at], __dmul_rn(l, rowv[pk]));
+      colv[pj] = l;
+      a[(int64_t)colj[pj] * m + i] = l;
+    }
+    __syncthreads();
+    // rank-1 update of the |col| x |row| non-zero block, (j, k) pairs flattened over the whole workgroup; UB
+    // independent read-modify-writes per thread are read first and written afterwards (one memory round trip per
+    // batch, not one per element)
+    constexpr int UB = 4;
+    const int total = ncol * nrow;
+    for (int e0 = tid; e0 < total; e0 += NT * UB) {
+      double v[UB], add[UB];
+      int64_t at[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int e = e0 + u * NT;
+        if (e < total) {
+          const int pj = e / nrow, pk = e - pj * nrow;
+          at[u] = (int64_t)colj[pj] * m + rowk[pk];
+          v[u] = a[at[u]];
+          add[u] = __dmul_rn(colv[pj], rowv[pk]);
+        }
       }
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (e0 + u * NT < total) a[at[u]] = __dadd_rn(v[u], add[u]);
     }
     __syncthreads();
   }
 
+  if (c.dbg && tid == 0) c.dbg[(int64_t)b * 8 + 5] = (long long)wall_clock64();
   // ---- F: back-substitution, normalisation, reward sum -------------------------------------------------------------
   if (wave == 0 && m > 0) {
     for (int i = lane; i < m; i += 64) xs[i] = 0.0;
     if (lane == 0) xs[n_eff - 1] = 1.0;
+    constexpr int PFB = 8;  // column chunks fetched together (strided loads: one round trip per 512 rows)
     for (int i = n_eff - 2; i >= 0; --i) {
       double acc = 0.0;
-      for (int j0 = i + 1; j0 < n_eff; j0 += 64) {
-        const int j = j0 + lane;
-        double pr = 0.0;
-        if (j < n_eff) {
-          const double l = a[(int64_t)j * m + i];
-          if (l != 0.0) pr = __dmul_rn(xs[j], l);
+      for (int j0 = i + 1; j0 < n_eff; j0 += 64 * PFB) {
+        double l[PFB];
+#pragma unroll
+        for (int u = 0; u < PFB; ++u) {
+          const int j = j0 + 64 * u + lane;
+          l[u] = (j < n_eff) ? a[(int64_t)j * m + i] : 0.0;
         }
-        acc = ordered_add(acc, pr, __ballot(pr != 0.0));
+#pragma unroll
+        for (int u = 0; u < PFB; ++u) {
+          if (j0 + 64 * u >= n_eff) break;
+          const int j = j0 + 64 * u + lane;
+          const double pr = (l[u] != 0.0) ? __dmul_rn(xs[j < n_eff ? j : 0], l[u]) : 0.0;
+          acc = ordered_add(acc, pr, __ballot(pr != 0.0));
+        }
       }
       if (lane == 0) xs[i] = acc;
     }
@@ -391,6 +424,7 @@ __global__ void __launch_bounds__(NW * 64) k_chain_average_reward(ChainArgs c) {
     for (int i = lane; i < n_eff; i += 64) xs[i] = xs[i] / tot;
   }
   __syncthreads();
+  if (c.dbg && tid == 0) c.dbg[(int64_t)b * 8 + 6] = (long long)wall_clock64();
   const bool f32 = (n_attr == 1 && m < S);
   float* ev32 = reinterpret_cast<float*>(ev);
   for (int s = tid; s < S; s += NT) {
@@ -408,6 +442,7 @@ __global__ void __launch_bounds__(NW * 64) k_chain_average_reward(ChainArgs c) {
     c.avg[b] = out;
     c.kind[b] = f32 ? CHAIN_F32 : CHAIN_F64;
     if (c.n_classes) c.n_classes[b] = n_attr;
+    if (c.dbg) { c.dbg[(int64_t)b * 8 + 7] = (long long)wall_clock64(); }
   }
 }
 

@@ -28,9 +28,13 @@ def main():
     ap.add_argument("--steps", type=int)
     ap.add_argument("--seeds", type=int)
     ap.add_argument("--log-every", type=int)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsals)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0")
     args = ap.parse_args()
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
     dist = None
+    if args.share_gpu:
+        local = 0
     if args.folder:
         cfg = yaml.safe_load(open(os.path.join(args.folder, "experiment_config.yml")))
         benchmarks = [bm.load_mdp_configs(args.folder)]
@@ -56,11 +60,15 @@ def main():
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.dist_backend)
     lo, hi = shard_range(len(instances), rank, world)
     local_vec = np.stack([bm.summary_vector(results[i]) for i in range(lo, hi)]) if hi > lo else np.zeros((0, 3))
-    allv = gather_instances(local_vec, len(instances), dist, device="cuda" if dist is not None else None)
+    allv = gather_instances(local_vec, len(instances), dist,
+                            device="cuda" if dist is not None and args.dist_backend == "nccl" else None)
     if rank == 0:
         print(json.dumps(dict(instances=len(instances), steps_each=n_steps, wall_s=time.time() - t0,
                               agent_steps_per_s=len(instances) * n_steps / (time.time() - t0),
