@@ -57,37 +57,10 @@ class HipEvents:
         return float(ms.value)
 
 
-def _build_fl(args):
-    from colosseum_amd.mdp import make_model
-
-    seed, size = args
-    m = make_model("FrozenLakeContinuous", seed=seed, size=size, p_frozen=0.9, is_slippery=True, p_rand=0.1)
-    ptr, col, val = m.csr()
-    return m.n_states, ptr, col, val, m.reward_matrix().ravel()
-
-
 def frozenlake_dp_tables(seeds, size, workers):
-    """DP half of the tables for FrozenLakeContinuous(seed, size, p_frozen=0.9, is_slippery=True, p_rand=0.1)
-    (config C3), built by a process pool (the builder is host Python)."""
-    import multiprocessing as mp
+    from colosseum_amd.mdp.fast_batch import frozenlake_dp_tables as build
 
-    jobs = [(int(s), size) for s in seeds]
-    if workers > 1:
-        with mp.get_context("fork").Pool(workers) as pool:
-            res = pool.map(_build_fl, jobs, chunksize=max(1, len(jobs) // (workers * 8)))
-    else:
-        res = [_build_fl(j) for j in jobs]
-    S = np.array([r[0] for r in res], np.int64)
-    nz = np.array([len(r[2]) for r in res], np.int64)
-    nz_off = np.concatenate([[0], np.cumsum(nz)])
-    return dict(
-        B=len(res), A=4, H=0, rewards_range=(0.0, 1.0),
-        state_off=np.concatenate([[0], np.cumsum(S)]).astype(np.int64),
-        csr_ptr=np.concatenate([r[1][:-1].astype(np.int64) + nz_off[i] for i, r in enumerate(res)] + [nz_off[-1:]]),
-        csr_col=np.concatenate([r[2] for r in res]),
-        csr_val=np.concatenate([r[3] for r in res]),
-        R=np.concatenate([r[4] for r in res]),
-    )
+    return build(seeds, size, workers, context="fork")
 
 
 def main():

@@ -59,3 +59,39 @@ def deepsea_episodic_tables(seeds: Sequence[int], size: int, with_dp: bool = Fal
         t["csr_val"] = np.ones(R, np.float32)
         t["R"] = t["sp_reward"].astype(np.float32)
     return t
+
+
+def _build_fl(args):
+    from .registry import make_model
+
+    seed, size, kw = args
+    m = make_model("FrozenLakeContinuous", seed=seed, size=size, **kw)
+    ptr, col, val = m.csr()
+    return m.n_states, ptr, col, val, m.reward_matrix().ravel()
+
+
+def frozenlake_dp_tables(seeds, size, workers=1, context="fork", **kw):
+    """DP half of the tables (`tables_from_models(..., with_env=False)`) for many FrozenLakeContinuous(seed, size, **kw)
+    instances (config C3 = p_frozen 0.9, slippery, p_rand 0.1), built by a process pool -- the builder is
+    host Python.  `context="fork"` must only be used before the HIP runtime is initialised in this process; "spawn" is
+    safe at any time."""
+    import multiprocessing as mp
+
+    kw = dict(dict(p_frozen=0.9, is_slippery=True, p_rand=0.1), **kw)
+    jobs = [(int(s), size, kw) for s in seeds]
+    if workers > 1:
+        with mp.get_context(context).Pool(workers) as pool:
+            res = pool.map(_build_fl, jobs, chunksize=max(1, len(jobs) // (workers * 8)))
+    else:
+        res = [_build_fl(j) for j in jobs]
+    S = np.array([r[0] for r in res], np.int64)
+    nz = np.array([len(r[2]) for r in res], np.int64)
+    nz_off = np.concatenate([[0], np.cumsum(nz)])
+    return dict(
+        B=len(res), A=4, H=0, rewards_range=(0.0, 1.0),
+        state_off=np.concatenate([[0], np.cumsum(S)]).astype(np.int64),
+        csr_ptr=np.concatenate([r[1][:-1].astype(np.int64) + nz_off[i] for i, r in enumerate(res)] + [nz_off[-1:]]),
+        csr_col=np.concatenate([r[2] for r in res]),
+        csr_val=np.concatenate([r[3] for r in res]),
+        R=np.concatenate([r[4] for r in res]),
+    )

@@ -1,0 +1,118 @@
+"""BASELINE.json's full sizes on the GPU, checked through properties that do not need a CPU run of the whole batch:
+two independent kernels must agree on every count (a checksum of everything), counts are conserved, launches compose,
+value functions are fixed points of one more backup -- plus the CPU oracle, bit for bit, on instances sampled from all
+over the batch.  (The oracle cannot run 65 536 x 3 000 transitions in test time; 64 instances take a second.)"""
+import os
+
+import numpy as np
+import pytest
+
+from colosseum_amd import _lib as L
+from colosseum_amd.batched import BatchedMDP
+from colosseum_amd.mdp import make_model
+from colosseum_amd.mdp.fast_batch import deepsea_episodic_tables, frozenlake_dp_tables
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c2_full_size_65536_deepsea30(need_gpu):
+    B, size, n = 65536, 30, 3000
+    S = size * (size + 1) // 2
+    seeds = np.arange(B, dtype=np.int64)
+    tables = deepsea_episodic_tables(seeds, size, with_dp=False)
+    keys = seeds.astype(np.uint64)
+    env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX, philox_keys=keys)   # automatic choice: LDS-resident kernel
+    env.reset()
+    a = env.rollout(n)
+    vs_a, vsa_a = env.visits()
+    env.close()
+    env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX, philox_keys=keys)
+    env.set_rollout_kernel(L.ROLLOUT_GLOBAL)                                    # lane-per-instance HBM-table kernel
+    env.reset()
+    b1 = env.rollout(1000)                                                      # launches compose: 1000 + 2000
+    b2 = env.rollout(n - 1000)
+    vs_b, vsa_b = env.visits()
+    env.close()
+    # (i) two kernels, one answer: every one of the 30.5 M state counters and 61 M state-action counters
+    np.testing.assert_array_equal(vs_a, vs_b)
+    np.testing.assert_array_equal(vsa_a, vsa_b)
+    np.testing.assert_array_equal(a["last_obs"], b2["last_obs"])
+    # float64 reward sums: one launch adds 3000 terms in order, two launches add two partial sums -> rounding only
+    np.testing.assert_allclose(a["reward_sum"], b1["reward_sum"] + b2["reward_sum"], rtol=1e-12, atol=0)
+    # (ii) conservation: arrivals = transitions + resets, the same for every instance (fixed horizon)
+    per_inst = vs_a.reshape(B, S).sum(1)
+    assert (per_inst == n + 1 + n // size).all()
+    assert (vsa_a.reshape(B, S * 2).sum(1) == n).all()
+    # (iii) the oracle on 64 instances taken from all over the batch
+    for b0 in range(0, B, B // 4):
+        last, rsum, cvs, _ = O.batch_rollout(tables, b0, b0 + 16, n, rng_mode=1, philox_keys=keys, want_visits=True)
+        np.testing.assert_array_equal(cvs, vs_a[b0 * S:(b0 + 16) * S])
+        np.testing.assert_array_equal(rsum, a["reward_sum"][b0:b0 + 16])
+        np.testing.assert_array_equal(last, a["last_obs"][b0:b0 + 16])
+
+
+def test_c3_full_size_4096_frozenlake20_vi(need_gpu):
+    B = 4096
+    fl = frozenlake_dp_tables(np.arange(B), 20, workers=min(16, os.cpu_count() or 1), context="spawn")
+    dp = BatchedMDP(tables=fl, with_env=False)
+    dp.set_dp_kernel(L.DP_REGISTER)
+    Q, V, sw = dp.value_iteration(0.99, 1e-6)
+    dp.set_dp_kernel(L.DP_WORKGROUP)
+    Q2, V2, sw2 = dp.value_iteration(0.99, 1e-6)
+    # (i) register-resident and LDS/HBM workgroup kernels: identical bits, identical sweep counts
+    np.testing.assert_array_equal(V, V2)
+    np.testing.assert_array_equal(Q, Q2)
+    np.testing.assert_array_equal(sw, sw2)
+    # (ii) fixed point: one more Bellman backup (numpy, float64) moves no value by more than the stopping threshold
+    ptr, col, val, R = fl["csr_ptr"], fl["csr_col"], fl["csr_val"], fl["R"]
+    row_state = np.repeat(np.arange(len(R)) // 4, np.diff(ptr))          # flat state of every non-zero's row
+    inst_base = fl["state_off"][np.searchsorted(fl["state_off"], row_state, side="right") - 1]
+    contrib = val.astype(np.float64) * V[inst_base + col].astype(np.float64)
+    EV = np.add.reduceat(contrib, ptr[:-1])
+    Qn = R.astype(np.float64) + 0.99 * EV
+    Vn = Qn.reshape(-1, 4).max(1)
+    assert np.abs(Vn - V).max() < 2e-6
+    assert np.abs(Qn - Q).max() < 2e-6
+    assert (V >= 0).all() and (V <= 1.0 / (1 - 0.99) + 1e-3).all()
+    assert sw.min() > 100 and sw.max() < 5000
+    # (iii) the oracle on 32 instances from all over the batch: values and sweep counts bit-equal
+    so = fl["state_off"]
+    for b in range(0, B, B // 32):
+        r0, r1 = so[b] * 4, so[b + 1] * 4
+        csr = (ptr[r0:r1 + 1] - ptr[r0], col[ptr[r0]:ptr[r1]], val[ptr[r0]:ptr[r1]])
+        n_s = int(so[b + 1] - so[b])
+        oQ, oV, oit, _ = O.vi_discounted(n_s, 4, csr, R[r0:r1].reshape(n_s, 4), 0.99, 1e-6, 1)
+        np.testing.assert_array_equal(V[so[b]:so[b + 1]], oV)
+        assert sw[b] == oit
+    dp.close()
+
+
+def test_c5_size_50272_diameter_sample(need_gpu):
+    m = make_model("MiniGridRoomsContinuous", seed=0, room_size=28, n_rooms=16, n_starting_states=2, p_lazy=0.1)
+    S, A = m.n_states, m.n_actions
+    assert S == 50272
+    dp = BatchedMDP([m], with_env=False)
+    lo, hi = 25000, 25000 + 192
+    per = dp.diameter_range(lo, hi)                      # fixed-width-row kernel
+    dp.set_option(L.OPT_DP_KERNEL, 4)
+    np.testing.assert_array_equal(dp.diameter_range(lo, hi), per)   # generic CSR walker: same bits
+    dp.close()
+    assert (per > 1).all() and (per < 1000).all()
+    ptr, col, val = m.csr()
+    for es in (lo, hi - 1):                              # the oracle's single-target Jacobi VI on T_es
+        rows = np.arange(es * A, (es + 1) * A)
+        keep = np.ones(len(col), bool)
+        keep[ptr[es * A]:ptr[(es + 1) * A]] = False
+        cnt = np.diff(ptr).copy()
+        cnt[rows] = 1
+        p2 = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        c2, v2 = np.zeros(p2[-1], np.int32), np.zeros(p2[-1], np.float32)
+        mask = np.ones(p2[-1], bool)
+        mask[p2[rows]] = False
+        c2[mask], v2[mask] = col[keep], val[keep]
+        c2[p2[rows]], v2[p2[rows]] = es, 1.0
+        R2 = -np.ones((S, A), np.float32)
+        R2[es] = 0
+        _, V, _, _ = O.vi_discounted(S, A, (p2, c2, v2), R2, gamma=1.0, eps=1e-3, scheme=1)
+        assert -V.min() == per[es - lo]
