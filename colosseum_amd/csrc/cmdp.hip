@@ -158,6 +158,14 @@ int bind(cmdp_t* h) {
 
 inline int grid_for(int64_t n, int block) { return (int)((n + block - 1) / block); }
 
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return CMDP_OK;
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -373,8 +381,15 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
         const int rows_max = max_S * A;
         LdsPlan p{};
         p.rows_max = rows_max;
+        // reward code in the upper bits of the successor word when both fit 16 bits: one table and one LDS read less
+        int bits_s = 1, bits_c = 0;
+        while ((1 << bits_s) < max_S) ++bits_s;
+        while ((1 << bits_c) < (int)vals.size()) ++bits_c;
+        p.code_shift = (bits_s + bits_c <= 16) ? bits_s : 0;
+        if (p.code_shift)
+          for (int64_t r = 0; r < R; ++r) next16[(size_t)r] = (uint16_t)(next16[(size_t)r] | (codes[(size_t)r] << p.code_shift));
         p.off_rcode = (rows_max * 2 + 3) & ~3;
-        p.off_cnt = p.off_rcode + ((rows_max + 3) & ~3);
+        p.off_cnt = p.code_shift ? p.off_rcode : p.off_rcode + ((rows_max + 3) & ~3);
         p.slot_bytes = p.off_cnt + (((rows_max + 1) / 2) * 4) + 4;  // + the walker's dummy count dword
         const int fixed = K1L_FIXED;
         const int per_inst = p.slot_bytes + 2 * K1L_CH;  // tables + count deltas + two action-ring chunks
@@ -382,9 +397,22 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
         // overlap the other group's walk
         p.G = std::min<int>(64, (kLdsBudget - fixed) / per_inst);
         const int g2 = std::min<int>(64, (kLdsBudget / 2 - fixed) / per_inst);
-        if (g2 >= 12) p.G = g2;
-        h->lds_G1 = std::min<int>(64, (kLdsBudget - fixed) / per_inst);
+        h->lds_G1 = p.G;
         h->lds_G2 = g2;
+        // The walk is bound by the latency of one transition times the number of "rounds" of workgroups the batch
+        // needs (instances resident per CU are limited by LDS capacity).  Two workgroups per CU overlap one group's
+        // staging / flush with the other's walk, one per CU holds a few more instances: take whichever needs fewer
+        // rounds for this batch, two per CU on a tie.
+        if (g2 >= 12) {
+          int cus = 256;
+          (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+          if (cus < 1) cus = 256;
+          auto rounds = [&](int g, int per_cu) {
+            const int64_t wgs = (B + g - 1) / g, slots = (int64_t)cus * per_cu;
+            return (wgs + slots - 1) / slots;
+          };
+          if (rounds(g2, 2) <= rounds(p.G, 1)) p.G = g2;
+        }
         p.n_codes = (int)vals.size();
         if (p.G >= 8) {
           // 16 bytes of slack in front of and behind both element arrays: the staging loads are 16-byte wide
@@ -567,11 +595,14 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
                                       "states, <= 256 distinct rewards, the random policy and no trace");
   // the LDS kernel pays a fixed staging + flush cost per launch: worth it from a few dozen transitions on
   if (lds_eligible && (h->rollout_kernel == 2 || (h->rollout_kernel == 0 && n_steps >= 64))) {
-    if (h->lds_bytes > 64 * 1024)
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)h->lds_bytes));
-    hipLaunchKernelGGL(k_rollout_lds, dim3(grid_for(h->B, h->lds_plan.G)), dim3(K1L_THREADS), h->lds_bytes, st, t, h->lds_plan,
-                       n_steps, d_rsum, d_last);
+    const dim3 lgrid(grid_for(h->B, h->lds_plan.G)), lblock(K1L_THREADS);
+    if (h->lds_plan.code_shift) {
+      if (int rc = set_lds(k_rollout_lds<true>, h->lds_bytes)) return rc;
+      hipLaunchKernelGGL(k_rollout_lds<true>, lgrid, lblock, h->lds_bytes, st, t, h->lds_plan, n_steps, d_rsum, d_last);
+    } else {
+      if (int rc = set_lds(k_rollout_lds<false>, h->lds_bytes)) return rc;
+      hipLaunchKernelGGL(k_rollout_lds<false>, lgrid, lblock, h->lds_bytes, st, t, h->lds_plan, n_steps, d_rsum, d_last);
+    }
     HIP_TRY(hipGetLastError());
     return CMDP_OK;
   }
@@ -747,13 +778,6 @@ int resolve_scheme(cmdp_t* h, int scheme, bool pe, bool diam, int* out) {
                                     "explicitly or split the batch");
   }
   *out = chosen;
-  return CMDP_OK;
-}
-
-template <typename K>
-int set_lds(K kernel, size_t bytes) {
-  if (bytes > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   return CMDP_OK;
 }
 

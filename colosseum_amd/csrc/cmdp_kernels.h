@@ -243,7 +243,8 @@ __global__ void __launch_bounds__(256) k_rollout(EnvTables t, const int8_t* __re
 // The lane-per-instance kernel above moves a whole HBM sector for every 4..32-byte table access
 // (measured ~640 B of traffic per 44-byte transition), so it is bound by HBM sector throughput.  Here a
 // one-wavefront workgroup stages the tables of G instances into LDS with coalesced loads ONCE per launch
-// -- per instance: successor table uint16[S*A], reward-code table uint8[S*A] and 16-bit visit-count
+// -- per instance: successor table uint16[S*A] (with the reward code packed into its upper bits when
+// log2 S + log2 #codes <= 16, otherwise a separate uint8[S*A] reward-code table) and 16-bit visit-count
 // deltas [S*A] -- walks them for n_steps entirely on chip (one LDS read on the dependency chain per
 // transition), then adds the deltas into the HBM counters with coalesced read-modify-writes.
 // HBM traffic per launch ~ (3 + 12) bytes per table row, independent of n_steps.
@@ -256,6 +257,7 @@ struct LdsPlan {
   int32_t off_rcode;       // byte offsets inside a slot
   int32_t off_cnt;
   int32_t n_codes;         // distinct reward values (<= 256)
+  int32_t code_shift;      // > 0: the reward code sits above this many successor bits of next16 (no rcode table)
   const uint16_t* next16;  // [R] successor of every (deterministic) row
   const uint8_t* rcode;    // [R] index into rvals
   const double* rvals;     // [n_codes]
@@ -282,6 +284,7 @@ __device__ __forceinline__ void flush_counts(int32_t* __restrict__ dst, int tota
 // instruction stream is only: action byte, successor read (the one LDS load on the dependency chain), 16-bit count
 // add, reward add.  The walker is software-pipelined by hand: the bookkeeping of transition s-1 (count add, reward
 // table read) and the reward add of transition s-2 are issued while the successor read of transition s is in flight.
+template <bool PACKED>
 __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPlan p, int64_t n_steps,
                                                             double* __restrict__ reward_sum,
                                                             int32_t* __restrict__ last_obs) {
@@ -336,7 +339,7 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
       }
     }
   }
-  {
+  if (!PACKED) {
     const uint8_t* src = p.rcode + row00;
     const int head = (int)(reinterpret_cast<uintptr_t>(src) & 15);
     const uint4* vsrc = reinterpret_cast<const uint4*>(src - head);
@@ -416,6 +419,7 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
   int pend_crow = dummy_crow, pend_code = 256;
   double pend_val = 0.0;
   const bool episodic = H > 0;
+  const int smask = (1 << p.code_shift) - 1;
   while (done < n_steps) {
     const int len = (int)min((int64_t)K1L_CH, n_steps - done);
     if (tid >= 64) {
@@ -430,8 +434,9 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
           if (s0 + j < len) {  // wave-uniform; false only in the last group of a ragged chunk
             const int a = (int)(((j < 4 ? aw.x : aw.y) >> (8 * (j & 3))) & 0xffu);
             const int row = cur * A + a;
-            const int nxt = nx[row];  // the one load on the dependency chain
-            const int code = rc[row];
+            const int word = nx[row];  // the one load on the dependency chain
+            const int nxt = PACKED ? (word & smask) : word;
+            const int code = PACKED ? (word >> p.code_shift) : (int)rc[row];
             // bookkeeping of the two previous transitions while the successor read is in flight
             sum += pend_val;             // rewards are added in transition order: bit-equal to the sequential sum
             pend_val = rv2[pend_code];
