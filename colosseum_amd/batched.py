@@ -143,16 +143,20 @@ class BatchedMDP:
         L.check(self._lib.cmdp_step(self._h, L.ptr(a), int(auto_reset), L.ptr(obs), L.ptr(rew), L.ptr(st)))
         return obs, rew, st
 
-    def rollout(self, n_steps: int, actions=None, trace: bool = False):
+    def rollout(self, n_steps: int, actions=None, trace: bool = False, greedy_q=None):
         """n_steps transitions per instance (episodic terminations are followed by reset()).
-        actions: None -> on-device uniform random policy; else int array [n_steps, B]."""
+        actions: None -> on-device uniform random policy; else int array [n_steps, B].  greedy_q: per-instance Q
+        tables ([S, A], or [H, S, A] for episodic handles): the fixed policy "first maximiser of the current row"."""
         n_steps = int(n_steps)
         last = np.zeros(self.B, np.int32)
         rsum = np.zeros(self.B, np.float64)
         tr_obs = np.zeros((n_steps, self.B), np.int32) if trace else None
         tr_rew = np.zeros((n_steps, self.B), np.float64) if trace else None
         tr_ty = np.zeros((n_steps, self.B), np.uint8) if trace else None
-        if actions is None:
+        if greedy_q is not None:
+            assert actions is None
+            policy, arg = L.POLICY_GREEDY_Q, np.ascontiguousarray(self._flat_rows(greedy_q, lead=max(self.H, 1)), np.float32)
+        elif actions is None:
             policy, arg = L.POLICY_RANDOM, None
         else:
             arg = L.carr(actions, np.int8)

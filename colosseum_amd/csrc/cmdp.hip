@@ -566,11 +566,18 @@ int cmdp_step(cmdp_t* h, const int32_t* actions, int auto_reset, int32_t* obs, d
 }
 
 static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_t n_steps, double* d_rsum,
-                          int32_t* d_last, int32_t* d_tobs, double* d_trew, uint8_t* d_ttype) {
+                          int32_t* d_last, int32_t* d_tobs, double* d_trew, uint8_t* d_ttype, const float* d_q = nullptr) {
   hipStream_t st = h->stream;
   const dim3 grid(grid_for(h->B, 256)), block(256);
   const bool trace = d_tobs || d_trew || d_ttype;
   EnvTables t = h->env();
+  if (policy == CMDP_POLICY_GREEDY_Q) {
+    if (h->layout == CMDP_LAYOUT_DENSE) return fail(CMDP_ERR_UNSUPPORTED, "CMDP_POLICY_GREEDY_Q runs on the CSR layout");
+    if (trace) hipLaunchKernelGGL((k_rollout<2, true>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype, d_q);
+    else hipLaunchKernelGGL((k_rollout<2, false>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype, d_q);
+    HIP_TRY(hipGetLastError());
+    return CMDP_OK;
+  }
   if (h->layout == CMDP_LAYOUT_DENSE) {
     if (trace) return fail(CMDP_ERR_UNSUPPORTED, "the dense-layout rollout does not record traces");
     DenseArgs dn{h->d_dense.p, h->dense_spad};
@@ -622,9 +629,9 @@ int cmdp_rollout(cmdp_t* h, int policy, const void* policy_arg, int64_t n_steps,
   if (int rc = bind(h)) return rc;
   if (!h->has_env) return fail(CMDP_ERR_INVALID, "handle was created without the sampler half");
   if (n_steps < 0) return fail(CMDP_ERR_INVALID, "n_steps < 0");
-  if (policy == CMDP_POLICY_GREEDY_Q) return fail(CMDP_ERR_UNSUPPORTED, "CMDP_POLICY_GREEDY_Q is not built yet");
-  if (policy != CMDP_POLICY_RANDOM && policy != CMDP_POLICY_HOST_ACTIONS) return fail(CMDP_ERR_INVALID, "policy");
-  if (policy == CMDP_POLICY_HOST_ACTIONS && !policy_arg && n_steps > 0) return fail(CMDP_ERR_INVALID, "actions missing");
+  if (policy != CMDP_POLICY_RANDOM && policy != CMDP_POLICY_HOST_ACTIONS && policy != CMDP_POLICY_GREEDY_Q)
+    return fail(CMDP_ERR_INVALID, "policy");
+  if (policy != CMDP_POLICY_RANDOM && !policy_arg && n_steps > 0) return fail(CMDP_ERR_INVALID, "policy_arg missing");
   bool any = false;
   if (int rc = any_needs_reset(h, &any)) return rc;
   if (any) return fail(CMDP_ERR_NEEDS_RESET, "rollout() on an instance that needs reset()");
@@ -639,13 +646,18 @@ int cmdp_rollout(cmdp_t* h, int policy, const void* policy_arg, int64_t n_steps,
     HIP_TRY(h->d_actions8.upload(a, NB, st));
     d_act = h->d_actions8.p;
   }
+  const float* d_q = nullptr;
+  if (policy == CMDP_POLICY_GREEDY_Q) {
+    HIP_TRY(h->d_gp_q.upload(static_cast<const float*>(policy_arg), (size_t)(h->H > 0 ? h->H : 1) * h->n_rows, st));
+    d_q = h->d_gp_q.p;
+  }
   if (h->d_rsum.n < (size_t)B) HIP_TRY(h->d_rsum.alloc(B));
   if (h->d_last_obs.n < (size_t)B) HIP_TRY(h->d_last_obs.alloc(B));
   if (trace_obs && h->d_tr_obs.n < NB) HIP_TRY(h->d_tr_obs.alloc(NB));
   if (trace_reward && h->d_tr_rew.n < NB) HIP_TRY(h->d_tr_rew.alloc(NB));
   if (trace_type && h->d_tr_type.n < NB) HIP_TRY(h->d_tr_type.alloc(NB));
   if (int rc = launch_rollout(h, policy, d_act, n_steps, h->d_rsum.p, h->d_last_obs.p, trace_obs ? h->d_tr_obs.p : nullptr,
-                              trace_reward ? h->d_tr_rew.p : nullptr, trace_type ? h->d_tr_type.p : nullptr))
+                              trace_reward ? h->d_tr_rew.p : nullptr, trace_type ? h->d_tr_type.p : nullptr, d_q))
     return rc;
   if (last_obs) HIP_TRY(hipMemcpyAsync(last_obs, h->d_last_obs.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
   if (reward_sum) HIP_TRY(hipMemcpyAsync(reward_sum, h->d_rsum.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));

@@ -201,20 +201,31 @@ __global__ void k_step(EnvTables t, const int32_t* __restrict__ actions, int aut
 // The env side of MDPLoop.run's loop (reference colosseum/experiment/agent_mdp_interaction.py:238-298),
 // fused: n_steps transitions per instance, every termination followed at once by reset().
 // POLICY 0: Philox random action; 1: actions[t][B] (int8).
+// POLICY 0: on-device uniform random; 1: host action stream; 2: greedy in a Q table (`qtab`: per instance [S][A], or
+// [H][S][A] indexed by the in-episode time when the handle is episodic), first maximiser.
 template <int POLICY, bool TRACE>
 __global__ void __launch_bounds__(256) k_rollout(EnvTables t, const int8_t* __restrict__ actions, int64_t n_steps,
                                                  double* __restrict__ reward_sum, int32_t* __restrict__ last_obs,
                                                  int32_t* __restrict__ tr_obs, double* __restrict__ tr_rew,
-                                                 uint8_t* __restrict__ tr_type) {
+                                                 uint8_t* __restrict__ tr_type, const float* __restrict__ qtab = nullptr) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= t.B) return;
   const int64_t soff = t.state_off[b], ebase = t.entry_base[b];
+  const int64_t S_b = t.state_off[b + 1] - soff;
   const uint2 key = t.philox_key ? t.philox_key[b] : make_uint2(0, 0);
   int32_t cur = t.cur[b], h = t.hstep[b], obs = cur;
   unsigned long long nt = t.n_trans[b], nr = t.n_reset[b];
   double sum = 0.0;
   for (int64_t s = 0; s < n_steps; ++s) {
-    const int a = (POLICY == 1) ? (int)actions[s * t.B + b] : -1;
+    int a = -1;
+    if (POLICY == 1) a = (int)actions[s * t.B + b];
+    if (POLICY == 2) {
+      const float* q = qtab + ((t.H > 0 ? (int64_t)t.H * soff + (int64_t)h * S_b : soff) + cur) * t.A;
+      float best = q[0];
+      a = 0;
+      for (int k = 1; k < t.A; ++k)
+        if (q[k] > best) { best = q[k]; a = k; }
+    }
     double r;
     const int ty = env_step(t, soff, ebase, key, cur, h, nt, a, obs, r);
     sum += r;

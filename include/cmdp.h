@@ -59,7 +59,9 @@ enum {
 enum {
   CMDP_POLICY_RANDOM = 0,       /* uniform over A from the instance's Philox stream (config C2)      */
   CMDP_POLICY_HOST_ACTIONS = 1, /* policy_arg = const int8_t actions[n_steps][B]                      */
-  CMDP_POLICY_GREEDY_Q = 2      /* policy_arg = const float Q[...]: first maximiser of Q[h? , s, :]   */
+  CMDP_POLICY_GREEDY_Q = 2      /* policy_arg = const float Q: per instance [S_b][A] (continuous) or
+                                   [H][S_b][A] at H*state_off[b]*A (episodic, row = in-episode time);
+                                   the action is the first maximiser of the current row            */
 };
 
 /* Sweep scheme of the discounted solvers. */

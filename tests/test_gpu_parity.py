@@ -578,3 +578,40 @@ def test_diameter_lanes_kernel_equals_workgroup_kernel_and_oracle(need_gpu):
         parts = [dp.diameter_range(a, b) for a, b in zip(cuts[:-1], cuts[1:])]
         np.testing.assert_array_equal(np.concatenate(parts), per0)
         dp.close()
+
+
+def test_greedy_q_policy_rollout(need_gpu):
+    """CMDP_POLICY_GREEDY_Q: the device picks the first maximiser of the current Q row.  Feeding the actions it must
+    have taken (recomputed on the host from the traced observations) through CMDP_POLICY_HOST_ACTIONS on a fresh handle
+    with the same streams reproduces observations, rewards and step types."""
+    rng = np.random.default_rng(3)
+    for cls, kw in (("FrozenLakeContinuous", dict(seed=3, size=6, p_frozen=0.9, p_rand=0.1)),
+                    ("MiniGridEmptyEpisodic", dict(seed=1, size=5, p_rand=0.2, n_starting_states=1)),
+                    ("DeepSeaEpisodic", dict(seed=2, size=7))):
+        ms = [make_model(cls, **kw)] * 3
+        m = ms[0]
+        assert len(m.start_states) == 1
+        S, A, H = m.n_states, m.n_actions, m.H
+        qs = [np.round(rng.random((max(H, 1), S, A)), 1).astype(np.float32) for _ in ms]   # rounding makes ties
+        n = 500
+        env = BatchedMDP(ms, rng_mode=L.RNG_MT_COMPAT, with_dp=False)
+        first = env.reset()
+        out = env.rollout(n, greedy_q=[q if H else q[0] for q in qs], trace=True)
+        env.close()
+        acts = np.zeros((n, len(ms)), np.int8)
+        for b in range(len(ms)):
+            cur, h = int(first[b]), 0
+            for t in range(n):
+                acts[t, b] = int(np.argmax(qs[b][h if H else 0, cur]))     # np.argmax = first maximiser
+                if out["stype"][t, b] == 2:       # termination: the device reset to the (single) start state
+                    cur, h = int(m.start_states[0]), 0
+                else:
+                    cur, h = int(out["obs"][t, b]), h + 1
+        assert len(np.unique(acts)) > 1
+        env = BatchedMDP(ms, rng_mode=L.RNG_MT_COMPAT, with_dp=False)
+        env.reset()
+        ref = env.rollout(n, acts, trace=True)
+        env.close()
+        np.testing.assert_array_equal(out["obs"], ref["obs"], err_msg=cls)
+        np.testing.assert_array_equal(out["rew"], ref["rew"])
+        np.testing.assert_array_equal(out["stype"], ref["stype"])
