@@ -19,6 +19,7 @@ OPT_ROLLOUT_KERNEL = 1
 OPT_DP_KERNEL = 2
 OPT_LDS_GROUPS_PER_CU = 3
 OPT_DIAMETER_WORKSPACE_MB = 4
+OPT_CHAIN_EXACT_ORDER = 5
 DP_AUTO, DP_WORKGROUP, DP_REGISTER = 0, 1, 2
 ROLLOUT_AUTO, ROLLOUT_GLOBAL, ROLLOUT_LDS = 0, 1, 2
 

@@ -123,9 +123,10 @@ struct cmdp {
   DevBuf<int64_t> d_dl_voff;
   size_t dl_ws_bytes = (size_t)24 << 30;  // value arrays of the target groups in flight per launch
   // cmdp_average_reward workspace (K9)
+  bool chain_exact = false;  // CMDP_OPT_CHAIN_EXACT_ORDER
   DevBuf<double> d_ch_work, d_ch_avg;
   DevBuf<int64_t> d_ch_off;
-  DevBuf<int32_t> d_ch_kind, d_ch_ncls, d_ch_act, d_ch_start;
+  DevBuf<int32_t> d_ch_kind, d_ch_ncls, d_ch_act, d_ch_start, d_ch_idx;
   DevBuf<uint8_t> d_ch_mask;
   DevBuf<float> d_dense;  // CMDP_LAYOUT_DENSE: [R][dense_spad]
   int dense_spad = 0;
@@ -693,6 +694,10 @@ int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
   }
   if (option == CMDP_OPT_DP_KERNEL && value >= 0 && value <= 4) {
     h->dp_kernel = (int)value;
+    return CMDP_OK;
+  }
+  if (option == CMDP_OPT_CHAIN_EXACT_ORDER && (value == 0 || value == 1)) {
+    h->chain_exact = value == 1;
     return CMDP_OK;
   }
   if (option == CMDP_OPT_DIAMETER_WORKSPACE_MB && value >= 1) {
@@ -1342,6 +1347,7 @@ static int chain_launch(cmdp_t* h, const float* d_pi, const int32_t* d_act, cons
     HIP_TRY(h->d_ch_off.upload(off.data(), off.size(), st));
     HIP_TRY(hipStreamSynchronize(st));  // `off` is a local
     HIP_TRY(h->d_ch_work.alloc((size_t)off[B]));
+    HIP_TRY(h->d_ch_idx.alloc((size_t)off[B]));
     HIP_TRY(h->d_ch_avg.alloc(B));
     HIP_TRY(h->d_ch_kind.alloc(B));
     HIP_TRY(h->d_ch_ncls.alloc(B));
@@ -1355,11 +1361,15 @@ static int chain_launch(cmdp_t* h, const float* d_pi, const int32_t* d_act, cons
   c.B = B; c.A = h->A; c.max_deg = h->max_row_nnz;
   c.state_off = h->d_state_off.p; c.csr_ptr = h->d_csr_ptr.p; c.csr_col = h->d_csr_col.p; c.csr_val = h->d_csr_val.p;
   c.R = h->d_R.p; c.pi = d_pi; c.act = d_act; c.start = d_start; c.mask = dmask;
-  c.work_off = h->d_ch_off.p; c.work = h->d_ch_work.p; c.avg = h->d_ch_avg.p; c.kind = h->d_ch_kind.p;
+  c.work_off = h->d_ch_off.p; c.work = h->d_ch_work.p; c.work_idx = h->d_ch_idx.p; c.avg = h->d_ch_avg.p; c.kind = h->d_ch_kind.p;
   c.n_classes = h->d_ch_ncls.p;
   if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_average_reward<16>),
+  {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_average_reward<16, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_average_reward<16, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   static const bool chain_debug = std::getenv("CMDP_CHAIN_DEBUG") != nullptr;
   DevBuf<long long> d_dbg;
   if (chain_debug) {
@@ -1367,7 +1377,8 @@ static int chain_launch(cmdp_t* h, const float* d_pi, const int32_t* d_act, cons
     HIP_TRY(d_dbg.zero(st));
     c.dbg = d_dbg.p;
   }
-  hipLaunchKernelGGL(k_chain_average_reward<16>, dim3(B), dim3(1024), lds, st, c);
+  if (h->chain_exact) hipLaunchKernelGGL((k_chain_average_reward<16, true>), dim3(B), dim3(1024), lds, st, c);
+  else hipLaunchKernelGGL((k_chain_average_reward<16, false>), dim3(B), dim3(1024), lds, st, c);
   if (chain_debug) {
     std::vector<long long> t((size_t)B * 8);
     HIP_TRY(hipMemcpyAsync(t.data(), d_dbg.p, sizeof(long long) * t.size(), hipMemcpyDeviceToHost, st));

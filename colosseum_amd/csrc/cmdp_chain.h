@@ -41,6 +41,7 @@ struct ChainArgs {
   const uint8_t* mask;       // [B] instances to evaluate, or null = all
   const int64_t* work_off;   // [B+1] prefix of S_b^2
   double* work;              // class matrices
+  int32_t* work_idx;         // same offsets: row indices of the packed elimination columns
   double* avg;               // [B]
   int32_t* kind;             // [B] 0 = float64 result, 1 = float32 result
   int32_t* n_classes;        // [B] number of recurrent classes of the chain
@@ -69,6 +70,18 @@ __device__ __forceinline__ double ordered_add(double acc, double v, unsigned lon
   return acc;
 }
 
+// EXACT: acc + (set lanes of v in lane order) -- the reference's summation order, ~28 cycles per term on one chain.
+// otherwise: acc + butterfly sum of the wave (fixed shuffle pattern: deterministic, but not the reference's order;
+// relative difference ~1e-16 per sum) -- ~100 cycles per 64 terms.
+template <bool EXACT>
+__device__ __forceinline__ double lanes_add(double acc, double v, unsigned long long m) {
+  if (EXACT) return ordered_add(acc, v, m);
+  if (!m) return acc;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = __dadd_rn(v, __shfl_xor(v, o, 64));
+  return __dadd_rn(acc, v);
+}
+
 // numpy's pairwise_sum (numpy/_core/src/umath/loops_utils.h.src): < 8 plain, <= 128 eight accumulators, else halves
 template <typename T, int D>
 __device__ T np_pairwise(const T* a, int n) {
@@ -92,7 +105,7 @@ __device__ T np_pairwise(const T* a, int n) {
   return np_pairwise<T, (D > 0 ? D - 1 : 0)>(a, n2) + np_pairwise<T, (D > 0 ? D - 1 : 0)>(a + n2, n - n2);
 }
 
-template <int NW>
+template <int NW, bool EXACT>
 __global__ void __launch_bounds__(NW * 64) k_chain_average_reward(ChainArgs c) {
   extern __shared__ unsigned char chain_smem[];
   __shared__ int s_i[8];
@@ -288,6 +301,8 @@ __global__ void __launch_bounds__(NW * 64) k_chain_average_reward(ChainArgs c) {
   __syncthreads();
   const int m = s_i[4];
   double* a = c.work + c.work_off[b];
+  int32_t* aj = c.work_idx + c.work_off[b];
+  int* lcnt = pre;  // [m] entries of every packed column (the search arrays are free by now)
   for (int64_t e = tid; e < (int64_t)m * m; e += NT) a[e] = 0.0;
   __syncthreads();
   for (int i = tid; i < m; i += NT) {
@@ -327,7 +342,7 @@ __global__ void __launch_bounds__(NW * 64) k_chain_average_reward(ChainArgs c) {
             rowv[p] = v[u];
           }
           cntr += __popcll(bm);
-          sc = ordered_add(sc, v[u], bm);
+          sc = lanes_add<EXACT>(sc, v[u], bm);
         }
       }
       if (lane == 0) { s_i[5] = cntr; s_scale = sc; }
@@ -359,11 +374,16 @@ __global__ void __launch_bounds__(NW * 64) k_chain_average_reward(ChainArgs c) {
     const double sc = s_scale;
     if (sc <= 0.0) { n_eff = i + 1; break; }
     const int nrow = s_i[5], ncol = s_i[6];
-    for (int pj = tid; pj < ncol; pj += NT) {  // a[j, i] /= scale
+    // a[j, i] /= scale.  The scaled column is what back-substitution needs; it is stored PACKED (value, row index) in
+    // the part of row i right of the diagonal, which is dead from here on (its entries live in rowv for the update):
+    // back-substitution then streams contiguous lists instead of walking strided columns
+    for (int pj = tid; pj < ncol; pj += NT) {
       const double l = colv[pj] / sc;
       colv[pj] = l;
-      a[(int64_t)colj[pj] * m + i] = l;
+      a[(int64_t)i * m + i + 1 + pj] = l;
+      aj[(int64_t)i * m + i + 1 + pj] = colj[pj];
     }
+    if (tid == 0) lcnt[i] = ncol;
     __syncthreads();
     // rank-1 update of the |col| x |row| non-zero block, (j, k) pairs flattened over the whole workgroup; UB
     // independent read-modify-writes per thread are read first and written afterwards (one memory round trip per
@@ -395,31 +415,47 @@ __global__ void __launch_bounds__(NW * 64) k_chain_average_reward(ChainArgs c) {
   if (wave == 0 && m > 0) {
     for (int i = lane; i < m; i += 64) xs[i] = 0.0;
     if (lane == 0) xs[n_eff - 1] = 1.0;
-    constexpr int PFB = 8;  // column chunks fetched together (strided loads: one round trip per 512 rows)
+    constexpr int PFB = 4;  // 64-entry chunks of a packed column held in registers; the NEXT pivot's are in flight
+    double cv[PFB], nv[PFB];
+    int cj[PFB], nj[PFB];
+    auto load_col = [&](int i, double (&lv)[PFB], int (&lj)[PFB]) {
+      const int64_t base = (int64_t)i * m + i + 1;
+      const int cnt = lcnt[i];
+#pragma unroll
+      for (int u = 0; u < PFB; ++u) {
+        const int e = 64 * u + lane;
+        lv[u] = (e < cnt) ? a[base + e] : 0.0;
+        lj[u] = (e < cnt) ? aj[base + e] : 0;
+      }
+    };
+    if (n_eff >= 2) load_col(n_eff - 2, cv, cj);
     for (int i = n_eff - 2; i >= 0; --i) {
+      if (i > 0) load_col(i - 1, nv, nj);
+      const int cnt = lcnt[i];
       double acc = 0.0;
-      for (int j0 = i + 1; j0 < n_eff; j0 += 64 * PFB) {
-        double l[PFB];
 #pragma unroll
-        for (int u = 0; u < PFB; ++u) {
-          const int j = j0 + 64 * u + lane;
-          l[u] = (j < n_eff) ? a[(int64_t)j * m + i] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < PFB; ++u) {
-          if (j0 + 64 * u >= n_eff) break;
-          const int j = j0 + 64 * u + lane;
-          const double pr = (l[u] != 0.0) ? __dmul_rn(xs[j < n_eff ? j : 0], l[u]) : 0.0;
-          acc = ordered_add(acc, pr, __ballot(pr != 0.0));
-        }
+      for (int u = 0; u < PFB; ++u) {
+        if (64 * u >= cnt) break;
+        const double pr = (cv[u] != 0.0) ? __dmul_rn(xs[cj[u]], cv[u]) : 0.0;
+        acc = lanes_add<EXACT>(acc, pr, __ballot(pr != 0.0));
+      }
+      for (int e0 = 64 * PFB; e0 < cnt; e0 += 64) {  // longer columns: the rest straight from memory
+        const int e = e0 + lane;
+        const int64_t base = (int64_t)i * m + i + 1;
+        const double l = (e < cnt) ? a[base + e] : 0.0;
+        const int j = (e < cnt) ? aj[base + e] : 0;
+        const double pr = (l != 0.0) ? __dmul_rn(xs[j], l) : 0.0;
+        acc = lanes_add<EXACT>(acc, pr, __ballot(pr != 0.0));
       }
       if (lane == 0) xs[i] = acc;
+#pragma unroll
+      for (int u = 0; u < PFB; ++u) { cv[u] = nv[u]; cj[u] = nj[u]; }
     }
     double tot = 0.0;
     for (int i0 = 0; i0 < n_eff; i0 += 64) {
       const int i = i0 + lane;
       const double v = (i < n_eff) ? xs[i] : 0.0;
-      tot = ordered_add(tot, v, __ballot(v != 0.0));
+      tot = lanes_add<EXACT>(tot, v, __ballot(v != 0.0));
     }
     for (int i = lane; i < n_eff; i += 64) xs[i] = xs[i] / tot;
   }

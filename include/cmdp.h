@@ -180,12 +180,16 @@ int cmdp_synchronize(cmdp_t* h);
    non-zeros per row, <= 1024 states), 3 = (cmdp_diameter only) the 64-targets-per-workgroup kernel K5S that is
    otherwise taken when the value vector of an instance does not fit LDS (4 = the same with its generic CSR walker
    instead of the fixed-width-row variant).
+   CMDP_OPT_CHAIN_EXACT_ORDER (cmdp_average_reward / cmdp_qlearning_average_reward): 1 = every float64 sum of the GTH
+   elimination in the reference's index order (bit-equal to cmdp_gth and the oracle, one serial chain per sum);
+   0 (default) = wave butterfly sums, deterministic, within ~1e-15 relative of the former, several times faster on
+   chains with hundreds of states.
    CMDP_OPT_DIAMETER_WORKSPACE_MB: HBM the value arrays of K5S may take per launch (default 24576; 512 bytes per
    state per group of 64 targets; more groups in flight = more of the GPU busy).
    CMDP_OPT_LDS_GROUPS_PER_CU: 1 or 2 workgroups of the LDS-resident rollout kernel per CU (default 2 when
    each still holds >= 12 instances). */
 enum { CMDP_OPT_ROLLOUT_KERNEL = 1, CMDP_OPT_DP_KERNEL = 2, CMDP_OPT_LDS_GROUPS_PER_CU = 3,
-       CMDP_OPT_DIAMETER_WORKSPACE_MB = 4 };
+       CMDP_OPT_DIAMETER_WORKSPACE_MB = 4, CMDP_OPT_CHAIN_EXACT_ORDER = 5 };
 int cmdp_set_option(cmdp_t* h, int option, int64_t value);
 
 /* BaseMDP.get_visitation_counts / reset_visitation_counts (colosseum/mdp/base.py:1357-1382).

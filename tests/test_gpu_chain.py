@@ -40,7 +40,12 @@ def test_average_reward_kernel_matches_host_restatement(need_gpu, cls, kw):
         acts.append(a.astype(np.int32))
         starts.append(int(rng.integers(0, S)))
     env = BatchedMDP([m] * n_pol, rng_mode=L.RNG_PHILOX, with_env=False)
+    fast, ncls_fast = env.average_reward(acts, starts)      # default: wave butterfly sums inside the elimination
+    env.set_option(L.OPT_CHAIN_EXACT_ORDER, 1)              # the reference's summation order: bit-equal below
     vals, ncls = env.average_reward(acts, starts)
+    np.testing.assert_array_equal(ncls_fast, ncls)
+    for x, y in zip(fast, vals):
+        assert type(x) is type(y) and x == pytest.approx(y, rel=1e-6 if isinstance(y, np.float32) else 1e-12, abs=1e-15)
     multi = 0
     for i in range(n_pol):
         pol = np.zeros((S, A), np.float32)
