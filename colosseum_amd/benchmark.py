@@ -170,20 +170,23 @@ def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, r
     return results
 
 
-def write_csv_logs(folder: str, instances: Sequence[Instance], results: Dict[int, list]):
-    """The reference's on-disk wire format (CSVLogger with add_uid=False; header = sorted keys)."""
-    from .experiment.vector_tracker import LogTable
+def write_csv_logs(folder: str, instances: Sequence[Instance], results: Dict[int, list], workers: int = 0):
+    """The reference's on-disk wire format (CSVLogger with add_uid=False; header = sorted keys).  `workers` > 1
+    formats the column stores of the device batches in a process pool."""
+    from .experiment.vector_tracker import LogTable, csv_texts_parallel
 
-    text = {}  # BatchLog -> its columns as text, converted once per device batch
+    logs = {}
+    for rows in results.values():
+        if isinstance(rows, LogTable):
+            logs.setdefault(id(rows.log), rows.log)
+    texts = csv_texts_parallel(list(logs.values()), workers) if logs else {}
     for i, rows in results.items():
         ins = instances[i]
         d = os.path.join(folder, "logs", ins.label)
         os.makedirs(d, exist_ok=True)
         with open(os.path.join(d, f"seed{ins.seed}_logs.csv"), "w", newline="") as f:
             if isinstance(rows, LogTable):
-                if id(rows.log) not in text:
-                    text[id(rows.log)] = rows.log.text_columns()
-                f.write(rows.log.csv_text(rows.b, text[id(rows.log)]))
+                f.write(texts[id(rows.log)][rows.b])
                 continue
             fields = sorted(rows[0].keys())
             w = csv.DictWriter(f, fieldnames=fields, extrasaction="ignore")

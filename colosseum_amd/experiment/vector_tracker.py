@@ -403,3 +403,38 @@ class ContinuousVectorTracker(_VectorTracker):
         self._accumulate_and_log(t, r, nr, avg, cum_reward, n_since)
         if in_loop:
             self._after_log(t, T, nr, 1e-5, lambda: nr)
+
+
+def _csv_texts_of_slice(args):
+    """Worker of `csv_texts_parallel`: the CSV texts of a slice of instances of one batch (pure numpy / str work)."""
+    steps, cols, B = args
+    log = BatchLog(B)
+    log.steps = list(steps)
+    log._final = cols
+    text = log.text_columns()
+    return [log.csv_text(b, text) for b in range(B)]
+
+
+def csv_texts_parallel(logs: Sequence["BatchLog"], workers: int, chunk: int = 16):
+    """{id(log): [csv text per instance]} -- the float -> shortest-repr text conversion is Python-level work
+    (~1 us per value, 90 k values per instance at the benchmark's cadence), so it is spread over a process pool
+    ("spawn": safe after the HIP runtime has been initialised)."""
+    tasks, where = [], []
+    for log in logs:
+        fin = log.finalize()
+        for b0 in range(0, log.B, chunk):
+            b1 = min(log.B, b0 + chunk)
+            cols = {n: (v[:, b0:b1], k if isinstance(k, int) else k[:, b0:b1]) for n, (v, k) in fin.items()}
+            tasks.append((log.steps, cols, b1 - b0))
+            where.append((id(log), b0))
+    if workers > 1 and len(tasks) > 1:
+        import multiprocessing as mp
+
+        with mp.get_context("spawn").Pool(min(workers, len(tasks))) as pool:
+            parts = pool.map(_csv_texts_of_slice, tasks)
+    else:
+        parts = [_csv_texts_of_slice(t) for t in tasks]
+    out: Dict[int, list] = {}
+    for (key, b0), texts in zip(where, parts):
+        out.setdefault(key, {})[b0] = texts
+    return {key: [t for b0 in sorted(d) for t in d[b0]] for key, d in out.items()}

@@ -185,3 +185,19 @@ def test_continuous_vector_tracker_equals_scalar_trackers(seed):
             for k in ref:
                 if k != "steps_per_second":
                     _same(got[k], ref[k], (b, k, ref["steps"]))
+
+
+@pytest.mark.timeout(300)
+def test_parallel_csv_formatting_equals_serial():
+    from colosseum_amd.experiment.vector_tracker import BatchLog, csv_texts_parallel
+
+    B, n = 24, 200
+    log = BatchLog(B)
+    rng = np.random.default_rng(0)
+    for t in range(n):
+        log.append(t, {f"c{i}": MP(np.round(rng.random(B) * 1000, 5).astype(np.float32 if i % 2 else np.float64),
+                                  F32 if i % 2 else F64) for i in range(5)})
+    tc = log.text_columns()
+    ref = [log.csv_text(b, tc) for b in range(B)]
+    assert csv_texts_parallel([log], 1)[id(log)] == ref
+    assert csv_texts_parallel([log], 3, chunk=5)[id(log)] == ref

@@ -55,7 +55,9 @@ def main():
     results = bm.run_instances(instances, n_steps, log_every, rank, world, device=local,
                                build_workers=max(1, min(16, (os.cpu_count() or 1) // world)),
                                progress=lambda msg: print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True))
-    bm.write_csv_logs(args.out, instances, results)
+    t_run = time.time() - t0
+    bm.write_csv_logs(args.out, instances, results, workers=max(1, min(32, (os.cpu_count() or 1) // world)))
+    print(f"[rank {rank}] instances done in {t_run:.1f} s, logs written in {time.time() - t0 - t_run:.1f} s", file=sys.stderr, flush=True)
     if world > 1:
         import torch
         import torch.distributed as dist
