@@ -130,7 +130,7 @@ def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_m
 
 def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, rank: int = 0, world: int = 1,
                   agent_configs: Optional[Dict[str, Dict[str, Any]]] = None, rng_mode: int = L.RNG_MT_COMPAT,
-                  device: int = 0, max_concurrent_groups: int = 1, build_workers: int = 0, progress=None):
+                  device: int = 0, max_concurrent_groups: int = 6, build_workers: int = 0, progress=None):
     """Runs this rank's contiguous shard; returns {global instance index: logger rows}."""
     agent_configs = agent_configs or DEFAULT_AGENT_CONFIGS
     lo, hi = shard_range(len(instances), rank, world)
@@ -160,13 +160,23 @@ def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, r
                      f"{time.time() - t0:.1f} s")
         return idx, rows
 
-    # Groups run one after the other by default: a group of 20 instances x 200 000 steps takes 0.6-1.5 s alone, while four
-    # host threads driving four handles concurrently were measured 10-100x SLOWER (every small synchronous copy of one
-    # handle ends up waiting behind the other handles' long kernels).  max_concurrent_groups > 1 is kept for experiments.
-    with ThreadPoolExecutor(max_workers=max(1, max_concurrent_groups)) as pool:
-        for idx, rows in pool.map(work, list(groups.values())):
-            for i, r in zip(idx, rows):
-                results[i] = r
+    # Device batches are small next to the GPU (20-220 instances: a handful of wavefronts in latency-bound kernels), so a
+    # few of them are driven concurrently, one host thread and one HIP stream each; the C calls release the GIL.  This
+    # only pays because the per-log host work is short (vector_tracker): with per-instance Python trackers the threads
+    # convoyed on the GIL (every one of the ~6 short C calls per log waited a 5 ms switch interval) and ran 10-100x
+    # slower than one after the other.  Largest batches first, so that the tail is short.
+    order = sorted(groups.values(), key=lambda idx: -len(idx) * models[idx[0]].n_states * max(models[idx[0]].n_states, 64))
+    import sys
+
+    old_interval = sys.getswitchinterval()
+    sys.setswitchinterval(2e-4)
+    try:
+        with ThreadPoolExecutor(max_workers=max(1, max_concurrent_groups)) as pool:
+            for idx, rows in pool.map(work, order):
+                for i, r in zip(idx, rows):
+                    results[i] = r
+    finally:
+        sys.setswitchinterval(old_interval)
     return results
 
 
