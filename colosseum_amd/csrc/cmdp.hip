@@ -1015,11 +1015,19 @@ static int diameter_lanes(cmdp_t* h, DpTables t, int64_t unit_lo, int64_t unit_h
         h->ell_K = K;
       }
       ell = true;
-#define ELL_CASE(AT, KT)                                                                                        \
-  if (A == AT && K == KT)                                                                                       \
-    hipLaunchKernelGGL((k_diam_lanes_ell<8, AT, KT>), dim3((unsigned)n), dim3(512), 0, st, t, g, h->d_ell_col.p, \
-                       h->d_ell_val.p);                                                                         \
-  else
+      static const int k5s_nw = std::getenv("CMDP_K5S_NW") ? std::atoi(std::getenv("CMDP_K5S_NW")) : 8;  // tuning aid
+#define ELL_CASE(AT, KT)                                                                                          \
+  if (A == AT && K == KT) {                                                                                       \
+    if (k5s_nw == 16)                                                                                             \
+      hipLaunchKernelGGL((k_diam_lanes_ell<16, AT, KT>), dim3((unsigned)n), dim3(1024), 0, st, t, g, h->d_ell_col.p, \
+                         h->d_ell_val.p);                                                                         \
+    else if (k5s_nw == 4)                                                                                         \
+      hipLaunchKernelGGL((k_diam_lanes_ell<4, AT, KT>), dim3((unsigned)n), dim3(256), 0, st, t, g, h->d_ell_col.p, \
+                         h->d_ell_val.p);                                                                         \
+    else                                                                                                          \
+      hipLaunchKernelGGL((k_diam_lanes_ell<8, AT, KT>), dim3((unsigned)n), dim3(512), 0, st, t, g, h->d_ell_col.p, \
+                         h->d_ell_val.p);                                                                         \
+  } else
       ELL_CASE(2, 2) ELL_CASE(2, 4) ELL_CASE(2, 8) ELL_CASE(3, 2) ELL_CASE(3, 4) ELL_CASE(3, 8) ELL_CASE(4, 2)
       ELL_CASE(4, 4) ELL_CASE(4, 8) { ell = false; }
 #undef ELL_CASE
