@@ -383,12 +383,14 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
         LdsPlan p{};
         p.rows_max = rows_max;
         // reward code in the upper bits of the successor word when both fit 16 bits: one table and one LDS read less
+        // (the successor is stored as its row base, successor * A)
         int bits_s = 1, bits_c = 0;
-        while ((1 << bits_s) < max_S) ++bits_s;
+        while ((1 << bits_s) < rows_max) ++bits_s;
         while ((1 << bits_c) < (int)vals.size()) ++bits_c;
         p.code_shift = (bits_s + bits_c <= 16) ? bits_s : 0;
         if (p.code_shift)
-          for (int64_t r = 0; r < R; ++r) next16[(size_t)r] = (uint16_t)(next16[(size_t)r] | (codes[(size_t)r] << p.code_shift));
+          for (int64_t r = 0; r < R; ++r)
+            next16[(size_t)r] = (uint16_t)((next16[(size_t)r] * A) | (codes[(size_t)r] << p.code_shift));
         p.off_rcode = (rows_max * 2 + 3) & ~3;
         p.off_cnt = p.code_shift ? p.off_rcode : p.off_rcode + ((rows_max + 3) & ~3);
         p.slot_bytes = p.off_cnt + (((rows_max + 1) / 2) * 4) + 4;  // + the walker's dummy count dword

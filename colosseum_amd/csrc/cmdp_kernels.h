@@ -11,6 +11,7 @@
 // Float32 DP arithmetic uses __fmul_rn/__fadd_rn (never contracted into FMA): the reference's
 // accumulations round the product and the sum separately.
 #pragma once
+#include <type_traits>
 #include "cmdp_device.h"
 
 struct __attribute__((aligned(32))) RowDesc {  // 32 B, one per (instance, state, action): ONE load per transition
@@ -268,7 +269,8 @@ struct LdsPlan {
   int32_t off_rcode;       // byte offsets inside a slot
   int32_t off_cnt;
   int32_t n_codes;         // distinct reward values (<= 256)
-  int32_t code_shift;      // > 0: the reward code sits above this many successor bits of next16 (no rcode table)
+  int32_t code_shift;      // > 0: next16 holds (successor * A) in its low code_shift bits and the reward code above
+                           //      them (no rcode table, no multiply on the walker's dependency chain)
   const uint16_t* next16;  // [R] successor of every (deterministic) row
   const uint8_t* rcode;    // [R] index into rvals
   const double* rvals;     // [n_codes]
@@ -386,7 +388,8 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
   const bool walker = tid < nb;
   const int b = g0 + (walker ? tid : 0);
   const int32_t start = t.start_state[t.start_off[b]];
-  int32_t cur = t.cur[b], h = t.hstep[b];
+  const int32_t start_k = PACKED ? start * A : start;
+  int32_t cur = PACKED ? t.cur[b] * A : t.cur[b], h = t.hstep[b];
   // every instance of the group has its own transition counter; the producers need all of them
   const unsigned long long nt0 = t.n_trans[b];
   unsigned long long nr = t.n_reset[b];
@@ -431,6 +434,8 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
   double pend_val = 0.0;
   const bool episodic = H > 0;
   const int smask = (1 << p.code_shift) - 1;
+  // wave 0 only: lanes beyond the group's instances mirror lane 0 (b = g0), so a plain wave vote works
+  const bool uniform_h = episodic && tid < 64 && __all(h == __builtin_amdgcn_readfirstlane(h));
   while (done < n_steps) {
     const int len = (int)min((int64_t)K1L_CH, n_steps - done);
     if (tid >= 64) {
@@ -438,31 +443,49 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
       if (nfirst < n_steps) produce(buf ^ 1, nfirst, (int)min((int64_t)K1L_CH, n_steps - nfirst));
     } else if (walker) {
       const unsigned char* acts = ring + ((size_t)buf * p.G + tid) * K1L_CH;
-      for (int s0 = 0; s0 < len; s0 += 8) {
-        const uint2 aw = *reinterpret_cast<const uint2*>(acts + s0);  // eight action bytes, one LDS read
+      // UNI: every walker of the group is at the same in-episode time (the usual case: one reset() for the whole
+      // batch, one horizon), so the episode-end test is a scalar one and costs the vector pipe nothing
+      auto walk = [&](auto uni_tag) {
+        constexpr bool UNI = decltype(uni_tag)::value;
+        int hs = UNI ? __builtin_amdgcn_readfirstlane(h) : 0, nres_s = 0;
+        for (int s0 = 0; s0 < len; s0 += 8) {
+          const uint2 aw = *reinterpret_cast<const uint2*>(acts + s0);  // eight action bytes, one LDS read
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (s0 + j < len) {  // wave-uniform; false only in the last group of a ragged chunk
-            const int a = (int)(((j < 4 ? aw.x : aw.y) >> (8 * (j & 3))) & 0xffu);
-            const int row = cur * A + a;
-            const int word = nx[row];  // the one load on the dependency chain
-            const int nxt = PACKED ? (word & smask) : word;
-            const int code = PACKED ? (word >> p.code_shift) : (int)rc[row];
-            // bookkeeping of the two previous transitions while the successor read is in flight
-            sum += pend_val;             // rewards are added in transition order: bit-equal to the sequential sum
-            pend_val = rv2[pend_code];
-            // visit count of the ARRIVAL node under the action taken (base.py:1302-1303), 16-bit halves of a dword
-            atomicAdd(cnt + (pend_crow >> 1), (pend_crow & 1) ? 0x10000u : 1u);
-            pend_crow = nxt * A + a;
-            pend_code = code;
-            ++h;
-            const bool term = episodic && h >= H;  // episodic termination followed at once by reset()
-            cur = term ? start : nxt;
-            h = term ? 0 : h;
-            n_resets += term ? 1 : 0;
+          for (int j = 0; j < 8; ++j) {
+            if (s0 + j < len) {  // wave-uniform; false only in the last group of a ragged chunk
+              const int a = (int)(((j < 4 ? aw.x : aw.y) >> (8 * (j & 3))) & 0xffu);
+              // PACKED: `cur` and the table's successor field are ROW BASES (state * A): no multiply on the chain
+              const int row = PACKED ? cur + a : cur * A + a;
+              const int word = nx[row];  // the one load on the dependency chain
+              const int nxt = PACKED ? (word & smask) : word;
+              const int code = PACKED ? (word >> p.code_shift) : (int)rc[row];
+              // bookkeeping of the two previous transitions while the successor read is in flight
+              sum += pend_val;             // rewards are added in transition order: bit-equal to the sequential sum
+              pend_val = rv2[pend_code];
+              // visit count of the ARRIVAL node under the action taken (base.py:1302-1303), 16-bit halves of a dword
+              atomicAdd(cnt + (pend_crow >> 1), (pend_crow & 1) ? 0x10000u : 1u);
+              pend_crow = PACKED ? nxt + a : nxt * A + a;
+              pend_code = code;
+              if (UNI) {
+                ++hs;
+                const bool term = hs >= H;  // scalar
+                cur = term ? start_k : nxt;
+                hs = term ? 0 : hs;
+                nres_s += term ? 1 : 0;
+              } else {
+                ++h;
+                const bool term = episodic && h >= H;  // episodic termination followed at once by reset()
+                cur = term ? start_k : nxt;
+                h = term ? 0 : h;
+                n_resets += term ? 1 : 0;
+              }
+            }
           }
         }
-      }
+        if (UNI) { h = hs; n_resets += nres_s; }
+      };
+      if (uniform_h) walk(std::true_type{});
+      else walk(std::false_type{});
     }
     done += len;
     since_flush += len;
@@ -495,6 +518,7 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
     }
   }
   if (walker) {
+    if (PACKED) cur /= A;
     t.cur[b] = cur;
     t.hstep[b] = h;
     t.n_trans[b] = nt0 + (unsigned long long)n_steps;
