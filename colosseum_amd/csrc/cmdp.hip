@@ -809,7 +809,7 @@ int run_sweeps(cmdp_t* h, int mode, bool diam, int scheme, DpTables t, int64_t u
     // register-resident CSR (K2R) when the shapes fit one of the compiled instantiations
     const int A = h->A, K = h->max_row_nnz <= 4 ? 4 : (h->max_row_nnz <= 8 ? 8 : 0);
     const int spt = h->max_S <= 256 ? 1 : (h->max_S <= 512 ? 2 : (h->max_S <= 1024 ? 4 : 0));
-    const size_t lds = 2 * v_bytes + sizeof(float) * 16;
+    const size_t lds = 2 * sizeof(float) * 256 * (size_t)std::max(spt, 1) + sizeof(float) * 16;  // Va, Vb at fixed offsets
     bool launched = true;
     const dim3 grid((unsigned)units), block(256);
 #define REG_CASE(AT, KT, ST)                                                                                  \

@@ -89,6 +89,22 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// max over the wave with DPP moves (VALU only: no LDS traffic, no lgkmcnt waits); the result is valid in LANE 63.
+// quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8, row_bcast:15, row_bcast:31; lanes a move does not reach
+// keep their own value (old = src), which is harmless for an idempotent operation.
+__device__ __forceinline__ float wave_max_lane63(float v) {
+  int x = __float_as_int(v);
+#define CMDP_DPP_MAX(ctrl) \
+  x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(x, x, ctrl, 0xf, 0xf, false))))
+  CMDP_DPP_MAX(0xb1);
+  CMDP_DPP_MAX(0x4e);
+  CMDP_DPP_MAX(0x124);
+  CMDP_DPP_MAX(0x128);
+  CMDP_DPP_MAX(0x142);
+  CMDP_DPP_MAX(0x143);
+#undef CMDP_DPP_MAX
+  return __int_as_float(x);
+}
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));

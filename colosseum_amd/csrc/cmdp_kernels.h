@@ -928,11 +928,13 @@ __global__ void __launch_bounds__(256) k_dp_reg(DpTables t) {
   const int64_t row0 = soff * A_T;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   constexpr int NW = 4;
-  float* Va = reinterpret_cast<float*>(smem);
-  float* Vb = Va + S;
-  float* red = Vb + S;  // [2][NW][2]
+  // The two value vectors sit at COMPILE-TIME offsets (0 and VB_OFF) and the sweep body exists once per parity, so a
+  // gather is `ds_read_b32 v, col4 offset:<const>`: the byte offsets col*4 live in registers for the whole solve and no
+  // address arithmetic is left in the loop.
+  constexpr int VB_OFF = SPT * 256 * 4;
+  float* red = reinterpret_cast<float*>(smem + 2 * VB_OFF);  // [2][NW][2]
 
-  int32_t col[SPT][A_T][KMAX];
+  int32_t col4[SPT][A_T][KMAX];
   float cf[SPT][A_T][KMAX];
   float Rr[SPT][A_T], Pi[SPT][A_T];
 #pragma unroll
@@ -948,21 +950,30 @@ __global__ void __launch_bounds__(256) k_dp_reg(DpTables t) {
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
         const bool in = lo + k < hi;
-        col[j][a][k] = in ? t.csr_col[lo + k] : 0;
+        col4[j][a][k] = in ? 4 * t.csr_col[lo + k] : 0;
         const float v = in ? t.csr_val[lo + k] : 0.0f;
         // PE (and every non-Jacobi-VI form) multiplies the coefficient by gamma first: `(gamma * T) @ V`
         cf[j][a][k] = (MODE == DP_PE) ? __fmul_rn(t.gamma, v) : v;
       }
     }
   }
-  for (int i = tid; i < S; i += 256) { Va[i] = 0.0f; Vb[i] = 0.0f; }
+  for (int i = tid; i < 2 * SPT * 256; i += 256) reinterpret_cast<float*>(smem)[i] = 0.0f;
   __syncthreads();
 
-  float* Vold = Va;
-  float* Vnew = Vb;
+  const bool track_abs = t.max_abs > 0.0;
   int64_t it = 0;
   int status = -5;
-  while (it < t.max_sweeps) {
+  // one Jacobi sweep reading the vector at byte offset RD and writing the one at WR; Q rows go to `qout` when given
+  auto backup = [&](auto rd_tag, int j, int a) -> float {
+    constexpr int RD = decltype(rd_tag)::value;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      acc = __fadd_rn(acc, __fmul_rn(cf[j][a][k], *reinterpret_cast<const float*>(smem + RD + col4[j][a][k])));
+    return (MODE == DP_VI) ? __fadd_rn(Rr[j][a], __fmul_rn(t.gamma, acc)) : __fadd_rn(Rr[j][a], acc);
+  };
+  auto sweep = [&](auto rd_tag) -> int {
+    constexpr int RD = decltype(rd_tag)::value, WR = VB_OFF - RD;
     ++it;
     float dmax = 0.0f, vabs = 0.0f;
 #pragma unroll
@@ -972,52 +983,63 @@ __global__ void __launch_bounds__(256) k_dp_reg(DpTables t) {
         float v = 0.0f;
 #pragma unroll
         for (int a = 0; a < A_T; ++a) {
-          float acc = 0.0f;
-#pragma unroll
-          for (int k = 0; k < KMAX; ++k) acc = __fadd_rn(acc, __fmul_rn(cf[j][a][k], Vold[col[j][a][k]]));
-          float q;
+          const float q = backup(rd_tag, j, a);
           if (MODE == DP_VI) {
-            q = __fadd_rn(Rr[j][a], __fmul_rn(t.gamma, acc));
             v = (a == 0) ? q : fmaxf(v, q);
           } else {
-            q = __fadd_rn(Rr[j][a], acc);
             const float qp = __fmul_rn(q, Pi[j][a]);
             v = (a == 0) ? qp : __fadd_rn(v, qp);
           }
         }
-        Vnew[s] = v;
-        dmax = fmaxf(dmax, fabsf(Vold[s] - v));
-        vabs = fmaxf(vabs, fabsf(v));
+        *reinterpret_cast<float*>(smem + WR + 4 * s) = v;
+        dmax = fmaxf(dmax, fabsf(*reinterpret_cast<const float*>(smem + RD + 4 * s) - v));
+        if (track_abs) vabs = fmaxf(vabs, fabsf(v));
       }
     }
-    dmax = wave_max(dmax);
-    vabs = wave_max(vabs);
-    float* rbuf = red + (it & 1) * 2 * NW;
-    if (lane == 0) { rbuf[2 * wave] = dmax; rbuf[2 * wave + 1] = vabs; }
+    dmax = wave_max_lane63(dmax);
+    if (track_abs) vabs = wave_max_lane63(vabs);
+    float* rbuf = red + (it & 1) * 2 * NW;  // [NW] max|dV| then [NW] max|V|, 16-byte aligned
+    if (lane == 63) {
+      rbuf[wave] = dmax;
+      if (track_abs) rbuf[NW + wave] = vabs;
+    }
     __syncthreads();
-    float diff = 0.0f, vmax = 0.0f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { diff = fmaxf(diff, rbuf[2 * w]); vmax = fmaxf(vmax, rbuf[2 * w + 1]); }
-    float* tmp = Vold; Vold = Vnew; Vnew = tmp;
-    if (t.max_abs > 0.0 && (double)vmax > t.max_abs) { status = -7; break; }
-    if ((double)diff < t.eps) { status = 0; break; }
+    const float4 d4 = *reinterpret_cast<const float4*>(rbuf);
+    const float diff = fmaxf(fmaxf(d4.x, d4.y), fmaxf(d4.z, d4.w));
+    float vmax = 0.0f;
+    if (track_abs) {
+      const float4 a4 = *reinterpret_cast<const float4*>(rbuf + NW);
+      vmax = fmaxf(fmaxf(a4.x, a4.y), fmaxf(a4.z, a4.w));
+    }
+    if (track_abs && (double)vmax > t.max_abs) return 2;
+    if ((double)diff < t.eps) return 1;
+    return 0;
+  };
+  using Even = std::integral_constant<int, 0>;
+  using Odd = std::integral_constant<int, VB_OFF>;
+  int newest = 0;  // byte offset of the newest vector after the loop
+  while (it < t.max_sweeps) {
+    int rc = sweep(Even{});  // reads Va (offset 0), writes Vb
+    newest = VB_OFF;
+    if (rc == 0 && it < t.max_sweeps) {
+      rc = sweep(Odd{});     // reads Vb, writes Va
+      newest = 0;
+    }
+    if (rc) { status = (rc == 1) ? 0 : -7; break; }
   }
   if (tid == 0) {
     t.status[b] = status;
     if (t.sweeps) t.sweeps[b] = it;
   }
-  // Q of the last sweep = the same arithmetic on the vector that sweep read (now in Vnew)
+  // Q of the last sweep = the same arithmetic on the vector that sweep read (the older one)
 #pragma unroll
   for (int j = 0; j < SPT; ++j) {
     const int s = tid + j * 256;
     if (s < S) {
-      t.V[soff + s] = Vold[s];
+      t.V[soff + s] = *reinterpret_cast<const float*>(smem + newest + 4 * s);
 #pragma unroll
       for (int a = 0; a < A_T; ++a) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) acc = __fadd_rn(acc, __fmul_rn(cf[j][a][k], Vnew[col[j][a][k]]));
-        const float q = (MODE == DP_VI) ? __fadd_rn(Rr[j][a], __fmul_rn(t.gamma, acc)) : __fadd_rn(Rr[j][a], acc);
+        const float q = (newest == VB_OFF) ? backup(Even{}, j, a) : backup(Odd{}, j, a);
         t.Q[row0 + (int64_t)s * A_T + a] = q;
       }
     }
