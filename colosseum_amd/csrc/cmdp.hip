@@ -392,30 +392,45 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
           for (int64_t r = 0; r < R; ++r)
             next16[(size_t)r] = (uint16_t)((next16[(size_t)r] * A) | (codes[(size_t)r] << p.code_shift));
         p.off_rcode = (rows_max * 2 + 3) & ~3;
-        p.off_cnt = p.code_shift ? p.off_rcode : p.off_rcode + ((rows_max + 3) & ~3);
-        p.slot_bytes = p.off_cnt + (((rows_max + 1) / 2) * 4) + 4;  // + the walker's dummy count dword
-        const int fixed = K1L_FIXED;
-        const int per_inst = p.slot_bytes + 2 * K1L_CH;  // tables + count deltas + two action-ring chunks
-        // two workgroups per CU when that keeps >= 12 instances each: one group's staging / flush streams
-        // overlap the other group's walk
-        p.G = std::min<int>(64, (kLdsBudget - fixed) / per_inst);
-        const int g2 = std::min<int>(64, (kLdsBudget / 2 - fixed) / per_inst);
-        h->lds_G1 = p.G;
-        h->lds_G2 = g2;
-        // The walk is bound by the latency of one transition times the number of "rounds" of workgroups the batch
-        // needs (instances resident per CU are limited by LDS capacity).  Two workgroups per CU overlap one group's
-        // staging / flush with the other's walk, one per CU holds a few more instances: take whichever needs fewer
-        // rounds for this batch, two per CU on a tie.
-        if (g2 >= 12) {
-          int cus = 256;
-          (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
-          if (cus < 1) cus = 256;
-          auto rounds = [&](int g, int per_cu) {
-            const int64_t wgs = (B + g - 1) / g, slots = (int64_t)cus * per_cu;
-            return (wgs + slots - 1) / slots;
-          };
-          if (rounds(g2, 2) <= rounds(p.G, 1)) p.G = g2;
+        if (p.code_shift) {  // packed: successor words, 8-bit count deltas (+ the walker's dummy counter), overflow list
+          p.off_cnt = p.off_rcode;
+          p.off_ovf = p.off_cnt + ((rows_max + 4 + 3) & ~3);
+          p.slot_bytes = p.off_ovf + ((2 * K1L_OVF + 3) & ~3);
+        } else {
+          p.off_cnt = p.off_rcode + ((rows_max + 3) & ~3);
+          p.off_ovf = 0;
+          p.slot_bytes = p.off_cnt + (((rows_max + 1) / 2) * 4) + 4;  // + the walker's dummy count dword
         }
+        const int fixed = K1L_FIXED;
+        // The walk is bound by the latency of one transition times the number of "rounds" of workgroups the batch
+        // needs (instances resident per CU are limited by LDS capacity).  Choose the action-ring chunk length and the
+        // workgroups per CU (two overlap one group's staging / flush with the other's walk, one holds a few more
+        // instances) that need the fewest rounds; ties go to the longer chunk (fewer barriers), then to two per CU.
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+        if (cus < 1) cus = 256;
+        int64_t best_rounds = -1;
+        p.ch = 256;
+        p.G = 0;
+        for (int ch : {256, 128, 112, 64}) {
+          const int pi = p.slot_bytes + 2 * ch;
+          const int g1 = std::min<int>(64, (kLdsBudget - fixed) / pi);
+          const int g2 = std::min<int>(64, (kLdsBudget / 2 - fixed) / pi);
+          for (int per_cu : {2, 1}) {
+            const int g = per_cu == 2 ? g2 : g1;
+            if (g < (per_cu == 2 ? 12 : 8)) continue;
+            const int64_t wgs = (B + g - 1) / g, slots_n = (int64_t)cus * per_cu;
+            const int64_t rounds = (wgs + slots_n - 1) / slots_n;
+            if (best_rounds < 0 || rounds < best_rounds) {
+              best_rounds = rounds;
+              p.ch = ch;
+              p.G = g;
+              h->lds_G1 = g1;
+              h->lds_G2 = g2;
+            }
+          }
+        }
+        const int per_inst = p.slot_bytes + 2 * p.ch;  // tables + count deltas + two action-ring chunks
         p.n_codes = (int)vals.size();
         if (p.G >= 8) {
           // 16 bytes of slack in front of and behind both element arrays: the staging loads are 16-byte wide
@@ -691,7 +706,7 @@ int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
     const int g = value == 1 ? h->lds_G1 : h->lds_G2;
     if (g < 1) return fail(CMDP_ERR_INVALID, "no room for %lld workgroups per CU", (long long)value);
     h->lds_plan.G = g;
-    h->lds_bytes = (size_t)K1L_FIXED + (size_t)g * (h->lds_plan.slot_bytes + 2 * K1L_CH);
+    h->lds_bytes = (size_t)K1L_FIXED + (size_t)g * (h->lds_plan.slot_bytes + 2 * h->lds_plan.ch);
     return CMDP_OK;
   }
   if (option == CMDP_OPT_DP_KERNEL && value >= 0 && value <= 4) {

@@ -268,6 +268,8 @@ struct LdsPlan {
   int32_t slot_bytes;      // LDS bytes per instance slot
   int32_t off_rcode;       // byte offsets inside a slot
   int32_t off_cnt;
+  int32_t off_ovf;         // packed mode: uint16 list of the rows whose 8-bit counter wrapped since the last flush
+  int32_t ch;              // transitions per action-ring chunk (multiple of 8)
   int32_t n_codes;         // distinct reward values (<= 256)
   int32_t code_shift;      // > 0: next16 holds (successor * A) in its low code_shift bits and the reward code above
                            //      them (no rcode table, no multiply on the walker's dependency chain)
@@ -279,7 +281,7 @@ struct LdsPlan {
 struct LdsPlan;
 // dst[j] += delta(j) for j in [0, total): ROWS: delta = 16-bit count of row j; else delta = sum over the A
 // counts of state j (+ the resets of its instance when j is the start state).  `per` = rows or states per slot.
-template <bool ROWS>
+template <bool ROWS, bool BYTES>
 __device__ __forceinline__ void flush_counts(int32_t* __restrict__ dst, int total, int per, int A, unsigned char* slots,
                                              const LdsPlan& p, const int32_t* resets, const int32_t* start_states,
                                              int tid);
@@ -287,12 +289,12 @@ __device__ __forceinline__ void flush_counts(int32_t* __restrict__ dst, int tota
 // the staging / flush phases are pure streaming and must not serialise on HBM latency).
 #define K1L_UNROLL 8
 #define K1L_THREADS 256
-#define K1L_CH 256                      // transitions per action-ring chunk
+#define K1L_OVF 30                      // wrap events an instance can record between two flushes (8-bit counters)
 #define K1L_NRV 264                      // reward table entries in LDS: 256 codes + a zero entry (index 256) + pad
 #define K1L_FIXED (K1L_NRV * 8 + 64 * 4 + 64 * 8)   // rv2[K1L_NRV] f64, resets[64] i32, keys[64] uint2
 
 // Wavefront specialisation: lanes of wavefront 0 walk one instance each; wavefronts 1-3 are the random-policy
-// PRODUCERS -- they compute the Philox blocks of the NEXT chunk of K1L_CH transitions for all G instances into a
+// PRODUCERS -- they compute the Philox blocks of the NEXT chunk of p.ch transitions for all G instances into a
 // double-buffered LDS ring of action bytes while the walkers consume the current chunk, so the walker's
 // instruction stream is only: action byte, successor read (the one LDS load on the dependency chain), 16-bit count
 // add, reward add.  The walker is software-pipelined by hand: the bookkeeping of transition s-1 (count add, reward
@@ -308,8 +310,9 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
   double* rv2 = reinterpret_cast<double*>(smem);                          // [256] reward value AFTER the range rescale
   int32_t* resets = reinterpret_cast<int32_t*>(smem + K1L_NRV * 8);       // [64]
   uint2* keys = reinterpret_cast<uint2*>(smem + K1L_NRV * 8 + 64 * 4);    // [64]
-  unsigned char* ring = smem + K1L_FIXED;                                 // [2][G][K1L_CH] action bytes
-  unsigned char* slots = ring + 2 * p.G * K1L_CH;
+  const int CH = p.ch;
+  unsigned char* ring = smem + K1L_FIXED;                                 // [2][G][CH] action bytes
+  unsigned char* slots = ring + 2 * p.G * CH;
   const int A = t.A, H = t.H;
   // all instances of the batch have the same S (eligibility): the group's rows are one contiguous range
   const int64_t so0 = t.state_off[g0];
@@ -381,8 +384,10 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
       }
     }
   }
-  for (int j = tid; j < nb * ((rows + 1) / 2); j += K1L_THREADS) {
-    const int slot = j / ((rows + 1) / 2), off = j - slot * ((rows + 1) / 2);
+  // count deltas: 16-bit halves of dwords, or (packed mode) bytes incl. the walker's dummy counter behind them
+  const int cnt_dwords = PACKED ? (p.rows_max + 4) / 4 : (rows + 1) / 2;
+  for (int j = tid; j < nb * cnt_dwords; j += K1L_THREADS) {
+    const int slot = j / cnt_dwords, off = j - slot * cnt_dwords;
     reinterpret_cast<uint32_t*>(slots + (size_t)slot * p.slot_bytes + p.off_cnt)[off] = 0u;
   }
   const bool walker = tid < nb;
@@ -398,12 +403,15 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
   const uint16_t* nx = reinterpret_cast<const uint16_t*>(base);
   const uint8_t* rc = base + p.off_rcode;
   uint32_t* cnt = reinterpret_cast<uint32_t*>(const_cast<unsigned char*>(base) + p.off_cnt);
+  uint8_t* c8 = const_cast<unsigned char*>(base) + p.off_cnt;                                  // packed mode
+  uint16_t* ovf = reinterpret_cast<uint16_t*>(const_cast<unsigned char*>(base) + p.off_ovf);    // packed mode
+  int n_ovf = 0;
   __syncthreads();
 
   // producer: fills ring buffer `buf` with the actions of transitions [first, first + len) of every instance
   auto produce = [&](int buf, int64_t first, int len) {
     const int ptid = tid - 64;  // 0..191
-    const int per_slot = K1L_CH / 4 + 1;  // Philox blocks that can overlap a chunk window (unaligned start)
+    const int per_slot = CH / 4 + 1;  // Philox blocks that can overlap a chunk window (unaligned start)
     for (int item = ptid; item < nb * per_slot; item += K1L_THREADS - 64) {
       const int slot = item / per_slot, qi = item - slot * per_slot;
       const unsigned long long n0 = t.n_trans[g0 + slot] + (unsigned long long)first;  // first transition of the window
@@ -411,7 +419,7 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
       const uint2 key = keys[slot];
       uint32_t w[4];
       philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), 2u, 0u, key.x, key.y, w);
-      unsigned char* dst = ring + ((size_t)buf * p.G + slot) * K1L_CH;
+      unsigned char* dst = ring + ((size_t)buf * p.G + slot) * CH;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const long long pos = (long long)(4 * q + j) - (long long)n0;
@@ -422,14 +430,14 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
 
   int64_t done = 0;
   int buf = 0;
-  if (n_steps > 0 && tid >= 64) produce(0, 0, (int)min((int64_t)K1L_CH, n_steps));
+  if (n_steps > 0 && tid >= 64) produce(0, 0, (int)min((int64_t)CH, n_steps));
   __syncthreads();
   int since_flush = 0;
   int32_t n_resets = 0, n_resets_total = 0;
   // Software pipeline registers of the walker.  They start at neutral elements so that the steady-state body needs
   // no predicates: +0.0 (x + 0.0 == x), the zero entry of the reward table, and a dummy count dword behind the
   // slot's real counters (never flushed).
-  const int dummy_crow = 2 * ((p.rows_max + 1) / 2);
+  const int dummy_crow = PACKED ? p.rows_max : 2 * ((p.rows_max + 1) / 2);
   int pend_crow = dummy_crow, pend_code = 256;
   double pend_val = 0.0;
   const bool episodic = H > 0;
@@ -437,12 +445,12 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
   // wave 0 only: lanes beyond the group's instances mirror lane 0 (b = g0), so a plain wave vote works
   const bool uniform_h = episodic && tid < 64 && __all(h == __builtin_amdgcn_readfirstlane(h));
   while (done < n_steps) {
-    const int len = (int)min((int64_t)K1L_CH, n_steps - done);
+    const int len = (int)min((int64_t)CH, n_steps - done);
     if (tid >= 64) {
       const int64_t nfirst = done + len;
-      if (nfirst < n_steps) produce(buf ^ 1, nfirst, (int)min((int64_t)K1L_CH, n_steps - nfirst));
+      if (nfirst < n_steps) produce(buf ^ 1, nfirst, (int)min((int64_t)CH, n_steps - nfirst));
     } else if (walker) {
-      const unsigned char* acts = ring + ((size_t)buf * p.G + tid) * K1L_CH;
+      const unsigned char* acts = ring + ((size_t)buf * p.G + tid) * CH;
       // UNI: every walker of the group is at the same in-episode time (the usual case: one reset() for the whole
       // batch, one horizon), so the episode-end test is a scalar one and costs the vector pipe nothing
       auto walk = [&](auto uni_tag) {
@@ -462,8 +470,19 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
               // bookkeeping of the two previous transitions while the successor read is in flight
               sum += pend_val;             // rewards are added in transition order: bit-equal to the sequential sum
               pend_val = rv2[pend_code];
-              // visit count of the ARRIVAL node under the action taken (base.py:1302-1303), 16-bit halves of a dword
-              atomicAdd(cnt + (pend_crow >> 1), (pend_crow & 1) ? 0x10000u : 1u);
+              // visit count of the ARRIVAL node under the action taken (base.py:1302-1303)
+              if (PACKED) {
+                // 8-bit counter, read-modify-write by its only owner (LDS executes a wave's operations in order, so
+                // the next transition's read sees this write); a wrap is recorded in the overflow list and costs
+                // nothing otherwise.  Half the bytes of the 16-bit form: 40 % more instances fit a CU.
+                // (branch-free: the list slot behind the last entry is written every time and only kept on a wrap)
+                const int c1 = (int)c8[pend_crow] + 1;
+                ovf[n_ovf] = (uint16_t)pend_crow;
+                n_ovf += c1 >> 8;
+                c8[pend_crow] = (uint8_t)c1;
+              } else {
+                atomicAdd(cnt + (pend_crow >> 1), (pend_crow & 1) ? 0x10000u : 1u);  // 16-bit halves of a dword
+              }
               pend_crow = PACKED ? nxt + a : nxt * A + a;
               pend_code = code;
               if (UNI) {
@@ -490,12 +509,20 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
     done += len;
     since_flush += len;
     buf ^= 1;
-    const bool flush_now = (since_flush + K1L_CH > 32768) || done >= n_steps;  // 16-bit deltas
+    // 16-bit deltas cannot wrap within 32 768 transitions; 8-bit ones wrap at most once per 256 transitions of their
+    // instance, and the overflow list holds K1L_OVF wraps
+    const bool flush_now = (since_flush + CH > (PACKED ? 256 * K1L_OVF : 32768)) || done >= n_steps;
     if (flush_now && tid < 64) {
       if (walker) {  // drain the software pipeline before the counters are read
         sum += pend_val;
         sum += rv2[pend_code];
-        atomicAdd(cnt + (pend_crow >> 1), (pend_crow & 1) ? 0x10000u : 1u);
+        if (PACKED) {
+          int c1 = (int)c8[pend_crow] + 1;
+          if (c1 == 256) { ovf[n_ovf++] = (uint16_t)pend_crow; c1 = 0; }
+          c8[pend_crow] = (uint8_t)c1;
+        } else {
+          atomicAdd(cnt + (pend_crow >> 1), (pend_crow & 1) ? 0x10000u : 1u);
+        }
         pend_crow = dummy_crow; pend_code = 256; pend_val = 0.0;
         resets[tid] = n_resets;
         n_resets_total += n_resets;
@@ -506,11 +533,21 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
     if (flush_now) {
       // ---- flush the deltas into the HBM counters: 16-byte read-modify-writes (every counter has exactly one
       //      owner; the partial chunks at the two ends of the group's range go element by element) -----------
-      flush_counts<true>(t.visits_sa + row00, total_rows, rows, A, slots, p, resets, nullptr, tid);
-      flush_counts<false>(t.visits_s + so0, total_states, S, A, slots, p, resets, t.start_state + t.start_off[g0], tid);
+      flush_counts<true, PACKED>(t.visits_sa + row00, total_rows, rows, A, slots, p, resets, nullptr, tid);
+      flush_counts<false, PACKED>(t.visits_s + so0, total_states, S, A, slots, p, resets, t.start_state + t.start_off[g0], tid);
       __syncthreads();
-      for (int j = tid; j < nb * ((rows + 1) / 2); j += K1L_THREADS) {
-        const int slot = j / ((rows + 1) / 2), off = j - slot * ((rows + 1) / 2);
+      if (PACKED && walker) {  // every recorded wrap is worth 256 visits (the dummy counter never gets that far)
+        for (int e = 0; e < n_ovf; ++e) {
+          const int r = ovf[e];
+          if (r < rows) {
+            t.visits_sa[row00 + (int64_t)tid * rows + r] += 256;
+            t.visits_s[so0 + (int64_t)tid * S + r / A] += 256;
+          }
+        }
+        n_ovf = 0;
+      }
+      for (int j = tid; j < nb * cnt_dwords; j += K1L_THREADS) {
+        const int slot = j / cnt_dwords, off = j - slot * cnt_dwords;
         reinterpret_cast<uint32_t*>(slots + (size_t)slot * p.slot_bytes + p.off_cnt)[off] = 0u;
       }
       since_flush = 0;
@@ -528,15 +565,16 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
   }
 }
 
-template <bool ROWS>
+template <bool ROWS, bool BYTES>
 __device__ __forceinline__ void flush_counts(int32_t* __restrict__ dst, int total, int per, int A, unsigned char* slots,
                                              const LdsPlan& p, const int32_t* resets, const int32_t* start_states,
                                              int tid) {
   auto delta = [&](int slot, int off) -> int {
-    const uint16_t* c16 = reinterpret_cast<const uint16_t*>(slots + (size_t)slot * p.slot_bytes + p.off_cnt);
-    if (ROWS) return c16[off];
+    const unsigned char* cb = slots + (size_t)slot * p.slot_bytes + p.off_cnt;
+    const uint16_t* c16 = reinterpret_cast<const uint16_t*>(cb);
+    if (ROWS) return BYTES ? (int)cb[off] : (int)c16[off];
     int acc = (off == start_states[slot]) ? resets[slot] : 0;
-    for (int a = 0; a < A; ++a) acc += c16[off * A + a];
+    for (int a = 0; a < A; ++a) acc += BYTES ? (int)cb[off * A + a] : (int)c16[off * A + a];
     return acc;
   };
   const int head = (int)((reinterpret_cast<uintptr_t>(dst) & 15) >> 2);  // counters before the first aligned chunk
