@@ -255,12 +255,12 @@ __global__ void __launch_bounds__(256) k_rollout(EnvTables t, const int8_t* __re
 // The lane-per-instance kernel above moves a whole HBM sector for every 4..32-byte table access
 // (measured ~640 B of traffic per 44-byte transition), so it is bound by HBM sector throughput.  Here a
 // one-wavefront workgroup stages the tables of G instances into LDS with coalesced loads ONCE per launch
-// -- per instance: successor table uint16[S*A] (with the reward code packed into its upper bits when
-// log2 S + log2 #codes <= 16, otherwise a separate uint8[S*A] reward-code table) and 16-bit visit-count
-// deltas [S*A] -- walks them for n_steps entirely on chip (one LDS read on the dependency chain per
+// -- per instance: successor table uint16[S*A] and visit-count deltas [S*A] (packed mode: successor row base with
+// the reward code in the upper bits, 8-bit deltas with an overflow list; otherwise a separate uint8[S*A] reward-code
+// table and 16-bit deltas) -- walks them for n_steps entirely on chip (one LDS read on the dependency chain per
 // transition), then adds the deltas into the HBM counters with coalesced read-modify-writes.
-// HBM traffic per launch ~ (3 + 12) bytes per table row, independent of n_steps.
-// G = floor(160 KiB / bytes per instance) (33 for DeepSea-30), one workgroup per CU at a time.
+// HBM traffic per launch ~ (2..3 + 12) bytes per table row, independent of n_steps.
+// Instances per workgroup, chunk length and workgroups per CU are chosen in cmdp_create (fewest rounds).
 // ---------------------------------------------------------------------------------------------------
 struct LdsPlan {
   int32_t G;               // instances per workgroup (<= 64)

@@ -186,8 +186,8 @@ int cmdp_synchronize(cmdp_t* h);
    chains with hundreds of states.
    CMDP_OPT_DIAMETER_WORKSPACE_MB: HBM the value arrays of K5S may take per launch (default 24576; 512 bytes per
    state per group of 64 targets; more groups in flight = more of the GPU busy).
-   CMDP_OPT_LDS_GROUPS_PER_CU: 1 or 2 workgroups of the LDS-resident rollout kernel per CU (default 2 when
-   each still holds >= 12 instances). */
+   CMDP_OPT_LDS_GROUPS_PER_CU: 1 or 2 workgroups of the LDS-resident rollout kernel per CU (default: whichever
+   needs fewer rounds of workgroups for the batch). */
 enum { CMDP_OPT_ROLLOUT_KERNEL = 1, CMDP_OPT_DP_KERNEL = 2, CMDP_OPT_LDS_GROUPS_PER_CU = 3,
        CMDP_OPT_DIAMETER_WORKSPACE_MB = 4, CMDP_OPT_CHAIN_EXACT_ORDER = 5 };
 int cmdp_set_option(cmdp_t* h, int option, int64_t value);
