@@ -283,6 +283,39 @@ def main():
             "sample": "instances 0..%d of the same batch, %d transitions each (same Philox streams), reset included; "
                       "%.1f s on 1 of %d host cores" % (n - 1, n_steps, cpu_s, os.cpu_count() or 0),
         }
+        # the reference's multiprocessing model (config.py:22-26: os.cpu_count() - 2 workers): the same oracle on all but
+        # two host cores, every thread its own contiguous range of the batch (the C call releases the GIL)
+        cores = max(1, (os.cpu_count() or 1) - 2)
+        try:  # a container's CPU quota (cgroup v2 cpu.max = "<quota> <period>") is what is really available
+            q, per_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                cores = max(1, min(cores, int(int(q) / int(per_))))
+        except Exception:
+            pass
+        try:
+            cores = max(1, min(cores, len(os.sched_getaffinity(0))))
+        except Exception:
+            pass
+        if cores > 1:
+            from concurrent.futures import ThreadPoolExecutor
+
+            n_mt = min(B, 1024 * cores)
+            per = -(-n_mt // cores)
+            ranges = [(lo, min(n_mt, lo + per)) for lo in range(0, n_mt, per)]
+            c0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=cores) as pool:
+                list(pool.map(lambda r: O.batch_rollout(tables, r[0], r[1], n_steps, rng_mode=1, philox_keys=keys), ranges))
+            mt_s = time.perf_counter() - c0
+            model = ""
+            try:
+                model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+            except Exception:
+                pass
+            line["cpu_baseline_all_cores"] = {
+                "value": n_mt * n_steps / mt_s, "unit": "env steps/s", "cores": len(ranges), "kind": "port",
+                "sample": "instances 0..%d, %d transitions each, %.1f s on %d threads (CPU quota of this box; %d host cores, %s)"
+                          % (n_mt - 1, n_steps, mt_s, len(ranges), os.cpu_count() or 0, model),
+            }
         if "vi" in line and args.vi_instances > 0:
             nv = min(256, args.vi_instances)
             c0 = time.perf_counter()
