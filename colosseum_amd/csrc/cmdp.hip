@@ -412,7 +412,9 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
         int64_t best_rounds = -1;
         p.ch = 256;
         p.G = 0;
+        const int force_ch = std::getenv("CMDP_K1L_CH") ? std::atoi(std::getenv("CMDP_K1L_CH")) : 0;  // tuning aid
         for (int ch : {256, 128, 112, 64}) {
+          if (force_ch && ch != force_ch) continue;
           const int pi = p.slot_bytes + 2 * ch;
           const int g1 = std::min<int>(64, (kLdsBudget - fixed) / pi);
           const int g2 = std::min<int>(64, (kLdsBudget / 2 - fixed) / pi);

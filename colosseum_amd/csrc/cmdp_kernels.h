@@ -291,7 +291,7 @@ __device__ __forceinline__ void flush_counts(int32_t* __restrict__ dst, int tota
 #define K1L_THREADS 256
 #define K1L_OVF 30                      // wrap events an instance can record between two flushes (8-bit counters)
 #define K1L_NRV 264                      // reward table entries in LDS: 256 codes + a zero entry (index 256) + pad
-#define K1L_FIXED (K1L_NRV * 8 + 64 * 4 + 64 * 8)   // rv2[K1L_NRV] f64, resets[64] i32, keys[64] uint2
+#define K1L_FIXED (K1L_NRV * 8 + 64 * 4 + 64 * 8 + 64 * 8)   // rv2[K1L_NRV] f64, resets[64] i32, keys[64] uint2, ntr[64] u64
 
 // Wavefront specialisation: lanes of wavefront 0 walk one instance each; wavefronts 1-3 are the random-policy
 // PRODUCERS -- they compute the Philox blocks of the NEXT chunk of p.ch transitions for all G instances into a
@@ -310,6 +310,7 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
   double* rv2 = reinterpret_cast<double*>(smem);                          // [256] reward value AFTER the range rescale
   int32_t* resets = reinterpret_cast<int32_t*>(smem + K1L_NRV * 8);       // [64]
   uint2* keys = reinterpret_cast<uint2*>(smem + K1L_NRV * 8 + 64 * 4);    // [64]
+  unsigned long long* ntr = reinterpret_cast<unsigned long long*>(smem + K1L_NRV * 8 + 64 * 4 + 64 * 8);  // [64] transition counters at launch
   const int CH = p.ch;
   unsigned char* ring = smem + K1L_FIXED;                                 // [2][G][CH] action bytes
   unsigned char* slots = ring + 2 * p.G * CH;
@@ -323,7 +324,7 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
   // `r * (max - min) - min` (base.py:1205-1207) applied once per distinct value: the same two float64 operations
   for (int i = tid; i < p.n_codes; i += K1L_THREADS) rv2[i] = p.rvals[i] * t.rscale - t.rmin;
   if (tid == 0) rv2[256] = 0.0;  // what the walker's software pipeline adds before it holds a real reward
-  if (tid < nb) keys[tid] = t.philox_key[g0 + tid];
+  if (tid < nb) { keys[tid] = t.philox_key[g0 + tid]; ntr[tid] = t.n_trans[g0 + tid]; }
   // ---- stage the tables: 16-byte loads from the aligned-down address, K1L_UNROLL of them in flight per
   //      thread (the element arrays carry 16 bytes of slack at both ends, see cmdp_create) -----------------
   {
@@ -414,7 +415,8 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
     const int per_slot = CH / 4 + 1;  // Philox blocks that can overlap a chunk window (unaligned start)
     for (int item = ptid; item < nb * per_slot; item += K1L_THREADS - 64) {
       const int slot = item / per_slot, qi = item - slot * per_slot;
-      const unsigned long long n0 = t.n_trans[g0 + slot] + (unsigned long long)first;  // first transition of the window
+      const unsigned long long n0 = ntr[slot] + (unsigned long long)first;  // first transition of the window (LDS copy:
+                                                                            // a global load per item made the producers as slow as the walk)
       const unsigned long long q = (n0 >> 2) + (unsigned long long)qi;
       const uint2 key = keys[slot];
       uint32_t w[4];
@@ -451,60 +453,88 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
       if (nfirst < n_steps) produce(buf ^ 1, nfirst, (int)min((int64_t)CH, n_steps - nfirst));
     } else if (walker) {
       const unsigned char* acts = ring + ((size_t)buf * p.G + tid) * CH;
-      // UNI: every walker of the group is at the same in-episode time (the usual case: one reset() for the whole
-      // batch, one horizon), so the episode-end test is a scalar one and costs the vector pipe nothing
-      auto walk = [&](auto uni_tag) {
-        constexpr bool UNI = decltype(uni_tag)::value;
-        int hs = UNI ? __builtin_amdgcn_readfirstlane(h) : 0, nres_s = 0;
-        for (int s0 = 0; s0 < len; s0 += 8) {
-          const uint2 aw = *reinterpret_cast<const uint2*>(acts + s0);  // eight action bytes, one LDS read
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if (s0 + j < len) {  // wave-uniform; false only in the last group of a ragged chunk
-              const int a = (int)(((j < 4 ? aw.x : aw.y) >> (8 * (j & 3))) & 0xffu);
-              // PACKED: `cur` and the table's successor field are ROW BASES (state * A): no multiply on the chain
-              const int row = PACKED ? cur + a : cur * A + a;
-              const int word = nx[row];  // the one load on the dependency chain
-              const int nxt = PACKED ? (word & smask) : word;
-              const int code = PACKED ? (word >> p.code_shift) : (int)rc[row];
-              // bookkeeping of the two previous transitions while the successor read is in flight
-              sum += pend_val;             // rewards are added in transition order: bit-equal to the sequential sum
-              pend_val = rv2[pend_code];
-              // visit count of the ARRIVAL node under the action taken (base.py:1302-1303)
-              if (PACKED) {
-                // 8-bit counter, read-modify-write by its only owner (LDS executes a wave's operations in order, so
-                // the next transition's read sees this write); a wrap is recorded in the overflow list and costs
-                // nothing otherwise.  Half the bytes of the 16-bit form: 40 % more instances fit a CU.
-                // (branch-free: the list slot behind the last entry is written every time and only kept on a wrap)
-                const int c1 = (int)c8[pend_crow] + 1;
-                ovf[n_ovf] = (uint16_t)pend_crow;
-                n_ovf += c1 >> 8;
-                c8[pend_crow] = (uint8_t)c1;
-              } else {
-                atomicAdd(cnt + (pend_crow >> 1), (pend_crow & 1) ? 0x10000u : 1u);  // 16-bit halves of a dword
-              }
-              pend_crow = PACKED ? nxt + a : nxt * A + a;
-              pend_code = code;
-              if (UNI) {
-                ++hs;
-                const bool term = hs >= H;  // scalar
-                cur = term ? start_k : nxt;
-                hs = term ? 0 : hs;
-                nres_s += term ? 1 : 0;
-              } else {
-                ++h;
-                const bool term = episodic && h >= H;  // episodic termination followed at once by reset()
-                cur = term ? start_k : nxt;
-                h = term ? 0 : h;
-                n_resets += term ? 1 : 0;
-              }
-            }
-          }
+      // The walker is bound by the number of instructions it issues per transition (a lone wavefront issues one every
+      // 4-8 cycles: ~25 instructions made ~85 ns, against ~35 ns for the bare dependent LDS chain,
+      // tools/calib/lds_chase.hip), so the body exists in three flavours chosen per group of 8 transitions:
+      //   T0  all walkers share their in-episode time and no episode ends inside the group: no episode logic at all
+      //   T1  shared in-episode time, scalar episode-end test
+      //   T2  per-lane in-episode time (general case)
+      // and the loop over whole groups carries no per-transition bounds test (the ragged tail runs separately).
+      int hs = uniform_h ? __builtin_amdgcn_readfirstlane(h) : 0, nres_s = 0;
+      auto step = [&](int a, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        // PACKED: `cur` and the table's successor field are ROW BASES (state * A): no multiply on the chain
+        const int row = PACKED ? cur + a : cur * A + a;
+        const int word = nx[row];  // the one load on the dependency chain
+        const int nxt = PACKED ? (word & smask) : word;
+        const int code = PACKED ? (word >> p.code_shift) : (int)rc[row];
+        // bookkeeping of the two previous transitions while the successor read is in flight
+        sum += pend_val;             // rewards are added in transition order: bit-equal to the sequential sum
+        pend_val = rv2[pend_code];
+        // visit count of the ARRIVAL node under the action taken (base.py:1302-1303)
+        if (PACKED) {
+          // 8-bit counter, read-modify-write by its only owner (LDS executes a wave's operations in order, so the
+          // next transition's read sees this write); a wrap is recorded in the overflow list (a vote + branch instead was
+          // slower: it forces the wait for the count read at once).  Half the bytes of the 16-bit form: 40 % more instances fit a CU.
+          const int c1 = (int)c8[pend_crow] + 1;
+          ovf[n_ovf] = (uint16_t)pend_crow;  // branch-free: the slot behind the last entry is only kept on a wrap
+          n_ovf += c1 >> 8;
+          c8[pend_crow] = (uint8_t)c1;
+        } else {
+          atomicAdd(cnt + (pend_crow >> 1), (pend_crow & 1) ? 0x10000u : 1u);  // 16-bit halves of a dword
         }
-        if (UNI) { h = hs; n_resets += nres_s; }
+        pend_crow = PACKED ? nxt + a : nxt * A + a;
+        pend_code = code;
+        if (MODE == 0) {
+          cur = nxt;
+        } else if (MODE == 1) {
+          ++hs;
+          const bool term = hs >= H;  // scalar
+          cur = term ? start_k : nxt;
+          hs = term ? 0 : hs;
+          nres_s += term ? 1 : 0;
+        } else {
+          ++h;
+          const bool term = episodic && h >= H;  // episodic termination followed at once by reset()
+          cur = term ? start_k : nxt;
+          h = term ? 0 : h;
+          n_resets += term ? 1 : 0;
+        }
       };
-      if (uniform_h) walk(std::true_type{});
-      else walk(std::false_type{});
+      using T0 = std::integral_constant<int, 0>;
+      using T1 = std::integral_constant<int, 1>;
+      using T2 = std::integral_constant<int, 2>;
+      int s0 = 0;
+      for (; s0 + 8 <= len; s0 += 8) {
+        const uint2 aw = *reinterpret_cast<const uint2*>(acts + s0);  // eight action bytes, one LDS read
+#define K1L_ACT(j) (int)((((j) < 4 ? aw.x : aw.y) >> (8 * ((j) & 3))) & 0xffu)
+        if (uniform_h && hs + 8 < H) {
+          step(K1L_ACT(0), T0{}); step(K1L_ACT(1), T0{}); step(K1L_ACT(2), T0{}); step(K1L_ACT(3), T0{});
+          step(K1L_ACT(4), T0{}); step(K1L_ACT(5), T0{}); step(K1L_ACT(6), T0{}); step(K1L_ACT(7), T0{});
+          hs += 8;
+        } else if (uniform_h && H >= 8) {
+          // exactly one episode ends inside this group, after transition jstar: plain transitions around one reset
+          const int jstar = H - hs - 1;
+#define K1L_STEP_R(j)                               \
+  step(K1L_ACT(j), T0{});                           \
+  if (jstar == (j)) { cur = start_k; ++nres_s; }
+          K1L_STEP_R(0) K1L_STEP_R(1) K1L_STEP_R(2) K1L_STEP_R(3) K1L_STEP_R(4) K1L_STEP_R(5) K1L_STEP_R(6) K1L_STEP_R(7)
+#undef K1L_STEP_R
+          hs = 7 - jstar;
+        } else if (uniform_h) {
+          step(K1L_ACT(0), T1{}); step(K1L_ACT(1), T1{}); step(K1L_ACT(2), T1{}); step(K1L_ACT(3), T1{});
+          step(K1L_ACT(4), T1{}); step(K1L_ACT(5), T1{}); step(K1L_ACT(6), T1{}); step(K1L_ACT(7), T1{});
+        } else {
+          step(K1L_ACT(0), T2{}); step(K1L_ACT(1), T2{}); step(K1L_ACT(2), T2{}); step(K1L_ACT(3), T2{});
+          step(K1L_ACT(4), T2{}); step(K1L_ACT(5), T2{}); step(K1L_ACT(6), T2{}); step(K1L_ACT(7), T2{});
+        }
+#undef K1L_ACT
+      }
+      for (; s0 < len; ++s0) {  // ragged tail of the launch's last chunk
+        const int a = acts[s0];
+        if (uniform_h) step(a, T1{}); else step(a, T2{});
+      }
+      if (uniform_h) { h = hs; n_resets += nres_s; }
     }
     done += len;
     since_flush += len;

@@ -165,7 +165,13 @@ def test_lds_resident_rollout_equals_global_kernel_and_oracle(need_gpu):
     instances-per-workgroup), visits / last observation / reward sums bit-equal."""
     from colosseum_amd.mdp.fast_batch import deepsea_episodic_tables
 
-    B, size, n1, n2 = 75, 12, 50, 70_000
+    for size, n2 in ((12, 70_000), (5, 9_000)):   # horizon 5 < 8: several episode ends inside one group of 8 transitions
+        _check_lds_rollout(75, size, 50, n2)
+
+
+def _check_lds_rollout(B, size, n1, n2):
+    from colosseum_amd.mdp.fast_batch import deepsea_episodic_tables
+
     seeds = np.arange(1000, 1000 + B)
     tables = deepsea_episodic_tables(seeds, size)
     keys = (seeds * 7919).astype(np.uint64)
