@@ -85,6 +85,7 @@ struct cmdp {
   double rmin = 0, rmax = 1;
   int64_t n_states = 0, n_rows = 0, n_entries = 0, n_csr = 0, n_slots = 0;
   bool has_env = false, has_dp = false;
+  bool sample_beta = false;  // Beta rewards drawn on the device (CMDP_RNG_PHILOX without CMDP_FLAG_REWARD_MEANS)
   std::vector<int64_t> state_off;  // host copy
   std::vector<int64_t> csr_nnz;    // per instance
   int max_S = 0;
@@ -258,6 +259,7 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
         any_beta |= d->sp_rkind[e] == 1;
       }
     const bool sample_beta = any_beta && !(d->flags & CMDP_FLAG_REWARD_MEANS);
+    h->sample_beta = sample_beta;
     if (sample_beta) {
       if (d->rng_mode != CMDP_RNG_PHILOX || !d->sp_rp0 || !d->sp_rp1)
         return fail(CMDP_ERR_UNSUPPORTED, "Beta rewards are sampled on the device only in CMDP_RNG_PHILOX mode with sp_rp0/"
@@ -593,8 +595,8 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
   EnvTables t = h->env();
   if (policy == CMDP_POLICY_GREEDY_Q) {
     if (h->layout == CMDP_LAYOUT_DENSE) return fail(CMDP_ERR_UNSUPPORTED, "CMDP_POLICY_GREEDY_Q runs on the CSR layout");
-    if (trace) hipLaunchKernelGGL((k_rollout<2, true>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype, d_q);
-    else hipLaunchKernelGGL((k_rollout<2, false>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype, d_q);
+    if (trace) hipLaunchKernelGGL((k_rollout<2, true, true>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype, d_q);
+    else hipLaunchKernelGGL((k_rollout<2, false, true>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype, d_q);
     HIP_TRY(hipGetLastError());
     return CMDP_OK;
   }
@@ -603,16 +605,17 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
     DenseArgs dn{h->d_dense.p, h->dense_spad};
     const dim3 dgrid(grid_for(h->B, 4));
     const int nv = h->dense_spad / 256;
-#define DENSE_CASE(NV)                                                                                            \
-  if (nv == NV) {                                                                                                 \
-    if (policy == CMDP_POLICY_RANDOM)                                                                             \
-      hipLaunchKernelGGL((k_rollout_dense<0, NV>), dgrid, block, 0, st, t, dn, d_actions, n_steps, d_rsum, d_last); \
-    else                                                                                                          \
-      hipLaunchKernelGGL((k_rollout_dense<1, NV>), dgrid, block, 0, st, t, dn, d_actions, n_steps, d_rsum, d_last); \
+#define DENSE_LAUNCH(P, NV, BT) \
+  hipLaunchKernelGGL((k_rollout_dense<P, NV, BT>), dgrid, block, 0, st, t, dn, d_actions, n_steps, d_rsum, d_last)
+#define DENSE_CASE(NV)                                                                            \
+  if (nv == NV) {                                                                                 \
+    if (policy == CMDP_POLICY_RANDOM) { if (h->sample_beta) DENSE_LAUNCH(0, NV, true); else DENSE_LAUNCH(0, NV, false); } \
+    else { if (h->sample_beta) DENSE_LAUNCH(1, NV, true); else DENSE_LAUNCH(1, NV, false); }      \
   } else
     DENSE_CASE(1) DENSE_CASE(2) DENSE_CASE(3) DENSE_CASE(4) DENSE_CASE(6) DENSE_CASE(8) DENSE_CASE(12) DENSE_CASE(16)
     { return fail(CMDP_ERR_UNSUPPORTED, "dense layout: no kernel for a row stride of %d floats", h->dense_spad); }
 #undef DENSE_CASE
+#undef DENSE_LAUNCH
     HIP_TRY(hipGetLastError());
     return CMDP_OK;
   }
@@ -633,13 +636,17 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
     HIP_TRY(hipGetLastError());
     return CMDP_OK;
   }
+#define ROLL(P, TR, BT) \
+  hipLaunchKernelGGL((k_rollout<P, TR, BT>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype)
+  const bool bt = h->sample_beta;
   if (policy == CMDP_POLICY_RANDOM) {
-    if (trace) hipLaunchKernelGGL((k_rollout<0, true>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype);
-    else hipLaunchKernelGGL((k_rollout<0, false>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype);
+    if (trace) { if (bt) ROLL(0, true, true); else ROLL(0, true, false); }
+    else { if (bt) ROLL(0, false, true); else ROLL(0, false, false); }
   } else {
-    if (trace) hipLaunchKernelGGL((k_rollout<1, true>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype);
-    else hipLaunchKernelGGL((k_rollout<1, false>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype);
+    if (trace) { if (bt) ROLL(1, true, true); else ROLL(1, true, false); }
+    else { if (bt) ROLL(1, false, true); else ROLL(1, false, false); }
   }
+#undef ROLL
   HIP_TRY(hipGetLastError());
   return CMDP_OK;
 }

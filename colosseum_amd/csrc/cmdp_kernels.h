@@ -106,6 +106,9 @@ __device__ __forceinline__ int32_t env_reset(const EnvTables& t, int b, int64_t 
 
 // BaseMDP.step (reference colosseum/mdp/base.py:1293-1317) for one instance.
 // Returns the step type (1 MID, 2 LAST); `action` < 0 requests the Philox random-policy action.
+// BETA = false compiles the Beta-reward sampler (Marsaglia-Tsang gammas: log/pow/cos in float64, ~100 VGPRs) out of
+// the kernel: handles without stochastic rewards then run at twice the occupancy.
+template <bool BETA = true>
 __device__ __forceinline__ int env_step(const EnvTables& t, int64_t soff, int64_t ebase, uint2 key, int32_t& cur,
                                         int32_t& h, unsigned long long& n_trans, int action, int32_t& obs,
                                         double& reward) {
@@ -131,7 +134,7 @@ __device__ __forceinline__ int env_step(const EnvTables& t, int64_t soff, int64_
     nxt = t.sp_next[e];
     rraw = t.sp_reward[e];
   }
-  if (t.sp_rkind && t.sp_rkind[e] == 1) rraw = philox_beta(t.sp_rp0[e], t.sp_rp1[e], n, key);  // throughput mode only
+  if (BETA && t.sp_rkind && t.sp_rkind[e] == 1) rraw = philox_beta(t.sp_rp0[e], t.sp_rp1[e], n, key);  // throughput mode only
   // visit counts on the arrival node with the action taken at the departure node (base.py:1302-1303)
   bump(t.visits_s + soff + nxt);
   bump(t.visits_sa + (soff + nxt) * t.A + action);
@@ -204,7 +207,7 @@ __global__ void k_step(EnvTables t, const int32_t* __restrict__ actions, int aut
 // POLICY 0: Philox random action; 1: actions[t][B] (int8).
 // POLICY 0: on-device uniform random; 1: host action stream; 2: greedy in a Q table (`qtab`: per instance [S][A], or
 // [H][S][A] indexed by the in-episode time when the handle is episodic), first maximiser.
-template <int POLICY, bool TRACE>
+template <int POLICY, bool TRACE, bool BETA>
 __global__ void __launch_bounds__(256) k_rollout(EnvTables t, const int8_t* __restrict__ actions, int64_t n_steps,
                                                  double* __restrict__ reward_sum, int32_t* __restrict__ last_obs,
                                                  int32_t* __restrict__ tr_obs, double* __restrict__ tr_rew,
@@ -228,7 +231,7 @@ __global__ void __launch_bounds__(256) k_rollout(EnvTables t, const int8_t* __re
         if (q[k] > best) { best = q[k]; a = k; }
     }
     double r;
-    const int ty = env_step(t, soff, ebase, key, cur, h, nt, a, obs, r);
+    const int ty = env_step<BETA>(t, soff, ebase, key, cur, h, nt, a, obs, r);
     sum += r;
     if (TRACE) {
       if (tr_obs) tr_obs[s * t.B + b] = obs;
@@ -676,7 +679,7 @@ __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
 // partial-sum pass and the search pass.  The Philox work of a wavefront is spread over its lanes: every 64
 // transitions lane j computes the transition uniform of transition base+j and the action block base/4+j, and
 // the per-transition values are then broadcast with one shuffle each (values are wave-uniform anyway).
-template <int POLICY, int NV>
+template <int POLICY, int NV, bool BETA>
 __global__ void __launch_bounds__(256) k_rollout_dense(EnvTables t, DenseArgs dn, const int8_t* __restrict__ actions,
                                                        int64_t n_steps, double* __restrict__ reward_sum,
                                                        int32_t* __restrict__ last_obs) {
@@ -767,7 +770,7 @@ __global__ void __launch_bounds__(256) k_rollout_dense(EnvTables t, DenseArgs dn
       ent += found;
       rraw = t.sp_reward[ent];
     }
-    if (t.sp_rkind && t.sp_rkind[ent] == 1) rraw = philox_beta(t.sp_rp0[ent], t.sp_rp1[ent], nt - 1, key);
+    if (BETA && t.sp_rkind && t.sp_rkind[ent] == 1) rraw = philox_beta(t.sp_rp0[ent], t.sp_rp1[ent], nt - 1, key);
     sum += rraw * t.rscale - t.rmin;
     if (lane == 0) {
       bump(t.visits_s + soff + nxt);
