@@ -606,3 +606,56 @@ class Taxi(Family):
             if node[2] == -1 and next_node[2] != -1:
                 return self.success_r
         return self.default_r
+
+
+class Custom(Family):
+    """mdp/custom_mdp.py:80-104,184-232.  Node = (ID,); the user gives the start distribution T_0 (dict state -> prob,
+    or an array), the transition array T [S, A, S] and the rewards R: a dict (state, action) -> distribution (scipy
+    frozen distribution or ("deterministic", (v,)) / ("beta", (a, b)) tuple) or an [S, A] array.
+
+    As in the reference every reward is DETERMINISTIC and equal to the distribution's mean (its `R` property returns
+    the mean matrix, so the `type(self.R) == dict` branch of `_get_reward_distribution` never runs, :96-100).  Deviation:
+    the reference's array-R constructor raises (`_R` is unbound, :207-211); here an array R means what the docstring
+    says.  T is taken as float64 (a float32 T would make the reference's samplers accumulate in float32)."""
+
+    name = "Custom"
+
+    def __init__(self, T_0, T, R):
+        self.T = np.asarray(T, np.float64)
+        assert self.T.ndim == 3 and self.T.shape[0] == self.T.shape[2]
+        S, A = self.T.shape[:2]
+        self.n_actions = A
+        if isinstance(R, dict):
+            Rm = np.zeros((S, A), np.float32)
+            for (s_, a_), d in R.items():
+                if isinstance(d, tuple):
+                    Rm[s_, a_] = dist_mean(_dist(d))
+                else:
+                    Rm[s_, a_] = d.mean()
+        else:
+            Rm = np.asarray(R, np.float32)
+            assert Rm.shape == (S, A)
+        self.R = Rm
+        if isinstance(T_0, dict):
+            self.T_0 = {int(k): float(v) for k, v in T_0.items()}
+        else:
+            self.T_0 = {i: float(p) for i, p in enumerate(np.asarray(T_0)) if p > 0}
+        assert np.isclose(sum(self.T_0.values()), 1)
+        for s_ in range(S):
+            for a_ in range(A):
+                assert np.isclose(self.T[s_, a_].sum(), 1), (
+                    f"The transition kernel associated with state {s_} and action {a_} is not a well defined "
+                    f"probability distribution.")
+
+    def possible_starting_nodes(self):
+        return [(k,) for k in self.T_0]
+
+    def start(self, rng, fast_rng):
+        return StartSpec(self.possible_starting_nodes(), list(self.T_0.values()), True)
+
+    def next_nodes(self, node, action):
+        row = self.T[node[0], action]
+        return tuple(((int(j),), float(row[j])) for j in range(len(row)) if row[j] > 0.0)
+
+    def reward_dist(self, node, action, next_node):
+        return ("deterministic", float(self.R[node[0], action]))

@@ -301,3 +301,5 @@ SimpleGridEpisodic = _make_class("SimpleGridEpisodic")
 SimpleGridContinuous = _make_class("SimpleGridContinuous")
 TaxiEpisodic = _make_class("TaxiEpisodic")
 TaxiContinuous = _make_class("TaxiContinuous")
+CustomEpisodic = _make_class("CustomEpisodic")
+CustomContinuous = _make_class("CustomContinuous")

@@ -6,7 +6,7 @@ configuration written for the reference can be fed here unchanged."""
 from typing import Any, Dict
 
 from .builder import TabularModel, build_model
-from .families import DeepSea, FrozenLake, MiniGridEmpty, MiniGridRooms, RiverSwim, SimpleGrid, Taxi
+from .families import Custom, DeepSea, FrozenLake, MiniGridEmpty, MiniGridRooms, RiverSwim, SimpleGrid, Taxi
 
 _BASE_KEYS = ("randomize_actions", "p_lazy", "p_rand", "rewards_range")
 _IGNORED = ("emission_map", "emission_map_kwargs", "noise", "noise_kwargs", "instantiate_mdp",
@@ -20,6 +20,7 @@ FAMILIES = {
     "RiverSwim": RiverSwim,
     "SimpleGrid": SimpleGrid,
     "Taxi": Taxi,
+    "Custom": Custom,
 }
 
 

@@ -21,6 +21,7 @@ Fixture groups:
   G5  hardness known-answer table lifted from benchmark/cached_hardness_measures/*.txt
   G6  episodic/continuous diameter + value-norm recomputed by the reference here (small cases)
   G7  MDPLoop + QLearningEpisodic logger rows and action stream (config C1, plumbing)
+  G13 CustomMDP (user-given T_0, T, R)
   G12 RiverSwim / SimpleGrid / Taxi: structure, DP values, trajectories
   G10 MDPLoop + QLearningContinuous logger rows (continuous-setting regret via stationary distributions)
   G9  stationary distributions / average rewards of the continuous setting
@@ -736,7 +737,39 @@ def g12():
     save("G12_families", **arrays)
 
 
-GROUPS = dict(G12=g12, G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11)
+
+def g13():
+    """CustomMDP: user-given T_0, T, R (dict of distributions -- the only form the reference accepts)."""
+    from colosseum.mdp.custom_mdp import CustomContinuous, CustomEpisodic
+    from colosseum.utils.miscellanea import deterministic
+
+    rng = np.random.RandomState(7)
+    cases, arrays = [], {}
+    for cls, S, A, base in ((CustomContinuous, 7, 3, dict(p_rand=0.1)), (CustomEpisodic, 5, 2, dict(H=6, p_lazy=0.05)),
+                            (CustomContinuous, 12, 4, dict())):
+        T = rng.rand(S, A, S)
+        T[T < 0.55] = 0
+        T[:, :, 0] += 1e-3
+        T /= T.sum(-1, keepdims=True)
+        Rm = np.round(rng.rand(S, A), 3)
+        T0 = {0: 0.25, S - 1: 0.75} if cls is CustomContinuous else {1: 1.0}
+        R = {(s, a): deterministic(float(Rm[s, a])) for s in range(S) for a in range(A)}
+        mdp = cls(seed=len(cases) + 2, T_0=T0, T=T, R=R, **base)
+        key = f"c{len(cases)}_"
+        st = structure(mdp)
+        arrays.update(flat(key, st))
+        arrays[key + "in_T"], arrays[key + "in_R"] = T, Rm
+        arrays[key + "in_T0k"], arrays[key + "in_T0v"] = np.array(list(T0.keys())), np.array(list(T0.values()))
+        acts = np.random.RandomState(900 + len(cases)).randint(0, A, 4000)
+        tr = trajectory(mdp, acts)
+        arrays.update(flat(key, tr))
+        cases.append(dict(cls=cls.__name__, kwargs=dict(seed=len(cases) + 2, **base), extra={}))
+        print("   ", cls.__name__, base, "S=", mdp.n_states)
+    arrays["cases"] = np.array(json.dumps(cases))
+    save("G13_custom", **arrays)
+
+
+GROUPS = dict(G13=g13, G12=g12, G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

@@ -82,7 +82,7 @@ def test_constructor_checks():
     with pytest.raises(AssertionError):
         make_model("DeepSeaEpisodic", seed=0, size=5, p_lazy=0.1)  # no lazy mechanic for DeepSea
     with pytest.raises(KeyError):
-        make_model("CustomEpisodic", seed=0, size=5)  # CustomMDP is not built
+        make_model("RandomWalkEpisodic", seed=0, size=5)  # not a reference family
     with pytest.raises(NotImplementedError):
         make_model("DeepSeaEpisodic", seed=0)
 
@@ -108,3 +108,43 @@ def test_recurrent_class_order_is_networkx_attracting_components_order():
         assert got == want, trial
         seen_multi += len(want) > 1
     assert seen_multi > 50
+
+
+def _custom_model(z, k, c):
+    T0 = {int(a): float(b) for a, b in zip(z[k + "in_T0k"], z[k + "in_T0v"])}
+    return make_model(c["cls"], T_0=T0, T=z[k + "in_T"], R=z[k + "in_R"], **c["kwargs"])
+
+
+def test_custom_mdp_matches_reference():
+    """CustomMDP (golden G13: the reference built from a dict of deterministic reward distributions; here from the mean
+    matrix, which is what the reference reduces the dict to): structure, sampler seeds, and through the oracle the
+    4 000-step reference trajectories."""
+    import random
+
+    from oracle import oracle as O
+
+    z, cases = load_golden("G13_custom")
+    for i, c in enumerate(cases):
+        k = f"c{i}_"
+        m = _custom_model(z, k, c)
+        S, A, H = z[k + "SAH"]
+        assert (m.n_states, m.n_actions, m.H) == (S, A, H), c
+        for name in ("nodes", "sp_ptr", "sp_next", "sp_prob", "sp_rmean", "start_states", "start_probs"):
+            np.testing.assert_array_equal(getattr(m, name), z[k + name], err_msg=name)
+        # (the reference's `T`, `R` properties return the USER's arrays, indexed by node ID and raw action
+        #  (custom_mdp.py:213), not the matrices of the graph it simulates -- state indices follow the DFS and actions the
+        #  per-state permutation; the sampler tables above are the dynamics, and they are equal)
+        np.testing.assert_array_equal(z[k + "R"], z[k + "in_R"].astype(np.float32))
+        first = z[k + "sp_first"]
+        for r in range(S * A):
+            lo, hi = m.sp_ptr[r], m.sp_ptr[r + 1]
+            if hi - lo > 1:
+                got = random.Random(int(m.sp_seed[r])).choices(m.sp_next[lo:hi].tolist(), weights=m.sp_prob[lo:hi].tolist(), k=8)
+                assert got == first[r].tolist()
+        e = O.OracleEnv(m, rng_mode=0)
+        assert e.reset() == z[k + "resets"][0]
+        out = e.rollout(len(z[k + "actions"]), z[k + "actions"])
+        np.testing.assert_array_equal(out["obs"], z[k + "obs"])
+        np.testing.assert_array_equal(out["rew"], z[k + "rew"])
+        vs, vsa = e.visits()
+        np.testing.assert_array_equal(vs, z[k + "visits_s"])

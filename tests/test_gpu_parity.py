@@ -621,3 +621,24 @@ def test_greedy_q_policy_rollout(need_gpu):
         np.testing.assert_array_equal(out["obs"], ref["obs"], err_msg=cls)
         np.testing.assert_array_equal(out["rew"], ref["rew"])
         np.testing.assert_array_equal(out["stype"], ref["stype"])
+
+
+def test_custom_mdp_trajectories_on_device(need_gpu):
+    """CustomMDP (golden G13): the device's MT19937 streams reproduce the reference's 4 000-step trajectories."""
+    z, cases = load_golden("G13_custom")
+    for i, c in enumerate(cases):
+        k = f"c{i}_"
+        T0 = {int(a): float(b) for a, b in zip(z[k + "in_T0k"], z[k + "in_T0v"])}
+        m = make_model(c["cls"], T_0=T0, T=z[k + "in_T"], R=z[k + "in_R"], **c["kwargs"])
+        env = BatchedMDP([m], rng_mode=L.RNG_MT_COMPAT, with_dp=False)
+        first = env.reset()
+        acts = z[k + "actions"][:, None]
+        out = env.rollout(len(acts), acts, trace=True)
+        vs, vsa = env.visits()
+        assert first[0] == z[k + "resets"][0]
+        np.testing.assert_array_equal(out["obs"][:, 0], z[k + "obs"])
+        np.testing.assert_array_equal(out["rew"][:, 0], z[k + "rew"])
+        np.testing.assert_array_equal(out["stype"][:, 0], z[k + "stype"])
+        np.testing.assert_array_equal(vs, z[k + "visits_s"])
+        np.testing.assert_array_equal(vsa.reshape(-1, env.A), z[k + "visits_sa"])
+        env.close()
