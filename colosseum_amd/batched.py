@@ -314,7 +314,7 @@ class BatchedMDP:
         """Optimal expected hitting times (max over start states) of the targets [target_lo, target_hi) of the flat
         state space, Jacobi scheme, 64 targets per workgroup (kernel K5S): the shard of `diameter()` one GPU takes
         when one large MDP is split over ranks (config C5)."""
-        per = np.zeros(int(target_hi) - int(target_lo), np.float32)
+        per = np.zeros(max(0, int(target_hi) - int(target_lo)), np.float32)  # a reversed range is refused by the library
         L.check(self._lib.cmdp_diameter_range(self._h, float(epsilon), int(max_sweeps), int(target_lo), int(target_hi),
                                               L.ptr(per)))
         return per

@@ -94,3 +94,30 @@ def test_mixing_time_against_dense_float64_powers(need_gpu):
                 break
         assert want is not None and t[i] == want[0], (i, t[i], want)
         assert tv[i] == pytest.approx(want[1], rel=1e-10)
+
+
+def test_chain_api_argument_checks(need_gpu):
+    """Error paths of the new entry points: they fail loudly with a library error, never with a GPU fault."""
+    m = make_model("FrozenLakeContinuous", seed=3, size=5, p_frozen=0.8)
+    S, A = m.n_states, m.n_actions
+    env = BatchedMDP([m, m], rng_mode=L.RNG_PHILOX, with_env=False)
+    good = [np.zeros(S, np.int32)] * 2
+    with pytest.raises(L.CmdpError):
+        env.average_reward([np.full(S, A, np.int32)] * 2, [0, 0])       # action out of range
+    with pytest.raises(L.CmdpError):
+        env.average_reward(good, [0, S])                               # start state out of range
+    vals, ncls = env.average_reward(good, [0, S - 1])
+    assert all(np.isfinite(v) for v in vals) and (ncls >= 1).all()
+    with pytest.raises(L.CmdpError):
+        env.diameter_range(5, 3)                                       # empty / reversed range
+    with pytest.raises(L.CmdpError):
+        env.diameter_range(0, 2 * S + 1)                               # beyond the flat state space
+    assert env.diameter_range(4, 4).size == 0
+    with pytest.raises(L.CmdpError):
+        env.mixing_time([np.full(S, 1.0 / S)] * 2, threshold=0.0)      # threshold must be positive
+    env.close()
+    ep = make_model("DeepSeaEpisodic", seed=0, size=4)
+    env = BatchedMDP([ep], rng_mode=L.RNG_PHILOX, with_env=False)
+    with pytest.raises(L.CmdpError):                                   # average rewards are a continuous-setting notion
+        env.average_reward([np.zeros(ep.n_states, np.int32)], [0])
+    env.close()
