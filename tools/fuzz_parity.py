@@ -1,0 +1,119 @@
+"""Randomised parity sweep: random family / size / noise parameters, GPU against the CPU oracle, bit for bit.
+    python tools/fuzz_parity.py [seconds] [seed]
+Covers: MT_COMPAT trajectories with host actions, Philox random-policy rollouts (LDS-resident kernel when eligible),
+discounted VI/PE (both schemes), episodic VI, diameter (workgroup kernel and the 64-targets-per-workgroup kernel),
+average reward of random deterministic policies (K9, exact-order mode against the host restatement)."""
+import sys, time
+import numpy as np
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from colosseum_amd import _lib as L
+from colosseum_amd.batched import BatchedMDP
+from colosseum_amd.markov_chain import get_average_reward
+from colosseum_amd.mdp import make_model
+from oracle import oracle as O
+
+rng = np.random.default_rng(0)
+
+
+def random_model():
+    fam = rng.choice(["DeepSea", "FrozenLake", "MiniGridEmpty", "MiniGridRooms", "RiverSwim", "SimpleGrid", "Taxi"])
+    episodic = bool(rng.integers(0, 2))
+    kw = dict(seed=int(rng.integers(0, 10_000)))
+    p_rand = float(rng.choice([0, 0.05, 0.3])) or None
+    p_lazy = float(rng.choice([0, 0.1])) or None
+    if fam == "DeepSea":
+        kw.update(size=int(rng.integers(3, 14)))
+        p_lazy = None
+    elif fam == "FrozenLake":
+        kw.update(size=int(rng.integers(3, 9)), p_frozen=float(rng.choice([0.7, 0.9, 1.0])), is_slippery=bool(rng.integers(0, 2)))
+    elif fam == "MiniGridEmpty":
+        kw.update(size=int(rng.integers(3, 8)), n_starting_states=int(rng.integers(1, 4)))
+    elif fam == "MiniGridRooms":
+        kw.update(room_size=int(rng.integers(3, 5)), n_rooms=int(rng.choice([4, 9])), n_starting_states=int(rng.integers(1, 3)))
+    elif fam == "RiverSwim":
+        kw.update(size=int(rng.integers(3, 30)))
+    elif fam == "SimpleGrid":
+        kw.update(size=int(rng.integers(3, 8)), reward_type=int(rng.integers(0, 4)), n_starting_states=int(rng.integers(1, 4)))
+    else:
+        kw.update(size=int(rng.integers(5, 7)))
+    if p_rand: kw["p_rand"] = p_rand
+    if p_lazy: kw["p_lazy"] = p_lazy
+    if rng.integers(0, 4) == 0 and fam != "Taxi": kw["randomize_actions"] = False
+    cls = fam + ("Episodic" if episodic else "Continuous")
+    return cls, kw, make_model(cls, **kw)
+
+
+def check_one():
+    cls, kw, m = random_model()
+    S, A, H = m.n_states, m.n_actions, m.H
+    tag = (cls, kw)
+    # --- MT_COMPAT with host actions + Philox random policy -----------------------------------------------------------
+    n = int(rng.integers(50, 3000))
+    acts = rng.integers(0, A, n).astype(np.int8)
+    env = BatchedMDP([m, m], rng_mode=L.RNG_MT_COMPAT)
+    first = env.reset()
+    out = env.rollout(n, np.stack([acts, acts], 1), trace=True)
+    e = O.OracleEnv(m, rng_mode=0)
+    assert e.reset() == first[0], tag
+    ref = e.rollout(n, acts)
+    for b in range(2):
+        assert np.array_equal(out["obs"][:, b], ref["obs"]) and np.array_equal(out["rew"][:, b], ref["rew"]), tag
+    assert np.array_equal(env.split_states(env.visits()[0])[1], e.visits()[0]), tag
+    # --- DP on the same handle -----------------------------------------------------------------------------------------
+    if H:
+        Q, V = env.episodic_value_iteration()
+        oQ, oV = O.episodic(S, A, H, m.csr(), m.reward_matrix())
+        assert np.array_equal(env.split_states(V, H + 1)[0].reshape(H + 1, S), oV), tag
+    else:
+        for scheme in (L.SCHEME_JACOBI, L.SCHEME_GAUSS_SEIDEL):
+            g = float(rng.choice([0.9, 0.99]))
+            Q, V, sw = env.value_iteration(g, 1e-5, scheme)
+            oQ, oV, oit, _ = O.vi_discounted(S, A, m.csr(), m.reward_matrix(), g, 1e-5, scheme)
+            assert np.array_equal(env.split_states(V)[1], oV) and sw[1] == oit, (tag, scheme)
+        if S <= 120:
+            d0, per0 = env.diameter(1e-3, L.SCHEME_JACOBI)
+            env.set_option(L.OPT_DP_KERNEL, 3)
+            d1, per1 = env.diameter(1e-3, L.SCHEME_JACOBI)
+            env.set_option(L.OPT_DP_KERNEL, 0)
+            _, oper = O.diameter_continuous(S, A, m.csr(), scheme=1)
+            assert np.array_equal(per0[:S], oper) and np.array_equal(per1, per0), tag
+        pol = rng.integers(0, A, S).astype(np.int32)
+        st = int(rng.integers(0, S))
+        env.set_option(L.OPT_CHAIN_EXACT_ORDER, 1)
+        vals, ncls = env.average_reward([pol, pol], [st, st])
+        T, R = m.dense()
+        oh = np.zeros((S, A), np.float32); oh[np.arange(S), pol] = 1
+        want = get_average_reward(T, R, oh, [(st, 1.0)])
+        assert type(vals[0]) is type(want) and vals[0] == want, (tag, vals[0], want, ncls)
+    env.close()
+    if m.deterministic_rewards:
+        keys = rng.integers(1, 2**40, 3).astype(np.uint64)
+        env = BatchedMDP([m] * 3, rng_mode=L.RNG_PHILOX, philox_keys=keys, with_dp=False)
+        env.reset()
+        o2 = env.rollout(n)
+        vs, _ = env.visits()
+        for b in range(3):
+            e = O.OracleEnv(m, rng_mode=1, philox_key=int(keys[b]))
+            e.reset()
+            r2 = e.rollout(n, trace=False)
+            assert o2["last_obs"][b] == r2["last_obs"] and o2["reward_sum"][b] == r2["reward_sum"], tag
+            assert np.array_equal(env.split_states(vs)[b], e.visits()[0]), tag
+        env.close()
+
+
+def run(seconds=None, n_cases=None, seed=0):
+    """Runs for `seconds` or for exactly `n_cases` random MDPs; raises AssertionError on the first mismatch."""
+    global rng
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + (seconds or 1e9)
+    done = 0
+    while time.time() < t_end and (n_cases is None or done < n_cases):
+        check_one()
+        done += 1
+    return done
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    print("fuzz parity: %d random MDPs, all checks bit-equal" % run(seconds=budget, seed=seed))
