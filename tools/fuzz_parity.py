@@ -11,6 +11,10 @@ from colosseum_amd.batched import BatchedMDP
 from colosseum_amd.markov_chain import get_average_reward
 from colosseum_amd.mdp import make_model
 from oracle import oracle as O
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), "tests"))
+from colosseum_amd import timestep as ts_
+from colosseum_amd.agents import BatchedQLearningContinuous, BatchedQLearningEpisodic
+from helpers_agents import QLearningContinuous, QLearningEpisodic   # numpy restatements of the reference agents (pinned to G7 / G10)
 
 rng = np.random.default_rng(0)
 
@@ -101,6 +105,58 @@ def check_one():
         env.close()
 
 
+class _Spec:
+    def __init__(self, m):
+        self.time_horizon = m.H if m.H else np.inf
+        self.observations = type("o", (), {"num_values": m.n_states})()
+        self.actions = type("a", (), {"num_values": m.n_actions})()
+
+
+def check_agent():
+    """Device Q-learning (both settings, random hyper-parameters) against the numpy agent stepping the CPU oracle:
+    action streams and final tables bit-equal."""
+    cls, kw, m = random_model()
+    if m.n_states * max(m.H, 1) > 3000 or not m.deterministic_rewards:
+        return
+    n = int(rng.integers(200, 1500))
+    seeds = [int(rng.integers(0, 1000)) for _ in range(2)]
+    keys = rng.integers(1, 2**40, 2).astype(np.uint64)
+    env = BatchedMDP([m, m], rng_mode=L.RNG_PHILOX, philox_keys=keys, with_dp=False)
+    env.reset()
+    if m.H:
+        ucb = str(rng.choice(["hoeffding", "bernstein"]))
+        hp = dict(p=float(rng.choice([0.05, 0.2])), c_1=float(rng.choice([0.01, 0.5, 0.94])), min_at=float(rng.choice([0.0, 0.07, 0.3])),
+                  UCB_type=ucb, optimization_horizon=n)
+        if ucb == "bernstein":
+            hp["c_2"] = float(rng.choice([0.014, 0.5]))
+        ag = BatchedQLearningEpisodic(env, seeds, **hp)
+        host_cls = QLearningEpisodic
+    else:
+        hp = dict(min_at=float(rng.choice([0.0, 0.05])), confidence=float(rng.choice([0.9, 0.95])),
+                  span_approx_weight=float(rng.choice([0.5, 1.0])), h_weight=float(rng.choice([0.5, 1.0])), optimization_horizon=n)
+        ag = BatchedQLearningContinuous(env, seeds, **hp)
+        host_cls = QLearningContinuous
+    out = ag.run(n, train=True, trace_actions=True)
+    Q, N = ag.tables()
+    for i in range(2):
+        e = O.OracleEnv(m, rng_mode=1, philox_key=int(keys[i]))
+        host = host_cls(mdp_specs=_Spec(m), seed=seeds[i], **hp)
+        ts, h, acts = ts_.restart(e.reset()), 0, []
+        for t in range(n):
+            a = int(host.select_action(ts, h if m.H else t))
+            acts.append(a)
+            ty, o, r, _ = e.step(a)
+            nts = ts_.termination(r, -1) if ty == 2 else ts_.transition(r, o)
+            host.step_update(ts, a, nts, h if m.H else t)
+            h, ts = h + 1, nts
+            if ty == 2:
+                ts, h = ts_.restart(e.reset()), 0
+        assert np.array_equal(out["actions"][:, i], np.array(acts, np.int8)), (cls, kw, hp, i)
+        assert np.array_equal(np.asarray(Q[i], np.float64), np.asarray(host.Q, np.float64)) and np.array_equal(N[i], host.N), (cls, kw, hp)
+    ag.close()
+    env.close()
+
+
 def run(seconds=None, n_cases=None, seed=0):
     """Runs for `seconds` or for exactly `n_cases` random MDPs; raises AssertionError on the first mismatch."""
     global rng
@@ -109,6 +165,8 @@ def run(seconds=None, n_cases=None, seed=0):
     done = 0
     while time.time() < t_end and (n_cases is None or done < n_cases):
         check_one()
+        if done % 4 == 0:
+            check_agent()
         done += 1
     return done
 
