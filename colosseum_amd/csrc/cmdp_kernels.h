@@ -666,6 +666,8 @@ struct DenseArgs {
   int32_t spad;     // multiple of 256
 };
 
+// (A DPP row_shr / row_bcast version of this scan was measured 9 % SLOWER in K1D: every DPP move is a dependent VALU
+// instruction with hazard wait states, while the ds_bpermute latency below is hidden by the other resident waves.)
 __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -727,32 +729,39 @@ __global__ void __launch_bounds__(256) k_rollout_dense(EnvTables t, DenseArgs dn
 #pragma unroll
     for (int q = 0; q < NV; ++q) v[q] = row[q];
     const RowDesc d = t.row[r];  // independent of the row data: in flight together with it
+    // exact float64 prefix sums inside the lane (kept in registers), then across the wave
+    double cl[4 * NV];
     double part = 0.0;
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
-      part += (double)v[q].x; part += (double)v[q].y; part += (double)v[q].z; part += (double)v[q].w;
+      part += (double)v[q].x; cl[4 * q + 0] = part;
+      part += (double)v[q].y; cl[4 * q + 1] = part;
+      part += (double)v[q].z; cl[4 * q + 2] = part;
+      part += (double)v[q].w; cl[4 * q + 3] = part;
     }
     const double incl = wave_incl_scan(part, lane);
     const double total = __shfl(incl, 63, 64);
     const double x = u * total;
-    double c = incl - part;
-    int hit = -1, last_nz = -1;
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int j = lane * (4 * NV) + q * 4 + k;
-        c += (double)e[k];
-        if (e[k] != 0.0f) last_nz = j;
-        if (hit < 0 && e[k] != 0.0f && c > x) hit = j;
-      }
-    }
-    const unsigned long long m = __ballot(hit >= 0);
+    const double excl = incl - part;
+    // next = min{ j : cum_j > x }.  The cumulative sums are non-decreasing and only grow at non-zero columns, so the
+    // first lane whose inclusive total exceeds x holds the column, and inside it the column is the number of its
+    // prefix sums that are still <= x (all sums are exact, so excl + cl[i] is the sequential scan's value).
+    const unsigned long long m = __ballot(incl > x);
     int nxt;
     if (m) {
-      nxt = __shfl(hit, __ffsll((long long)m) - 1, 64);
+      int cnt = 0;
+#pragma unroll
+      for (int i = 0; i < 4 * NV; ++i) cnt += (excl + cl[i] <= x) ? 1 : 0;
+      nxt = __builtin_amdgcn_readlane(lane * (4 * NV) + cnt, __ffsll((long long)m) - 1);
     } else {  // u * total rounded up to total: the last non-zero column of the row
+      int last_nz = -1;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (e[k] != 0.0f) last_nz = lane * (4 * NV) + q * 4 + k;
+      }
       const unsigned long long mz = __ballot(last_nz >= 0);
       nxt = __shfl(last_nz, 63 - __clzll((long long)mz), 64);
     }
