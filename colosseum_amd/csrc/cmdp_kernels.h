@@ -712,13 +712,16 @@ __global__ void __launch_bounds__(256) k_rollout_dense(EnvTables t, DenseArgs dn
         for (int j = 0; j < 4; ++j) acts_lane |= (uint32_t)(((uint64_t)w[j] * (uint64_t)t.A) >> 32) << (8 * j);
       }
     }
-    const int idx = (int)(nt - base);
-    const double u = __shfl(u_lane, idx, 64);
+    // wave-uniform lane indices: v_readlane (scalar result, no LDS round trip) instead of a shuffle
+    const int idx = __builtin_amdgcn_readfirstlane((int)(nt - base));
+    const double u = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(u_lane), idx),
+                                      __builtin_amdgcn_readlane(__double2loint(u_lane), idx));
     int a;
     if (POLICY == 1) {
       a = (int)actions[step * t.B + b];
     } else {
-      const uint32_t word = __shfl(acts_lane, (int)((nt >> 2) - (base >> 2)), 64);
+      const int widx = __builtin_amdgcn_readfirstlane((int)((nt >> 2) - (base >> 2)));
+      const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)acts_lane, widx);
       a = (int)((word >> (8 * (int)(nt & 3))) & 0xffu);
     }
     ++nt;
@@ -740,7 +743,8 @@ __global__ void __launch_bounds__(256) k_rollout_dense(EnvTables t, DenseArgs dn
       part += (double)v[q].w; cl[4 * q + 3] = part;
     }
     const double incl = wave_incl_scan(part, lane);
-    const double total = __shfl(incl, 63, 64);
+    const double total = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(incl), 63),
+                                          __builtin_amdgcn_readlane(__double2loint(incl), 63));
     const double x = u * total;
     const double excl = incl - part;
     // next = min{ j : cum_j > x }.  The cumulative sums are non-decreasing and only grow at non-zero columns, so the
