@@ -689,6 +689,7 @@ __global__ void __launch_bounds__(256) k_rollout_dense(EnvTables t, DenseArgs dn
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= t.B) return;  // whole wavefronts leave together
   const int64_t soff = t.state_off[b], ebase = t.entry_base[b];
+  const int S_b = (int)(t.state_off[b + 1] - soff);
   const uint2 key = t.philox_key[b];
   int32_t cur = t.cur[b], h = t.hstep[b];
   unsigned long long nt = t.n_trans[b], nr = t.n_reset[b];
@@ -730,7 +731,8 @@ __global__ void __launch_bounds__(256) k_rollout_dense(EnvTables t, DenseArgs dn
     const float4* row = reinterpret_cast<const float4*>(dn.P + r * dn.spad + (int64_t)lane * (4 * NV));
     float4 v[NV];
 #pragma unroll
-    for (int q = 0; q < NV; ++q) v[q] = row[q];
+    for (int q = 0; q < NV; ++q)  // the padding behind the last state is all zeros: not fetched
+      v[q] = (lane * (4 * NV) + 4 * q < S_b) ? row[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     const RowDesc d = t.row[r];  // independent of the row data: in flight together with it
     // exact float64 prefix sums inside the lane (kept in registers), then across the wave
     double cl[4 * NV];
