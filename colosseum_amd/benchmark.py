@@ -130,7 +130,8 @@ def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_m
 
 def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, rank: int = 0, world: int = 1,
                   agent_configs: Optional[Dict[str, Dict[str, Any]]] = None, rng_mode: int = L.RNG_MT_COMPAT,
-                  device: int = 0, max_concurrent_groups: int = 6, build_workers: int = 0, progress=None):
+                  device: int = 0, max_concurrent_groups: int = 6, build_workers: int = 0, progress=None,
+                  max_batch: int = 128):
     """Runs this rank's contiguous shard; returns {global instance index: logger rows}."""
     agent_configs = agent_configs or DEFAULT_AGENT_CONFIGS
     lo, hi = shard_range(len(instances), rank, world)
@@ -165,7 +166,14 @@ def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, r
     # only pays because the per-log host work is short (vector_tracker): with per-instance Python trackers the threads
     # convoyed on the GIL (every one of the ~6 short C calls per log waited a 5 ms switch interval) and ran 10-100x
     # slower than one after the other.  Largest batches first, so that the tail is short.
-    order = sorted(groups.values(), key=lambda idx: -len(idx) * models[idx[0]].n_states * max(models[idx[0]].n_states, 64))
+    # very large batches are split: their per-log kernels are latency-bound per instance, so two halves in flight on two
+    # streams finish sooner than one batch (and the longest batch is what bounds the wall time)
+    parts = []
+    for idx in groups.values():
+        n_parts = -(-len(idx) // max(1, max_batch))
+        size = -(-len(idx) // n_parts)
+        parts += [idx[i:i + size] for i in range(0, len(idx), size)]
+    order = sorted(parts, key=lambda idx: -len(idx) * models[idx[0]].n_states * max(models[idx[0]].n_states, 64))
     import sys
 
     old_interval = sys.getswitchinterval()

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--seeds", type=int)
     ap.add_argument("--log-every", type=int)
     ap.add_argument("--concurrent-groups", type=int, default=6, help="device batches driven concurrently (host threads, one stream each)")
+    ap.add_argument("--max-batch", type=int, default=128, help="instances per device batch (larger groups are split)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0")
     args = ap.parse_args()
@@ -53,7 +54,7 @@ def main():
             instances.append(ins)
     t0 = time.time()
     # NOTE: run_instances builds the models with a fork()ed pool first; RCCL / HIP are initialised only afterwards
-    results = bm.run_instances(instances, n_steps, log_every, rank, world, device=local, max_concurrent_groups=args.concurrent_groups,
+    results = bm.run_instances(instances, n_steps, log_every, rank, world, device=local, max_concurrent_groups=args.concurrent_groups, max_batch=args.max_batch,
                                build_workers=max(1, min(16, (os.cpu_count() or 1) // world)),
                                progress=lambda msg: print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True))
     t_run = time.time() - t0
