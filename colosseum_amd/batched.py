@@ -215,6 +215,24 @@ class BatchedMDP:
         self.previous_start = prev
         return out
 
+    def set_observation_table(self, tables):
+        """Per-instance feature tables ([S_b, F], or [H, S_b, F] for episodic handles -- `EmissionMap.all_observations`,
+        see colosseum_amd.emission_maps.observation_table)."""
+        tables = [np.ascontiguousarray(t, np.float32) for t in tables]
+        assert len(tables) == self.B
+        timed = tables[0].ndim == 3
+        F = tables[0].shape[-1]
+        flat = np.ascontiguousarray(np.concatenate([t.reshape(-1) for t in tables]), np.float32)
+        L.check(self._lib.cmdp_set_observation_table(self._h, L.ptr(flat), int(F), int(timed)))
+        self._obs_F = F
+
+    def observe(self, noise_scale: float = 0.0) -> np.ndarray:
+        """Observations [B, F] of the current states (zeros after an episodic horizon); noise_scale > 0 adds Philox
+        Gaussian noise on the device (throughput mode)."""
+        out = np.zeros((self.B, self._obs_F), np.float32)
+        L.check(self._lib.cmdp_observe(self._h, float(noise_scale), L.ptr(out)))
+        return out
+
     def average_reward(self, actions, start_states, mask=None):
         """`get_average_reward(T, R, one_hot(actions), [(start, 1.0)])` for every (continuous) instance on the device
         (kernel K9).  actions: per-instance arrays [S_b] (or one flat array); returns (values, n_recurrent_classes) with

@@ -123,6 +123,10 @@ struct cmdp {
   DevBuf<int32_t> d_dl_inst, d_dl_t0, d_dl_cnt;
   DevBuf<int64_t> d_dl_voff;
   size_t dl_ws_bytes = (size_t)24 << 30;  // value arrays of the target groups in flight per launch
+  // observation tables (k_emit)
+  DevBuf<float> d_obs_table, d_obs_out;
+  DevBuf<unsigned long long> d_n_obs;
+  int obs_F = 0, obs_time_indexed = 0;
   // cmdp_average_reward workspace (K9)
   bool chain_exact = false;  // CMDP_OPT_CHAIN_EXACT_ORDER
   DevBuf<double> d_ch_work, d_ch_avg;
@@ -1459,6 +1463,41 @@ int cmdp_qlearning_average_reward(cmdp_agent_t* a, const uint8_t* mask, double* 
                      h->d_state_off.p, a->d_Qc.p, a->d_pi.p);
   HIP_TRY(hipGetLastError());
   return chain_launch(h, a->d_pi.p, nullptr, h->d_cur.p, mask, avg, kind, nullptr);
+}
+
+int cmdp_set_observation_table(cmdp_t* h, const float* table, int32_t F, int time_indexed) {
+  if (int rc = bind(h)) return rc;
+  if (!h->has_env) return fail(CMDP_ERR_INVALID, "handle was created without the sampler half");
+  if (!table || F < 1) return fail(CMDP_ERR_INVALID, "null table or F < 1");
+  if (time_indexed && h->H < 1) return fail(CMDP_ERR_INVALID, "a time-indexed table needs an episodic handle");
+  hipStream_t st = h->stream;
+  const size_t n = (size_t)(time_indexed ? h->H : 1) * (size_t)h->n_states * (size_t)F;
+  HIP_TRY(h->d_obs_table.upload(table, n, st));
+  HIP_TRY(h->d_obs_out.alloc((size_t)h->B * F));
+  HIP_TRY(h->d_n_obs.alloc((size_t)h->B));
+  HIP_TRY(h->d_n_obs.zero(st));
+  HIP_TRY(hipStreamSynchronize(st));
+  h->obs_F = F;
+  h->obs_time_indexed = time_indexed ? 1 : 0;
+  return CMDP_OK;
+}
+
+int cmdp_observe(cmdp_t* h, double noise_scale, float* obs) {
+  if (int rc = bind(h)) return rc;
+  if (!obs) return fail(CMDP_ERR_INVALID, "null output");
+  if (h->obs_F < 1) return fail(CMDP_ERR_INVALID, "no observation table: call cmdp_set_observation_table first");
+  if (noise_scale > 0.0 && h->rng_mode != CMDP_RNG_PHILOX)
+    return fail(CMDP_ERR_UNSUPPORTED, "device noise needs CMDP_RNG_PHILOX (the reference-exact noise stream is host side)");
+  hipStream_t st = h->stream;
+  EmitArgs e{};
+  e.B = h->B; e.F = h->obs_F; e.H = h->H; e.time_indexed = h->obs_time_indexed;
+  e.state_off = h->d_state_off.p; e.table = h->d_obs_table.p; e.cur = h->d_cur.p; e.hstep = h->d_h.p;
+  e.key = h->d_key.p; e.n_obs = h->d_n_obs.p; e.scale = noise_scale; e.out = h->d_obs_out.p;
+  hipLaunchKernelGGL(k_emit, dim3(h->B), dim3(256), 0, st, e);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(obs, h->d_obs_out.p, sizeof(float) * (size_t)h->B * h->obs_F, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return CMDP_OK;
 }
 
 int cmdp_mixing_time(cmdp_t* h, const float* pi, const double* stationary, double threshold, int64_t max_steps,

@@ -553,3 +553,48 @@ __global__ void __launch_bounds__(256) k_mix_step(MixArgs m) {
     atomicMax(m.dlist + (int64_t)b * m.chunk + m.k, (unsigned long long)__double_as_longlong(tv));
   }
 }
+
+
+// ===================================================================================================
+// k_emit: non-tabular observations of all instances (reference colosseum/emission_maps/base.py:56-141): row
+// [h][state] of the instance's float32 feature table (zeros once an episodic instance has reached its horizon),
+// plus scale * N(0, 1) noise in throughput mode: Philox domain 4, counter (observation number of the instance,
+// element pair), Box-Muller in float64 on 32-bit uniforms, two normals per block half.  One workgroup per instance.
+// ===================================================================================================
+struct EmitArgs {
+  int32_t B, F, H, time_indexed;
+  const int64_t* state_off;
+  const float* table;          // per instance [H or 1][S_b][F] at (time_indexed ? H : 1) * state_off[b] * F
+  const int32_t* cur;
+  const int32_t* hstep;
+  const uint2* key;
+  unsigned long long* n_obs;   // [B] observations emitted so far (noise counter)
+  double scale;                // <= 0: no noise
+  float* out;                  // [B][F]
+};
+
+__global__ void __launch_bounds__(256) k_emit(EmitArgs e) {
+  const int b = blockIdx.x;
+  const int64_t so = e.state_off[b];
+  const int S = (int)(e.state_off[b + 1] - so);
+  const int h = e.hstep[b];
+  const bool ended = e.H > 0 && h >= e.H;
+  const int layer = e.time_indexed ? (h < e.H ? h : 0) : 0;
+  const float* row = e.table + ((int64_t)(e.time_indexed ? e.H : 1) * so + (int64_t)layer * S + e.cur[b]) * e.F;
+  const unsigned long long n = e.n_obs[b];
+  const uint2 key = e.key ? e.key[b] : make_uint2(0, 0);
+  for (int j = threadIdx.x; j < e.F; j += blockDim.x) {
+    float v = ended ? 0.0f : row[j];
+    if (e.scale > 0.0 && !ended) {
+      uint32_t w[4];
+      philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 4u, (uint32_t)(j >> 1), key.x, key.y, w);
+      const uint32_t a = (j & 1) ? w[2] : w[0], c = (j & 1) ? w[3] : w[1];
+      const double u1 = ((double)a + 1.0) * (1.0 / 4294967296.0), u2 = (double)c * (1.0 / 4294967296.0);
+      const double z = sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+      v = v + (float)(e.scale * z);
+    }
+    e.out[(int64_t)b * e.F + j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && e.scale > 0.0 && !ended) e.n_obs[b] = n + 1;
+}

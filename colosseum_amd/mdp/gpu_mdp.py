@@ -17,6 +17,7 @@ from .. import timestep as ts_
 from ..batched import BatchedMDP
 from ..dynamic_programming import get_policy_from_q_values
 from .registry import make_model, split_class_name
+from ..emission_maps import CompatNoise, observation_table
 from .reward_sampler import CompatRewardSampler
 
 
@@ -25,6 +26,15 @@ class GpuMDP:
 
     def __init__(self, cls_name: str = None, **kwargs):
         cls_name = cls_name or self._cls_name
+        # emission map / noise: class objects or names ("StateInfo", "OneHotEncoding"; noise "GaussianUncorrelated"),
+        # as BaseMDP.__init__ takes them (mdp/base.py:336-339,450-461); the noise seed is the MDP's seed
+        em = kwargs.pop("emission_map", None)
+        em_kwargs = kwargs.pop("emission_map_kwargs", {}) or {}
+        noise = kwargs.pop("noise", None)
+        noise_kwargs = dict(kwargs.pop("noise_kwargs", {}) or {})
+        em_name = em if isinstance(em, str) or em is None else em.__name__
+        noise_name = noise if isinstance(noise, str) or noise is None else noise.__name__
+        assert not em_kwargs, "the built emission maps take no keyword arguments"
         self._model = make_model(cls_name, **kwargs)
         self._family_name, self._episodic = split_class_name(cls_name)
         m = self._model
@@ -38,6 +48,16 @@ class GpuMDP:
         self.r_min, self.r_max = self.rewards_range
         self.emission_map = None
         self.is_tabular = True
+        self._obs_table = observation_table(m, em_name)
+        self._noise = None
+        if self._obs_table is not None:
+            self.emission_map = em_name
+            self.is_tabular = False
+            if noise_name is not None:
+                if noise_name != "GaussianUncorrelated":
+                    raise NotImplementedError(f"noise {noise_name!r} is not built (GaussianUncorrelated is)")
+                noise_kwargs.pop("seed", None)
+                self._noise = CompatNoise(kwargs.get("seed"), self._obs_table.shape[-1:], **noise_kwargs)
         self._seed = kwargs.get("seed")
         self.parameters = dict(kwargs)
         nodes = [tuple(int(x) for x in n) for n in m.nodes]
@@ -72,7 +92,21 @@ class GpuMDP:
         return ts_.DiscreteArray(self.n_actions, name="action")
 
     def observation_spec(self):
-        return ts_.DiscreteArray(self.n_states, name="observation")
+        if self._obs_table is None:
+            return ts_.DiscreteArray(self.n_states, name="observation")
+        # the reference builds the spec from an actual observation of the first starting node (mdp/base.py:1249-1252),
+        # which draws one noise sample every time it is called
+        obs = self._observation(self.starting_states[0], 0)
+        return ts_.BoundedArray(shape=obs.shape, dtype=obs.dtype, minimum=-np.inf, maximum=np.inf, name="observation")
+
+    def _observation(self, state: int, h: int):
+        """EmissionMap.get_observation (emission_maps/base.py:110-141)."""
+        if self._episodic and h >= self._model.H:
+            return np.zeros(self._obs_table.shape[-1:], np.float32)
+        # continuous setting: the reference indexes `all_observations[None, state]` (in_episode_time = None is numpy's
+        # newaxis, emission_maps/base.py:135-137), so its observations carry a leading axis of length 1
+        obs = self._obs_table[h, state] if self._episodic else self._obs_table[None, state]
+        return obs + next(self._noise) if self._noise is not None else obs
 
     def reward_spec(self):
         return ts_.Array(shape=(), dtype=float, name="reward")
@@ -86,7 +120,7 @@ class GpuMDP:
         self.necessary_reset = False
         self.h = 0
         self.cur_node = self.last_starting_node = self.index_to_node[obs]
-        return ts_.restart(obs)
+        return ts_.restart(obs if self._obs_table is None else self._observation(obs, 0))
 
     def step(self, action, auto_reset=False):
         if auto_reset and self.necessary_reset:
@@ -102,10 +136,21 @@ class GpuMDP:
         reward = float(rew[0])
         if self._reward_sampler is not None:
             reward = self._reward_sampler.sample(self.node_to_index[old], action, int(cur[0]))
+        if self._obs_table is None:
+            if st[0] == 2:
+                self.necessary_reset = True
+                return ts_.termination(reward=reward, observation=-1)
+            return ts_.transition(reward=reward, observation=int(obs[0]))
+        observation = self._observation(int(cur[0]), self.h)  # mdp/base.py:1308-1320
         if st[0] == 2:
             self.necessary_reset = True
-            return ts_.termination(reward=reward, observation=-1)
-        return ts_.transition(reward=reward, observation=int(obs[0]))
+            return ts_.termination(reward=reward, observation=np.zeros_like(self._spec_value()))
+        return ts_.transition(reward=reward, observation=observation)
+
+    def _spec_value(self):
+        # `np.zeros_like(self.observation_spec().generate_value())`: building the spec draws a noise sample
+        self.observation_spec()
+        return np.zeros(self._obs_table.shape[-1:], np.float32)
 
     def random_step(self, auto_reset=False):
         """mdp/base.py:1341-1355: the action comes from the MDP's own numpy stream (shared with the reward caches),

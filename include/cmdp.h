@@ -292,6 +292,17 @@ int cmdp_greedy_policy_episodic(cmdp_t* h, int H, int q_layers, const float* Q, 
    for the continuous agent, whose tables are float64], N likewise (int32); either may be NULL. */
 int cmdp_qlearning_tables(cmdp_agent_t* a, float* Q, int32_t* N);
 
+/* ---- non-tabular observations --------------------------------------------------------------------------------- */
+/* EmissionMap.all_observations (colosseum/emission_maps/base.py:56-83) of every instance: float32 feature vectors of
+   length F, per instance [S_b][F] at state_off[b]*F, or -- time_indexed, episodic handles -- [H][S_b][F] at
+   H*state_off[b]*F.  The table is copied to the device. */
+int cmdp_set_observation_table(cmdp_t* h, const float* table, int32_t F, int time_indexed);
+/* EmissionMap.get_observation (emission_maps/base.py:110-141) for the current state of every instance: obs [B][F];
+   all zeros for an episodic instance that has reached its horizon.  noise_scale > 0 adds scale * N(0,1) per element
+   from the instance's Philox stream (throughput mode, CMDP_RNG_PHILOX only; the reference-exact GaussianUncorrelated
+   stream is numpy's and stays on the host, colosseum_amd/emission_maps.py). */
+int cmdp_observe(cmdp_t* h, double noise_scale, float* obs);
+
 /* ---- Markov chains ------------------------------------------------------------------------------------ */
 /* BUILD-DEFINED (the reference has no mixing time): t_mix[b] = smallest t >= 1 with
    max_s TV(P^t(s, .), stationary) <= threshold for the chain P[s, j] = sum_a pi[s, a] T[s, a, j] of instance b

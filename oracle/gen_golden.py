@@ -21,6 +21,7 @@ Fixture groups:
   G5  hardness known-answer table lifted from benchmark/cached_hardness_measures/*.txt
   G6  episodic/continuous diameter + value-norm recomputed by the reference here (small cases)
   G7  MDPLoop + QLearningEpisodic logger rows and action stream (config C1, plumbing)
+  G14 emission maps (StateInfo, OneHotEncoding) and GaussianUncorrelated noise
   G13 CustomMDP (user-given T_0, T, R)
   G12 RiverSwim / SimpleGrid / Taxi: structure, DP values, trajectories
   G10 MDPLoop + QLearningContinuous logger rows (continuous-setting regret via stationary distributions)
@@ -769,7 +770,49 @@ def g13():
     save("G13_custom", **arrays)
 
 
-GROUPS = dict(G13=g13, G12=g12, G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11)
+
+def g14():
+    """Emission maps + GaussianUncorrelated noise: all_observations tables and the observation
+    stream of reset()/step() with noise, incl. the samples observation_spec() consumes at episode ends."""
+    from colosseum.emission_maps import OneHotEncoding, StateInfo
+    from colosseum.noises import GaussianUncorrelated
+
+    specs = [
+        ("DeepSeaEpisodic", dict(seed=2, size=5), StateInfo, 0.3),
+        ("FrozenLakeContinuous", dict(seed=1, size=4, p_frozen=0.9, p_rand=0.1), StateInfo, 0.1),
+        ("MiniGridEmptyEpisodic", dict(seed=3, size=4, n_starting_states=2), OneHotEncoding, 0.2),
+        ("RiverSwimContinuous", dict(seed=4, size=7, p_rand=0.2), OneHotEncoding, None),
+    ]
+    cases, arrays = [], {}
+    for cls, kw, em, scale in specs:
+        extra = dict(emission_map=em)
+        if scale is not None:
+            extra.update(noise=GaussianUncorrelated, noise_kwargs=dict(scale=scale))
+        mdp = CLASSES[cls](**kw, **extra)
+        key = f"c{len(cases)}_"
+        arrays[key + "all_observations"] = np.asarray(mdp.emission_map.all_observations, np.float32)
+        acts = np.random.RandomState(40 + len(cases)).randint(0, mdp.n_actions, 400)
+        obs, stype, first = [], [], []
+        ts = mdp.reset()
+        first.append(np.asarray(ts.observation, np.float32))
+        for a in acts:
+            ts = mdp.step(int(a))
+            obs.append(np.asarray(ts.observation, np.float32))
+            stype.append(int(ts.step_type))
+            if mdp.is_episodic() and ts.last():
+                ts = mdp.reset()
+                first.append(np.asarray(ts.observation, np.float32))
+        arrays[key + "actions"] = acts.astype(np.int8)
+        arrays[key + "obs"] = np.stack(obs)
+        arrays[key + "stype"] = np.array(stype, np.uint8)
+        arrays[key + "reset_obs"] = np.stack(first)
+        cases.append(dict(cls=cls, kwargs=kw, emission_map=em.__name__, noise_scale=scale))
+        print("   ", cls, em.__name__, scale, arrays[key + "all_observations"].shape)
+    arrays["cases"] = np.array(json.dumps(cases))
+    save("G14_emission_maps", **arrays)
+
+
+GROUPS = dict(G14=g14, G13=g13, G12=g12, G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)
