@@ -140,6 +140,8 @@ def main():
         env.set_option(L.OPT_LDS_GROUPS_PER_CU, args.lds_groups)
     t_build = time.time() - t_build
     S = int(env.n_states[0])
+    plan = env.lds_plan() if not dense else dict(kernel="", eligible=False)
+    lds_kernel = plan["kernel"]
 
     ev = HipEvents()
     stream = env.stream
@@ -227,8 +229,8 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_rollout_dense<0,NV>" if dense else ("k_rollout_lds" if args.rollout_kernel != 1 else "k_rollout<0,false>"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": "k_rollout_dense<0,NV>" if dense else (lds_kernel if args.rollout_kernel != 1 else "k_rollout<0,false>"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "lds_plan": plan,
             "algorithmic_bytes_per_transition": bytes_per_step, "accounting": "SURVEY 8(d) dense-row figure (4*S+28 B/transition)" if dense else "SURVEY 8(d) CSR figure (44 B/transition)",
             "launch_ms_avg": avg_launch_s * 1e3, "launch_ms_min": float(np.min(launch_ms)),
         },

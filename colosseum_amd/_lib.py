@@ -25,7 +25,7 @@ ROLLOUT_AUTO, ROLLOUT_GLOBAL, ROLLOUT_LDS = 0, 1, 2
 
 EXPORTS = [
     "cmdp_version", "cmdp_last_error", "cmdp_device_count", "cmdp_set_device", "cmdp_create", "cmdp_destroy",
-    "cmdp_stream", "cmdp_reset", "cmdp_step", "cmdp_rollout", "cmdp_rollout_async", "cmdp_synchronize", "cmdp_set_option",
+    "cmdp_stream", "cmdp_reset", "cmdp_step", "cmdp_rollout", "cmdp_rollout_async", "cmdp_synchronize", "cmdp_set_option", "cmdp_lds_plan",
     "cmdp_visits", "cmdp_reset_visits", "cmdp_state", "cmdp_last_start", "cmdp_vi_discounted", "cmdp_pe_discounted",
     "cmdp_vi_episodic", "cmdp_pe_episodic", "cmdp_diameter", "cmdp_diameter_episodic", "cmdp_value_norm", "cmdp_gth", "cmdp_qlearning_create", "cmdp_qlearning_destroy", "cmdp_qlearning_run",
     "cmdp_qlearning_tables", "cmdp_qlearning_evaluate", "cmdp_greedy_policy_episodic", "cmdp_qlearning_continuous_create",
@@ -83,6 +83,7 @@ def load():
         L.cmdp_rollout_async.argtypes = [vp, i32, i64]
         L.cmdp_synchronize.argtypes = [vp]
         L.cmdp_set_option.argtypes = [vp, i32, i64]
+        L.cmdp_lds_plan.argtypes = [vp, vp]
         L.cmdp_visits.argtypes = [vp, vp, vp]
         L.cmdp_reset_visits.argtypes = [vp]
         L.cmdp_state.argtypes = [vp, vp, vp, vp]

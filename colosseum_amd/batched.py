@@ -176,6 +176,14 @@ class BatchedMDP:
         """L.ROLLOUT_AUTO | L.ROLLOUT_GLOBAL | L.ROLLOUT_LDS (tuning only; results are identical)."""
         L.check(self._lib.cmdp_set_option(self._h, L.OPT_ROLLOUT_KERNEL, int(which)))
 
+    def lds_plan(self) -> dict:
+        """The LDS-resident rollout chosen for this batch (cmdp_lds_plan): eligible, pipeline (K1P) or fused walker
+        (K1L), instances per workgroup, transitions per chunk."""
+        plan = np.zeros(4, np.int32)
+        L.check(self._lib.cmdp_lds_plan(self._h, L.ptr(plan)))
+        return dict(eligible=bool(plan[0]), kernel="k_rollout_pipe" if plan[1] else "k_rollout_lds",
+                    instances_per_workgroup=int(plan[2]), chunk=int(plan[3]))
+
     def set_option(self, option: int, value: int):
         L.check(self._lib.cmdp_set_option(self._h, int(option), int(value)))
 

@@ -164,6 +164,12 @@ int bind(cmdp_t* h) {
 
 inline int grid_for(int64_t n, int block) { return (int)((n + block - 1) / block); }
 
+// dynamic LDS of a K1L / K1P workgroup of g instances
+size_t k1l_lds_bytes(const LdsPlan& p, int g) {
+  const int rings = p.pipe ? 2 * K1P_ACT_STRIDE(p.ch) + 2 * K1P_TR_STRIDE(p.ch) : 2 * p.ch;
+  return (size_t)K1L_FIXED + (size_t)g * (size_t)(p.slot_bytes + rings);
+}
+
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
   if (bytes > 64 * 1024)
@@ -394,9 +400,7 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
         while ((1 << bits_s) < rows_max) ++bits_s;
         while ((1 << bits_c) < (int)vals.size()) ++bits_c;
         p.code_shift = (bits_s + bits_c <= 16) ? bits_s : 0;
-        if (p.code_shift)
-          for (int64_t r = 0; r < R; ++r)
-            next16[(size_t)r] = (uint16_t)((next16[(size_t)r] * A) | (codes[(size_t)r] << p.code_shift));
+        const bool pipe_ok = bits_s + 1 + bits_c <= 16;  // K1P stores the row base as a byte offset: one more bit
         p.off_rcode = (rows_max * 2 + 3) & ~3;
         if (p.code_shift) {  // packed: successor words, 8-bit count deltas (+ the walker's dummy counter), overflow list
           p.off_cnt = p.off_rcode;
@@ -415,30 +419,45 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
         if (cus < 1) cus = 256;
-        int64_t best_rounds = -1;
+        double best_cost = -1.0;
         p.ch = 256;
         p.G = 0;
-        const int force_ch = std::getenv("CMDP_K1L_CH") ? std::atoi(std::getenv("CMDP_K1L_CH")) : 0;  // tuning aid
-        for (int ch : {256, 128, 112, 64}) {
-          if (force_ch && ch != force_ch) continue;
-          const int pi = p.slot_bytes + 2 * ch;
+        const int force_ch = std::getenv("CMDP_K1L_CH") ? std::atoi(std::getenv("CMDP_K1L_CH")) : 0;      // tuning aids
+        const int force_pipe = std::getenv("CMDP_K1L_PIPE") ? std::atoi(std::getenv("CMDP_K1L_PIPE")) : -1;
+        struct Cand { int pipe, ch; };
+        // Packed tables can also run as the wavefront pipeline K1P: ~0.62x the time per transition plus one barrier
+        // per chunk (measured at C2: 53 / 56 / 62 ns per transition at ch = 64 / 32 / 16 against K1L's 82), for
+        // 6 ch + 16 bytes of rings per instance instead of 2 ch.  K1P wants the CU to itself: two of its 8-wavefront
+        // workgroups per CU ran 1.8x slower than one.
+        const Cand cands[] = {{0, 256}, {0, 128}, {0, 112}, {0, 64}, {1, 64}, {1, 32}, {1, 16}};
+        for (const Cand& c : cands) {
+          if (force_ch && c.ch != force_ch) continue;
+          if (c.pipe && !pipe_ok) continue;
+          if (force_pipe >= 0 && c.pipe != force_pipe) continue;
+          const int pi = p.slot_bytes + (c.pipe ? 2 * K1P_ACT_STRIDE(c.ch) + 2 * K1P_TR_STRIDE(c.ch) : 2 * c.ch);
           const int g1 = std::min<int>(64, (kLdsBudget - fixed) / pi);
-          const int g2 = std::min<int>(64, (kLdsBudget / 2 - fixed) / pi);
+          const int g2 = c.pipe ? 0 : std::min<int>(64, (kLdsBudget / 2 - fixed) / pi);
           for (int per_cu : {2, 1}) {
             const int g = per_cu == 2 ? g2 : g1;
             if (g < (per_cu == 2 ? 12 : 8)) continue;
             const int64_t wgs = (B + g - 1) / g, slots_n = (int64_t)cus * per_cu;
             const int64_t rounds = (wgs + slots_n - 1) / slots_n;
-            if (best_rounds < 0 || rounds < best_rounds) {
-              best_rounds = rounds;
-              p.ch = ch;
+            const double per_step = c.pipe ? 0.62 * (1.0 + 3.5 / c.ch) : 1.0 + 2.0 / c.ch;
+            const double cost = (double)rounds * per_step;
+            if (best_cost < 0 || cost < best_cost) {
+              best_cost = cost;
+              p.ch = c.ch;
+              p.pipe = c.pipe;
               p.G = g;
               h->lds_G1 = g1;
               h->lds_G2 = g2;
             }
           }
         }
-        const int per_inst = p.slot_bytes + 2 * p.ch;  // tables + count deltas + two action-ring chunks
+        if (p.pipe) p.code_shift = bits_s + 1;
+        if (p.code_shift)
+          for (int64_t r = 0; r < R; ++r)
+            next16[(size_t)r] = (uint16_t)((next16[(size_t)r] * A * (p.pipe ? 2 : 1)) | (codes[(size_t)r] << p.code_shift));
         p.n_codes = (int)vals.size();
         if (p.G >= 8) {
           // 16 bytes of slack in front of and behind both element arrays: the staging loads are 16-byte wide
@@ -452,7 +471,7 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
           HIP_TRY(h->d_rvals.upload(vals.data(), vals.size(), st));
           p.next16 = h->d_next16.p + 8; p.rcode = h->d_rcode.p + 16; p.rvals = h->d_rvals.p;
           h->lds_plan = p;
-          h->lds_bytes = (size_t)fixed + (size_t)p.G * per_inst;
+          h->lds_bytes = k1l_lds_bytes(p, p.G);
           h->lds_ok = true;
           HIP_TRY(hipStreamSynchronize(st));  // staging vectors die with this scope
         }
@@ -630,7 +649,10 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
   // the LDS kernel pays a fixed staging + flush cost per launch: worth it from a few dozen transitions on
   if (lds_eligible && (h->rollout_kernel == 2 || (h->rollout_kernel == 0 && n_steps >= 64))) {
     const dim3 lgrid(grid_for(h->B, h->lds_plan.G)), lblock(K1L_THREADS);
-    if (h->lds_plan.code_shift) {
+    if (h->lds_plan.pipe) {
+      if (int rc = set_lds(k_rollout_pipe, h->lds_bytes)) return rc;
+      hipLaunchKernelGGL(k_rollout_pipe, lgrid, dim3(K1P_THREADS), h->lds_bytes, st, t, h->lds_plan, n_steps, d_rsum, d_last);
+    } else if (h->lds_plan.code_shift) {
       if (int rc = set_lds(k_rollout_lds<true>, h->lds_bytes)) return rc;
       hipLaunchKernelGGL(k_rollout_lds<true>, lgrid, lblock, h->lds_bytes, st, t, h->lds_plan, n_steps, d_rsum, d_last);
     } else {
@@ -719,7 +741,7 @@ int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
     const int g = value == 1 ? h->lds_G1 : h->lds_G2;
     if (g < 1) return fail(CMDP_ERR_INVALID, "no room for %lld workgroups per CU", (long long)value);
     h->lds_plan.G = g;
-    h->lds_bytes = (size_t)K1L_FIXED + (size_t)g * (h->lds_plan.slot_bytes + 2 * h->lds_plan.ch);
+    h->lds_bytes = k1l_lds_bytes(h->lds_plan, g);
     return CMDP_OK;
   }
   if (option == CMDP_OPT_DP_KERNEL && value >= 0 && value <= 4) {
@@ -735,6 +757,15 @@ int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
     return CMDP_OK;
   }
   return fail(CMDP_ERR_INVALID, "unknown option %d / value %lld", option, (long long)value);
+}
+
+int cmdp_lds_plan(cmdp_t* h, int32_t plan[4]) {
+  if (!h || !plan) return fail(CMDP_ERR_INVALID, "bad argument");
+  plan[0] = h->lds_ok ? 1 : 0;
+  plan[1] = h->lds_ok ? h->lds_plan.pipe : 0;
+  plan[2] = h->lds_ok ? h->lds_plan.G : 0;
+  plan[3] = h->lds_ok ? h->lds_plan.ch : 0;
+  return CMDP_OK;
 }
 
 int cmdp_synchronize(cmdp_t* h) {

@@ -274,6 +274,7 @@ struct LdsPlan {
   int32_t off_ovf;         // packed mode: uint16 list of the rows whose 8-bit counter wrapped since the last flush
   int32_t ch;              // transitions per action-ring chunk (multiple of 8)
   int32_t n_codes;         // distinct reward values (<= 256)
+  int32_t pipe;            // 1: run as the three-stage wavefront pipeline K1P (packed mode only)
   int32_t code_shift;      // > 0: next16 holds (successor * A) in its low code_shift bits and the reward code above
                            //      them (no rcode table, no multiply on the walker's dependency chain)
   const uint16_t* next16;  // [R] successor of every (deterministic) row
@@ -294,7 +295,45 @@ __device__ __forceinline__ void flush_counts(int32_t* __restrict__ dst, int tota
 #define K1L_THREADS 256
 #define K1L_OVF 30                      // wrap events an instance can record between two flushes (8-bit counters)
 #define K1L_NRV 264                      // reward table entries in LDS: 256 codes + a zero entry (index 256) + pad
+#define K1P_ACT_STRIDE(ch) ((ch) + 4)       // K1P ring strides in bytes per instance
+#define K1P_TR_STRIDE(ch) (2 * (ch) + 4)
 #define K1L_FIXED (K1L_NRV * 8 + 64 * 4 + 64 * 8 + 64 * 8)   // rv2[K1L_NRV] f64, resets[64] i32, keys[64] uint2, ntr[64] u64
+
+// Stages the successor words of a group's `total_rows` rows into the instance slots: 16-byte loads from the
+// aligned-down address, K1L_UNROLL of them in flight per thread (the element arrays carry 16 bytes of slack at
+// both ends, see cmdp_create).
+__device__ __forceinline__ void k1l_stage_words(const LdsPlan& p, int64_t row00, int total_rows, int rows,
+                                                unsigned char* slots, int tid) {
+  {
+    const uint16_t* src = p.next16 + row00;
+    const int head = (int)((reinterpret_cast<uintptr_t>(src) & 15) >> 1);
+    const uint4* vsrc = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(src) - 2 * head);
+    const int nchunks = (head + total_rows + 7) >> 3;
+    for (int c0 = 0; c0 < nchunks; c0 += K1L_THREADS * K1L_UNROLL) {
+      uint4 v[K1L_UNROLL];
+#pragma unroll
+      for (int k = 0; k < K1L_UNROLL; ++k) {
+        const int c = c0 + k * K1L_THREADS + tid;
+        if (c < nchunks) v[k] = vsrc[c];
+      }
+#pragma unroll
+      for (int k = 0; k < K1L_UNROLL; ++k) {
+        const int c = c0 + k * K1L_THREADS + tid;
+        if (c < nchunks) {
+          const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+          int j = c * 8 - head;
+          int slot = (j > 0) ? j / rows : 0, off = j - slot * rows;
+#pragma unroll
+          for (int e = 0; e < 8; ++e, ++j, ++off) {
+            if (off == rows) { off = 0; ++slot; }
+            if (j >= 0 && j < total_rows)
+              reinterpret_cast<uint16_t*>(slots + (size_t)slot * p.slot_bytes)[off] = (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
+          }
+        }
+      }
+    }
+  }
+}
 
 // Wavefront specialisation: lanes of wavefront 0 walk one instance each; wavefronts 1-3 are the random-policy
 // PRODUCERS -- they compute the Philox blocks of the NEXT chunk of p.ch transitions for all G instances into a
@@ -330,35 +369,7 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
   if (tid < nb) { keys[tid] = t.philox_key[g0 + tid]; ntr[tid] = t.n_trans[g0 + tid]; }
   // ---- stage the tables: 16-byte loads from the aligned-down address, K1L_UNROLL of them in flight per
   //      thread (the element arrays carry 16 bytes of slack at both ends, see cmdp_create) -----------------
-  {
-    const uint16_t* src = p.next16 + row00;
-    const int head = (int)((reinterpret_cast<uintptr_t>(src) & 15) >> 1);
-    const uint4* vsrc = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(src) - 2 * head);
-    const int nchunks = (head + total_rows + 7) >> 3;
-    for (int c0 = 0; c0 < nchunks; c0 += K1L_THREADS * K1L_UNROLL) {
-      uint4 v[K1L_UNROLL];
-#pragma unroll
-      for (int k = 0; k < K1L_UNROLL; ++k) {
-        const int c = c0 + k * K1L_THREADS + tid;
-        if (c < nchunks) v[k] = vsrc[c];
-      }
-#pragma unroll
-      for (int k = 0; k < K1L_UNROLL; ++k) {
-        const int c = c0 + k * K1L_THREADS + tid;
-        if (c < nchunks) {
-          const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-          int j = c * 8 - head;
-          int slot = (j > 0) ? j / rows : 0, off = j - slot * rows;
-#pragma unroll
-          for (int e = 0; e < 8; ++e, ++j, ++off) {
-            if (off == rows) { off = 0; ++slot; }
-            if (j >= 0 && j < total_rows)
-              reinterpret_cast<uint16_t*>(slots + (size_t)slot * p.slot_bytes)[off] = (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
-          }
-        }
-      }
-    }
-  }
+  k1l_stage_words(p, row00, total_rows, rows, slots, tid);
   if (!PACKED) {
     const uint8_t* src = p.rcode + row00;
     const int head = (int)(reinterpret_cast<uintptr_t>(src) & 15);
@@ -598,6 +609,315 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K1P: the packed LDS rollout as a WAVEFRONT PIPELINE.
+//
+// K1L's walker is bound by the instructions one wavefront issues per transition (~17; a lone wavefront issues one
+// every 4-8 cycles), not by the dependent LDS read.  Here a transition's work is split over the wavefronts of the
+// workgroup, one chunk of p.ch transitions apart:
+//   wave 0    CHAIN     action byte -> successor word (the dependent LDS read) -> trace entry `word + 2 action`
+//                       (= byte offset of the arrival row under the action taken | reward code << code_shift),
+//                       episode bookkeeping
+//   wave 1    COUNTS    8-bit visit counters of the traced rows (+ overflow list), one chunk behind the chain
+//   wave 2    REWARDS   adds the traced reward codes' values in transition order (bit-equal to the sequential sum)
+//   waves 3-5 PRODUCERS Philox action bytes of the chunk after the chain's (lane i: instance i; the blocks of a window
+//                       are dealt round-robin to the three waves)
+// Lane i of every wave owns instance i of the group.  Rings (actions, trace) are double-buffered; one barrier per chunk.
+// The successor field of the table word is the successor's row base as a BYTE offset (2 A s'), so the chain's
+// address is one add3.  LDS per instance: slot_bytes + 2 (p.ch + 4) + 2 (2 p.ch + 4); the odd strides keep the
+// per-lane rings off each other's banks.
+// ---------------------------------------------------------------------------------------------------
+#define K1P_THREADS 512
+#define K1P_NPROD 4
+__global__ void __launch_bounds__(K1P_THREADS) k_rollout_pipe(EnvTables t, LdsPlan p, int64_t n_steps,
+                                                             double* __restrict__ reward_sum,
+                                                             int32_t* __restrict__ last_obs) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // scalar: the role branches are uniform
+  const int g0 = blockIdx.x * p.G;
+  const int nb = min(p.G, t.B - g0);
+  double* rv2 = reinterpret_cast<double*>(smem);
+  int32_t* resets = reinterpret_cast<int32_t*>(smem + K1L_NRV * 8);
+  const int CH = p.ch;
+  const int AS = K1P_ACT_STRIDE(CH), TS = K1P_TR_STRIDE(CH);
+  unsigned char* ring = smem + K1L_FIXED;                 // [2][G] action bytes, stride AS
+  unsigned char* trace = ring + 2 * p.G * AS;             // [2][G] uint16 trace entries, stride TS bytes
+  unsigned char* slots = trace + 2 * p.G * TS;
+  const int A = t.A, H = t.H;
+  const int64_t so0 = t.state_off[g0];
+  const int S = (int)(t.state_off[g0 + 1] - so0);
+  const int rows = S * A;
+  const int64_t row00 = so0 * A;
+  const int total_rows = nb * rows, total_states = nb * S;
+  const int cnt_dwords = (p.rows_max + 4) / 4;
+  if (tid < K1L_THREADS) {  // the staging / flush helpers are written for K1L_THREADS threads
+    for (int i = tid; i < p.n_codes; i += K1L_THREADS) rv2[i] = p.rvals[i] * t.rscale - t.rmin;
+    k1l_stage_words(p, row00, total_rows, rows, slots, tid);
+    for (int j = tid; j < nb * cnt_dwords; j += K1L_THREADS) {
+      const int slot = j / cnt_dwords, off = j - slot * cnt_dwords;
+      reinterpret_cast<uint32_t*>(slots + (size_t)slot * p.slot_bytes + p.off_cnt)[off] = 0u;
+    }
+  }
+  const bool owner = lane < nb;  // this lane's instance exists
+  const int b = g0 + (owner ? lane : 0);
+  unsigned char* base = slots + (size_t)(owner ? lane : 0) * p.slot_bytes;
+  uint8_t* c8 = base + p.off_cnt;
+  uint16_t* ovf = reinterpret_cast<uint16_t*>(base + p.off_ovf);
+  const int smask = (1 << p.code_shift) - 1;
+  // chain state (wave 0): `cur` is the byte offset of the current state's row base (2 A s)
+  const int32_t start_k = t.start_state[t.start_off[b]] * A * 2;
+  int32_t cur = t.cur[b] * A * 2, h = t.hstep[b];
+  int32_t n_resets = 0, n_resets_total = 0;
+  const bool episodic = H > 0;
+  const bool uniform_h = episodic && wave == 0 && __all(h == __builtin_amdgcn_readfirstlane(h));
+  int n_ovf = 0;     // counts state (wave 1)
+  double sum = 0.0;  // rewards state (wave 2)
+  // producer state: the lane's key, transition counter and ring row stay in registers
+  const uint2 my_key = t.philox_key[b];
+  const unsigned long long my_ntr = t.n_trans[b];
+  const bool a_pow2 = A > 1 && (A & (A - 1)) == 0;
+  const int a_shift = 32 - (31 - __clz(A | 1));  // A = 2^k: floor(w * A / 2^32) = w >> (32 - k)
+  __syncthreads();
+
+  // actions of transitions [first, first + len) of this lane's instance, Philox blocks pidx, pidx + K1P_NPROD, ...
+  auto produce = [&](int buf, int64_t first, int len, int pidx) {
+    if (!owner) return;
+    const unsigned long long n0 = my_ntr + (unsigned long long)first;
+    const int rel0 = (int)(n0 & 3ull);  // the window starts inside a block when the counter is not a multiple of 4
+    const unsigned long long q0 = n0 >> 2;
+    const int nblk = (rel0 + len + 3) >> 2;
+    unsigned char* dst = ring + ((size_t)buf * p.G + lane) * AS;
+    for (int qi = pidx; qi < nblk; qi += K1P_NPROD) {
+      const unsigned long long q = q0 + (unsigned long long)qi;
+      uint32_t w[4], act[4];
+      philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), 2u, 0u, my_key.x, my_key.y, w);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        act[j] = a_pow2 ? (w[j] >> a_shift) : (uint32_t)(((uint64_t)w[j] * (uint64_t)A) >> 32);
+      const int pos0 = 4 * qi - rel0;
+      if (rel0 == 0 && pos0 + 4 <= len) {
+        *reinterpret_cast<uint32_t*>(dst + pos0) = act[0] | (act[1] << 8) | (act[2] << 16) | (act[3] << 24);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (pos0 + j >= 0 && pos0 + j < len) dst[pos0 + j] = (unsigned char)act[j];
+      }
+    }
+  };
+
+  // chain (wave 0): walks chunk `cb` of `len` transitions
+  auto chain_body = [&](int cb, int len) {
+    if (!owner || len <= 0) return;
+    const unsigned char* acts = ring + ((size_t)cb * p.G + lane) * AS;
+    uint16_t* tr = reinterpret_cast<uint16_t*>(trace + ((size_t)cb * p.G + lane) * TS);
+    int hs = uniform_h ? __builtin_amdgcn_readfirstlane(h) : 0, nres_s = 0;
+    // flavours as in K1L: T0 no episode logic, T1 scalar episode test, T2 per-lane
+    auto step = [&](int s, int a, auto mode_tag) {
+      constexpr int MODE = decltype(mode_tag)::value;
+      const int word = *reinterpret_cast<const uint16_t*>(base + cur + 2 * a);  // the one load on the dependency chain
+      tr[s] = (uint16_t)(word + 2 * a);  // arrival row under the action taken (base.py:1302-1303) | reward code
+      const int nxt = word & smask;
+      if (MODE == 0) {
+        cur = nxt;
+      } else if (MODE == 1) {
+        ++hs;
+        const bool term = hs >= H;
+        cur = term ? start_k : nxt;
+        hs = term ? 0 : hs;
+        nres_s += term ? 1 : 0;
+      } else {
+        ++h;
+        const bool term = episodic && h >= H;  // episodic termination followed at once by reset()
+        cur = term ? start_k : nxt;
+        h = term ? 0 : h;
+        n_resets += term ? 1 : 0;
+      }
+    };
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
+    using T2 = std::integral_constant<int, 2>;
+    int s0 = 0;
+    for (; s0 + 8 <= len; s0 += 8) {
+      const uint32_t a_lo = *reinterpret_cast<const uint32_t*>(acts + s0);
+      const uint32_t a_hi = *reinterpret_cast<const uint32_t*>(acts + s0 + 4);
+#define K1P_ACT(j) (int)((((j) < 4 ? a_lo : a_hi) >> (8 * ((j) & 3))) & 0xffu)
+      if (uniform_h && hs + 8 < H) {
+        step(s0 + 0, K1P_ACT(0), T0{}); step(s0 + 1, K1P_ACT(1), T0{}); step(s0 + 2, K1P_ACT(2), T0{});
+        step(s0 + 3, K1P_ACT(3), T0{}); step(s0 + 4, K1P_ACT(4), T0{}); step(s0 + 5, K1P_ACT(5), T0{});
+        step(s0 + 6, K1P_ACT(6), T0{}); step(s0 + 7, K1P_ACT(7), T0{});
+        hs += 8;
+      } else if (uniform_h && H >= 8) {
+        const int jstar = H - hs - 1;  // exactly one episode ends inside this group, after transition jstar
+#define K1P_STEP_R(j)                         \
+  step(s0 + (j), K1P_ACT(j), T0{});           \
+  if (jstar == (j)) { cur = start_k; ++nres_s; }
+        K1P_STEP_R(0) K1P_STEP_R(1) K1P_STEP_R(2) K1P_STEP_R(3) K1P_STEP_R(4) K1P_STEP_R(5) K1P_STEP_R(6) K1P_STEP_R(7)
+#undef K1P_STEP_R
+        hs = 7 - jstar;
+      } else if (uniform_h) {
+        step(s0 + 0, K1P_ACT(0), T1{}); step(s0 + 1, K1P_ACT(1), T1{}); step(s0 + 2, K1P_ACT(2), T1{});
+        step(s0 + 3, K1P_ACT(3), T1{}); step(s0 + 4, K1P_ACT(4), T1{}); step(s0 + 5, K1P_ACT(5), T1{});
+        step(s0 + 6, K1P_ACT(6), T1{}); step(s0 + 7, K1P_ACT(7), T1{});
+      } else {
+        step(s0 + 0, K1P_ACT(0), T2{}); step(s0 + 1, K1P_ACT(1), T2{}); step(s0 + 2, K1P_ACT(2), T2{});
+        step(s0 + 3, K1P_ACT(3), T2{}); step(s0 + 4, K1P_ACT(4), T2{}); step(s0 + 5, K1P_ACT(5), T2{});
+        step(s0 + 6, K1P_ACT(6), T2{}); step(s0 + 7, K1P_ACT(7), T2{});
+      }
+#undef K1P_ACT
+    }
+    for (; s0 < len; ++s0) {  // ragged tail of the launch's last chunk
+      const int a = acts[s0];
+      if (uniform_h) step(s0, a, T1{}); else step(s0, a, T2{});
+    }
+    if (uniform_h) { h = hs; n_resets += nres_s; }
+  };
+  // counts (wave 1): the chunk the chain traced into buffer `tb`
+  auto counts_body = [&](int tb, int plen) {
+    if (!owner || plen <= 0) return;
+    const unsigned char* trb = trace + ((size_t)tb * p.G + lane) * TS;
+    // 8-bit counters, read-modify-write by their only owner (LDS executes a wave's operations in order).  Two
+    // transitions per round trip: both counter reads are in flight together, and the second takes the first's
+    // result when they hit the same row.  A wrap goes to the overflow list, branch-free: the slot behind the
+    // last entry is only kept on a wrap.
+    auto count2 = [&](int x0, int x1) {
+      const int r0 = c8[x0], r1 = c8[x1];
+      const int c0 = r0 + 1;
+      const int c1 = (x1 == x0 ? (c0 & 255) : r1) + 1;
+      ovf[n_ovf] = (uint16_t)x0;
+      n_ovf += c0 >> 8;
+      ovf[n_ovf] = (uint16_t)x1;
+      n_ovf += c1 >> 8;
+      c8[x0] = (uint8_t)c0;
+      c8[x1] = (uint8_t)c1;
+    };
+    auto count1 = [&](int x0) {
+      const int c0 = (int)c8[x0] + 1;
+      ovf[n_ovf] = (uint16_t)x0;
+      n_ovf += c0 >> 8;
+      c8[x0] = (uint8_t)c0;
+    };
+    int s0 = 0;
+    for (; s0 + 4 <= plen; s0 += 4) {
+      const uint32_t e0 = *reinterpret_cast<const uint32_t*>(trb + 2 * s0);
+      const uint32_t e1 = *reinterpret_cast<const uint32_t*>(trb + 2 * s0 + 4);
+      count2((int)((e0 & (uint32_t)smask) >> 1), (int)(((e0 >> 16) & (uint32_t)smask) >> 1));
+      count2((int)((e1 & (uint32_t)smask) >> 1), (int)(((e1 >> 16) & (uint32_t)smask) >> 1));
+    }
+    for (; s0 < plen; ++s0) count1((int)((reinterpret_cast<const uint16_t*>(trb)[s0] & smask) >> 1));
+  };
+  // rewards (wave 4)
+  auto rewards_body = [&](int tb, int plen) {
+    if (!owner || plen <= 0) return;
+    const unsigned char* trb = trace + ((size_t)tb * p.G + lane) * TS;
+    int s0 = 0;
+    for (; s0 + 4 <= plen; s0 += 4) {
+      const uint32_t e0 = *reinterpret_cast<const uint32_t*>(trb + 2 * s0);
+      const uint32_t e1 = *reinterpret_cast<const uint32_t*>(trb + 2 * s0 + 4);
+      const double r0 = rv2[(e0 & 0xffffu) >> p.code_shift], r1 = rv2[e0 >> (16 + p.code_shift)];
+      const double r2 = rv2[(e1 & 0xffffu) >> p.code_shift], r3 = rv2[e1 >> (16 + p.code_shift)];
+      sum += r0; sum += r1; sum += r2; sum += r3;  // transition order
+    }
+    for (; s0 < plen; ++s0) sum += rv2[reinterpret_cast<const uint16_t*>(trb)[s0] >> p.code_shift];
+  };
+
+  // wavefront w runs on SIMD w % 4: the chain and the counters keep a SIMD to themselves apart from the light
+  // reward adder (wave 4; wave 5 idles); the four producers share SIMDs 2 and 3
+  const int pidx = wave == 2 ? 0 : wave == 3 ? 1 : wave == 6 ? 2 : wave == 7 ? 3 : -1;
+  if (n_steps > 0 && pidx >= 0) produce(0, 0, (int)min((int64_t)CH, n_steps), pidx);
+  __syncthreads();
+  // Pipeline iteration: the chain walks chunk `cb` (len transitions) while the bookkeepers take the chunk before it
+  // (plen) and the producers fill the one after.  Every wave keeps its own copy of these (uniform) counters and runs
+  // its own compact loop -- one shared loop dispatching on the role cost ~0.6 us per iteration in far branches.
+  int since_flush = 0, cb = 0, len = 0, plen = 0;
+  int64_t left = n_steps;  // transitions the chain has not walked yet
+  bool last = false, flush_now = false;
+  auto begin_iter = [&]() {
+    plen = len;
+    len = (int)min((int64_t)CH, left);
+    left -= len;
+  };
+  auto end_iter = [&]() {
+    since_flush += plen;
+    last = len == 0;  // the bookkeepers have just drained the final chunk
+    // 8-bit deltas wrap at most once per 256 transitions of their instance; the overflow list holds K1L_OVF wraps
+    flush_now = (since_flush + CH > 256 * K1L_OVF) || last;
+    cb ^= 1;
+  };
+  for (;;) {
+    if (wave == 0) {
+      do {
+        begin_iter();
+        chain_body(cb, len);
+        end_iter();
+        if (flush_now && owner) {
+          resets[lane] = n_resets;
+          n_resets_total += n_resets;
+          n_resets = 0;
+        }
+        __syncthreads();
+      } while (!flush_now);
+    } else if (wave == 1) {
+      do {
+        begin_iter();
+        counts_body(cb ^ 1, plen);
+        end_iter();
+        __syncthreads();
+      } while (!flush_now);
+    } else if (wave == 4) {
+      do {
+        begin_iter();
+        rewards_body(cb ^ 1, plen);
+        end_iter();
+        __syncthreads();
+      } while (!flush_now);
+    } else if (pidx >= 0) {
+      do {
+        begin_iter();
+        if (left > 0) produce(cb ^ 1, n_steps - left, (int)min((int64_t)CH, left), pidx);
+        end_iter();
+        __syncthreads();
+      } while (!flush_now);
+    } else {
+      do {
+        begin_iter();
+        end_iter();
+        __syncthreads();
+      } while (!flush_now);
+    }
+    if (tid < K1L_THREADS) {
+      flush_counts<true, true>(t.visits_sa + row00, total_rows, rows, A, slots, p, resets, nullptr, tid);
+      flush_counts<false, true>(t.visits_s + so0, total_states, S, A, slots, p, resets, t.start_state + t.start_off[g0], tid);
+    }
+    __syncthreads();
+    if (wave == 1 && owner) {  // every recorded wrap is worth 256 visits
+      for (int e = 0; e < n_ovf; ++e) {
+        const int r = ovf[e];
+        t.visits_sa[row00 + (int64_t)lane * rows + r] += 256;
+        t.visits_s[so0 + (int64_t)lane * S + r / A] += 256;
+      }
+      n_ovf = 0;
+    }
+    if (last) break;
+    if (tid < K1L_THREADS)
+      for (int j = tid; j < nb * cnt_dwords; j += K1L_THREADS) {
+        const int slot = j / cnt_dwords, off = j - slot * cnt_dwords;
+        reinterpret_cast<uint32_t*>(slots + (size_t)slot * p.slot_bytes + p.off_cnt)[off] = 0u;
+      }
+    since_flush = 0;
+    __syncthreads();
+  }
+  if (wave == 0 && owner) {
+    cur /= 2 * A;
+    t.cur[b] = cur;
+    t.hstep[b] = h;
+    t.n_trans[b] = my_ntr + (unsigned long long)n_steps;
+    t.n_reset[b] += (unsigned long long)n_resets_total;
+    if (last_obs) last_obs[b] = cur;  // the state after the last transition (the start state after a termination)
+  }
+  if (wave == 4 && owner && reward_sum) reward_sum[b] = sum;
+}
+
 template <bool ROWS, bool BYTES>
 __device__ __forceinline__ void flush_counts(int32_t* __restrict__ dst, int total, int per, int A, unsigned char* slots,
                                              const LdsPlan& p, const int32_t* resets, const int32_t* start_states,
@@ -624,6 +944,7 @@ __device__ __forceinline__ void flush_counts(int32_t* __restrict__ dst, int tota
     if (d) dst[j] += d;
   }
   int4* vdst = reinterpret_cast<int4*>(dst + lead);
+  // (reading only the 16-byte groups whose deltas are nonzero was measured SLOWER: the loads lose their batching)
   for (int c0 = 0; c0 < nfull; c0 += K1L_THREADS * K1L_UNROLL) {
     int4 old[K1L_UNROLL];
 #pragma unroll

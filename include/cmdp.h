@@ -192,6 +192,13 @@ enum { CMDP_OPT_ROLLOUT_KERNEL = 1, CMDP_OPT_DP_KERNEL = 2, CMDP_OPT_LDS_GROUPS_
        CMDP_OPT_DIAMETER_WORKSPACE_MB = 4, CMDP_OPT_CHAIN_EXACT_ORDER = 5 };
 int cmdp_set_option(cmdp_t* h, int option, int64_t value);
 
+/* What the LDS-resident random-policy rollout of this handle is (introspection for benchmarks and tests; no
+   reference counterpart): plan[0] = 1 if the batch is eligible for it, plan[1] = 1 for the wavefront-pipeline kernel
+   K1P (k_rollout_pipe), 0 for the fused walker K1L (k_rollout_lds), plan[2] = instances per workgroup,
+   plan[3] = transitions per chunk.  The kernel flavour and chunk length are chosen when the handle is created (fewest
+   rounds of workgroups x measured time per transition). */
+int cmdp_lds_plan(cmdp_t* h, int32_t plan[4]);
+
 /* BaseMDP.get_visitation_counts / reset_visitation_counts (colosseum/mdp/base.py:1357-1382).
    state_counts [state_off[B]], sa_counts [state_off[B]*A]; either may be NULL. */
 int cmdp_visits(cmdp_t* h, int64_t* state_counts, int64_t* sa_counts);

@@ -169,33 +169,67 @@ def test_lds_resident_rollout_equals_global_kernel_and_oracle(need_gpu):
         _check_lds_rollout(75, size, 50, n2)
 
 
-def _check_lds_rollout(B, size, n1, n2):
+def _check_lds_rollout(B, size, n1, n2, tables=None, models=None):
+    import os
+
     from colosseum_amd.mdp.fast_batch import deepsea_episodic_tables
 
     seeds = np.arange(1000, 1000 + B)
-    tables = deepsea_episodic_tables(seeds, size)
+    if models is not None:
+        from colosseum_amd.batched import tables_from_models
+        tables = tables_from_models(models, True, False)
+    elif tables is None:
+        tables = deepsea_episodic_tables(seeds, size)
     keys = (seeds * 7919).astype(np.uint64)
     res = {}
-    for which in (L.ROLLOUT_GLOBAL, L.ROLLOUT_LDS):
-        env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX, philox_keys=keys)
+    # the LDS-resident rollout exists as the fused walker (K1L) and as the wavefront pipeline (K1P); CMDP_K1L_PIPE
+    # (read when the handle is created) forces one of them
+    for which, pipe in ((L.ROLLOUT_GLOBAL, None), (L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1")):
+        saved = os.environ.pop("CMDP_K1L_PIPE", None)
+        if pipe is not None:
+            os.environ["CMDP_K1L_PIPE"] = pipe
+        try:
+            env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX, philox_keys=keys)
+        finally:
+            os.environ.pop("CMDP_K1L_PIPE", None)
+            if saved is not None:
+                os.environ["CMDP_K1L_PIPE"] = saved
+        if pipe is not None:
+            plan = env.lds_plan()
+            assert plan["eligible"] and plan["kernel"] == ("k_rollout_pipe" if pipe == "1" else "k_rollout_lds"), plan
         env.set_rollout_kernel(which)
         env.reset()
         a = env.rollout(n1)  # odd transition count: the next launch starts mid Philox block and mid episode
         b = env.rollout(n2)
+        c = env.rollout(3)   # shorter than one Philox block / one group of 8
         vs, vsa = env.visits()
-        res[which] = (a["last_obs"], a["reward_sum"], b["last_obs"], b["reward_sum"], vs, vsa, env.state())
+        res[(which, pipe)] = (a["last_obs"], a["reward_sum"], b["last_obs"], b["reward_sum"], c["last_obs"],
+                              c["reward_sum"], vs, vsa, env.state())
         env.close()
-    g, l = res[L.ROLLOUT_GLOBAL], res[L.ROLLOUT_LDS]
-    for x, y in zip(g[:6], l[:6]):
-        np.testing.assert_array_equal(x, y)
-    for x, y in zip(g[6], l[6]):
-        np.testing.assert_array_equal(x, y)
-    last, rsum, ovs, ovsa = O.batch_rollout(tables, 0, B, n1 + n2, rng_mode=1, philox_keys=keys, want_visits=True)
-    np.testing.assert_array_equal(l[2], last)
-    np.testing.assert_array_equal(l[4], ovs)
-    np.testing.assert_array_equal(l[5], ovsa)
-    # the oracle sums all n1+n2 rewards in one go; the two launches' sums are separate partial sums
-    np.testing.assert_allclose(l[1] + l[3], rsum, rtol=1e-12)
+    g = res[(L.ROLLOUT_GLOBAL, None)]
+    for pipe in ("0", "1"):
+        l = res[(L.ROLLOUT_LDS, pipe)]
+        for x, y in zip(g[:8], l[:8]):
+            np.testing.assert_array_equal(x, y)
+        for x, y in zip(g[8], l[8]):
+            np.testing.assert_array_equal(x, y)
+    l = res[(L.ROLLOUT_LDS, "1")]
+    last, rsum, ovs, ovsa = O.batch_rollout(tables, 0, B, n1 + n2 + 3, rng_mode=1, philox_keys=keys, want_visits=True)
+    np.testing.assert_array_equal(l[4], last)
+    np.testing.assert_array_equal(l[6], ovs)
+    np.testing.assert_array_equal(l[7], ovsa)
+    # the oracle sums all rewards in one go; the launches' sums are separate partial sums
+    np.testing.assert_allclose(l[1] + l[3] + l[5], rsum, rtol=1e-12)
+
+
+def test_lds_rollout_continuous_and_other_families(need_gpu):
+    """K1L / K1P on continuous (no horizon: the per-lane flavour of the walker) and episodic instances of other
+    deterministic families, A = 2..5, against the HBM-table kernel and the oracle."""
+    B = 70
+    for cls, kw in (("DeepSeaContinuous", dict(size=9)), ("SimpleGridContinuous", dict(size=7)),
+                    ("MiniGridEmptyEpisodic", dict(size=6)), ("RiverSwimEpisodic", dict(size=40))):
+        models = [make_model(cls, seed=1000 + i, **kw) for i in range(B)]
+        _check_lds_rollout(B, None, 13, 9_001, models=models)
 
 
 def test_lds_kernel_refused_when_not_eligible(need_gpu):
