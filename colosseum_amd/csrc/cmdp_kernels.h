@@ -285,7 +285,7 @@ struct LdsPlan {
 struct LdsPlan;
 // dst[j] += delta(j) for j in [0, total): ROWS: delta = 16-bit count of row j; else delta = sum over the A
 // counts of state j (+ the resets of its instance when j is the start state).  `per` = rows or states per slot.
-template <bool ROWS, bool BYTES>
+template <bool ROWS, bool BYTES, int NT>
 __device__ __forceinline__ void flush_counts(int32_t* __restrict__ dst, int total, int per, int A, unsigned char* slots,
                                              const LdsPlan& p, const int32_t* resets, const int32_t* start_states,
                                              int tid);
@@ -302,6 +302,7 @@ __device__ __forceinline__ void flush_counts(int32_t* __restrict__ dst, int tota
 // Stages the successor words of a group's `total_rows` rows into the instance slots: 16-byte loads from the
 // aligned-down address, K1L_UNROLL of them in flight per thread (the element arrays carry 16 bytes of slack at
 // both ends, see cmdp_create).
+template <int NT>
 __device__ __forceinline__ void k1l_stage_words(const LdsPlan& p, int64_t row00, int total_rows, int rows,
                                                 unsigned char* slots, int tid) {
   {
@@ -309,16 +310,16 @@ __device__ __forceinline__ void k1l_stage_words(const LdsPlan& p, int64_t row00,
     const int head = (int)((reinterpret_cast<uintptr_t>(src) & 15) >> 1);
     const uint4* vsrc = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(src) - 2 * head);
     const int nchunks = (head + total_rows + 7) >> 3;
-    for (int c0 = 0; c0 < nchunks; c0 += K1L_THREADS * K1L_UNROLL) {
+    for (int c0 = 0; c0 < nchunks; c0 += NT * K1L_UNROLL) {
       uint4 v[K1L_UNROLL];
 #pragma unroll
       for (int k = 0; k < K1L_UNROLL; ++k) {
-        const int c = c0 + k * K1L_THREADS + tid;
+        const int c = c0 + k * NT + tid;
         if (c < nchunks) v[k] = vsrc[c];
       }
 #pragma unroll
       for (int k = 0; k < K1L_UNROLL; ++k) {
-        const int c = c0 + k * K1L_THREADS + tid;
+        const int c = c0 + k * NT + tid;
         if (c < nchunks) {
           const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
           int j = c * 8 - head;
@@ -369,7 +370,7 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
   if (tid < nb) { keys[tid] = t.philox_key[g0 + tid]; ntr[tid] = t.n_trans[g0 + tid]; }
   // ---- stage the tables: 16-byte loads from the aligned-down address, K1L_UNROLL of them in flight per
   //      thread (the element arrays carry 16 bytes of slack at both ends, see cmdp_create) -----------------
-  k1l_stage_words(p, row00, total_rows, rows, slots, tid);
+  k1l_stage_words<K1L_THREADS>(p, row00, total_rows, rows, slots, tid);
   if (!PACKED) {
     const uint8_t* src = p.rcode + row00;
     const int head = (int)(reinterpret_cast<uintptr_t>(src) & 15);
@@ -577,8 +578,8 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
     if (flush_now) {
       // ---- flush the deltas into the HBM counters: 16-byte read-modify-writes (every counter has exactly one
       //      owner; the partial chunks at the two ends of the group's range go element by element) -----------
-      flush_counts<true, PACKED>(t.visits_sa + row00, total_rows, rows, A, slots, p, resets, nullptr, tid);
-      flush_counts<false, PACKED>(t.visits_s + so0, total_states, S, A, slots, p, resets, t.start_state + t.start_off[g0], tid);
+      flush_counts<true, PACKED, K1L_THREADS>(t.visits_sa + row00, total_rows, rows, A, slots, p, resets, nullptr, tid);
+      flush_counts<false, PACKED, K1L_THREADS>(t.visits_s + so0, total_states, S, A, slots, p, resets, t.start_state + t.start_off[g0], tid);
       __syncthreads();
       if (PACKED && walker) {  // every recorded wrap is worth 256 visits (the dummy counter never gets that far)
         for (int e = 0; e < n_ovf; ++e) {
@@ -651,13 +652,11 @@ __global__ void __launch_bounds__(K1P_THREADS) k_rollout_pipe(EnvTables t, LdsPl
   const int64_t row00 = so0 * A;
   const int total_rows = nb * rows, total_states = nb * S;
   const int cnt_dwords = (p.rows_max + 4) / 4;
-  if (tid < K1L_THREADS) {  // the staging / flush helpers are written for K1L_THREADS threads
-    for (int i = tid; i < p.n_codes; i += K1L_THREADS) rv2[i] = p.rvals[i] * t.rscale - t.rmin;
-    k1l_stage_words(p, row00, total_rows, rows, slots, tid);
-    for (int j = tid; j < nb * cnt_dwords; j += K1L_THREADS) {
-      const int slot = j / cnt_dwords, off = j - slot * cnt_dwords;
-      reinterpret_cast<uint32_t*>(slots + (size_t)slot * p.slot_bytes + p.off_cnt)[off] = 0u;
-    }
+  for (int i = tid; i < p.n_codes; i += K1P_THREADS) rv2[i] = p.rvals[i] * t.rscale - t.rmin;
+  k1l_stage_words<K1P_THREADS>(p, row00, total_rows, rows, slots, tid);
+  for (int j = tid; j < nb * cnt_dwords; j += K1P_THREADS) {
+    const int slot = j / cnt_dwords, off = j - slot * cnt_dwords;
+    reinterpret_cast<uint32_t*>(slots + (size_t)slot * p.slot_bytes + p.off_cnt)[off] = 0u;
   }
   const bool owner = lane < nb;  // this lane's instance exists
   const int b = g0 + (owner ? lane : 0);
@@ -885,10 +884,8 @@ __global__ void __launch_bounds__(K1P_THREADS) k_rollout_pipe(EnvTables t, LdsPl
         __syncthreads();
       } while (!flush_now);
     }
-    if (tid < K1L_THREADS) {
-      flush_counts<true, true>(t.visits_sa + row00, total_rows, rows, A, slots, p, resets, nullptr, tid);
-      flush_counts<false, true>(t.visits_s + so0, total_states, S, A, slots, p, resets, t.start_state + t.start_off[g0], tid);
-    }
+    flush_counts<true, true, K1P_THREADS>(t.visits_sa + row00, total_rows, rows, A, slots, p, resets, nullptr, tid);
+    flush_counts<false, true, K1P_THREADS>(t.visits_s + so0, total_states, S, A, slots, p, resets, t.start_state + t.start_off[g0], tid);
     __syncthreads();
     if (wave == 1 && owner) {  // every recorded wrap is worth 256 visits
       for (int e = 0; e < n_ovf; ++e) {
@@ -899,11 +896,10 @@ __global__ void __launch_bounds__(K1P_THREADS) k_rollout_pipe(EnvTables t, LdsPl
       n_ovf = 0;
     }
     if (last) break;
-    if (tid < K1L_THREADS)
-      for (int j = tid; j < nb * cnt_dwords; j += K1L_THREADS) {
-        const int slot = j / cnt_dwords, off = j - slot * cnt_dwords;
-        reinterpret_cast<uint32_t*>(slots + (size_t)slot * p.slot_bytes + p.off_cnt)[off] = 0u;
-      }
+    for (int j = tid; j < nb * cnt_dwords; j += K1P_THREADS) {
+      const int slot = j / cnt_dwords, off = j - slot * cnt_dwords;
+      reinterpret_cast<uint32_t*>(slots + (size_t)slot * p.slot_bytes + p.off_cnt)[off] = 0u;
+    }
     since_flush = 0;
     __syncthreads();
   }
@@ -918,7 +914,7 @@ __global__ void __launch_bounds__(K1P_THREADS) k_rollout_pipe(EnvTables t, LdsPl
   if (wave == 4 && owner && reward_sum) reward_sum[b] = sum;
 }
 
-template <bool ROWS, bool BYTES>
+template <bool ROWS, bool BYTES, int NT>
 __device__ __forceinline__ void flush_counts(int32_t* __restrict__ dst, int total, int per, int A, unsigned char* slots,
                                              const LdsPlan& p, const int32_t* resets, const int32_t* start_states,
                                              int tid) {
@@ -945,16 +941,16 @@ __device__ __forceinline__ void flush_counts(int32_t* __restrict__ dst, int tota
   }
   int4* vdst = reinterpret_cast<int4*>(dst + lead);
   // (reading only the 16-byte groups whose deltas are nonzero was measured SLOWER: the loads lose their batching)
-  for (int c0 = 0; c0 < nfull; c0 += K1L_THREADS * K1L_UNROLL) {
+  for (int c0 = 0; c0 < nfull; c0 += NT * K1L_UNROLL) {
     int4 old[K1L_UNROLL];
 #pragma unroll
     for (int k = 0; k < K1L_UNROLL; ++k) {
-      const int c = c0 + k * K1L_THREADS + tid;
+      const int c = c0 + k * NT + tid;
       if (c < nfull) old[k] = vdst[c];
     }
 #pragma unroll
     for (int k = 0; k < K1L_UNROLL; ++k) {
-      const int c = c0 + k * K1L_THREADS + tid;
+      const int c = c0 + k * NT + tid;
       if (c < nfull) {
         int j = lead + 4 * c;
         int slot = j / per, off = j - slot * per;

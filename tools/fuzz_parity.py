@@ -94,11 +94,14 @@ def check_one():
         keys = rng.integers(1, 2**40, 3).astype(np.uint64)
         env = BatchedMDP([m] * 3, rng_mode=L.RNG_PHILOX, philox_keys=keys, with_dp=False)
         env.reset()
+        n1 = int(rng.integers(0, 200))  # the second launch starts mid Philox block / mid episode
+        env.rollout(n1)
         o2 = env.rollout(n)
         vs, _ = env.visits()
         for b in range(3):
             e = O.OracleEnv(m, rng_mode=1, philox_key=int(keys[b]))
             e.reset()
+            e.rollout(n1, trace=False)
             r2 = e.rollout(n, trace=False)
             assert o2["last_obs"][b] == r2["last_obs"] and o2["reward_sum"][b] == r2["reward_sum"], tag
             assert np.array_equal(env.split_states(vs)[b], e.visits()[0]), tag
