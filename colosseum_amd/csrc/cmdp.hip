@@ -420,6 +420,7 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
         if (cus < 1) cus = 256;
         double best_cost = -1.0;
+        int best_cap = 0;  // LDS capacity (instances per workgroup) of the chosen candidate
         p.ch = 256;
         p.G = 0;
         const int force_ch = std::getenv("CMDP_K1L_CH") ? std::atoi(std::getenv("CMDP_K1L_CH")) : 0;      // tuning aids
@@ -427,16 +428,20 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
         struct Cand { int pipe, ch; };
         // Packed tables can also run as the wavefront pipeline K1P: ~0.62x the time per transition plus one barrier
         // per chunk (measured at C2: 53 / 56 / 62 ns per transition at ch = 64 / 32 / 16 against K1L's 82), for
-        // 6 ch + 16 bytes of rings per instance instead of 2 ch.  K1P wants the CU to itself: two of its 8-wavefront
-        // workgroups per CU ran 1.8x slower than one.
+        // 6 ch + 16 bytes of rings per instance instead of 2 ch.
         const Cand cands[] = {{0, 256}, {0, 128}, {0, 112}, {0, 64}, {1, 64}, {1, 32}, {1, 16}};
         for (const Cand& c : cands) {
           if (force_ch && c.ch != force_ch) continue;
           if (c.pipe && !pipe_ok) continue;
           if (force_pipe >= 0 && c.pipe != force_pipe) continue;
           const int pi = p.slot_bytes + (c.pipe ? 2 * K1P_ACT_STRIDE(c.ch) + 2 * K1P_TR_STRIDE(c.ch) : 2 * c.ch);
-          const int g1 = std::min<int>(64, (kLdsBudget - fixed) / pi);
-          const int g2 = c.pipe ? 0 : std::min<int>(64, (kLdsBudget / 2 - fixed) / pi);
+          const int fx = fixed;
+          const int g1 = std::min<int>(64, (kLdsBudget - fx) / pi);
+          // K1P: one workgroup per CU.  Two (26 + 26 instances at C2) need <= 128 VGPRs to be co-resident at all (it has
+          // 145: the "1.8x slower" of the first trial was simply one resident group at a time); forced to 128 it spills,
+          // and two resident groups gain nothing -- they run in lockstep, so their flushes coincide, and a CU holds
+          // the same 52 instances either way.
+          const int g2 = c.pipe ? 0 : std::min<int>(64, (kLdsBudget / 2 - fx) / pi);
           for (int per_cu : {2, 1}) {
             const int g = per_cu == 2 ? g2 : g1;
             if (g < (per_cu == 2 ? 12 : 8)) continue;
@@ -446,9 +451,12 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
             const double cost = (double)rounds * per_step;
             if (best_cost < 0 || cost < best_cost) {
               best_cost = cost;
+              best_cap = g;
               p.ch = c.ch;
               p.pipe = c.pipe;
-              p.G = g;
+              // the fewest instances per workgroup that still need `rounds` rounds: evens out the last round and keeps
+              // LDS bank conflicts down (53 instead of 52 lanes per walker measured +1.2 % at C2)
+              p.G = (int)std::min<int64_t>(g, std::max<int64_t>(1, (B + rounds * slots_n - 1) / (rounds * slots_n)));
               h->lds_G1 = g1;
               h->lds_G2 = g2;
             }
@@ -459,7 +467,7 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
           for (int64_t r = 0; r < R; ++r)
             next16[(size_t)r] = (uint16_t)((next16[(size_t)r] * A * (p.pipe ? 2 : 1)) | (codes[(size_t)r] << p.code_shift));
         p.n_codes = (int)vals.size();
-        if (p.G >= 8) {
+        if (best_cap >= 8) {
           // 16 bytes of slack in front of and behind both element arrays: the staging loads are 16-byte wide
           // from the aligned-down address of a group's first element
           next16.insert(next16.begin(), 8, 0);
