@@ -232,6 +232,53 @@ def test_lds_rollout_continuous_and_other_families(need_gpu):
         _check_lds_rollout(B, None, 13, 9_001, models=models)
 
 
+def test_lds_rollout_with_per_instance_episode_phase(need_gpu):
+    """A masked reset() leaves the instances of a batch at different in-episode times: the LDS walkers then run
+    their per-lane flavour (no shared episode clock).  K1L, K1P and the HBM-table kernel against per-instance oracle
+    environments: last observation, reward sum, visit counts, state."""
+    import os
+
+    B, size = 45, 9
+    models = [make_model("DeepSeaEpisodic", seed=300 + i, size=size) for i in range(B)]
+    keys = (np.arange(B) * 104729 + 17).astype(np.uint64)
+    mask = (np.arange(B) % 3 == 0).astype(np.uint8)
+    n1, n2 = 13, 6_007
+    res = {}
+    for which, pipe in ((L.ROLLOUT_GLOBAL, None), (L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1")):
+        saved = os.environ.pop("CMDP_K1L_PIPE", None)
+        if pipe is not None:
+            os.environ["CMDP_K1L_PIPE"] = pipe
+        try:
+            env = BatchedMDP(models, rng_mode=L.RNG_PHILOX, philox_keys=keys, with_dp=False)
+        finally:
+            os.environ.pop("CMDP_K1L_PIPE", None)
+            if saved is not None:
+                os.environ["CMDP_K1L_PIPE"] = saved
+        env.set_rollout_kernel(which)
+        env.reset()
+        env.rollout(n1)
+        env.reset(mask)                       # every third instance back to h = 0, the others stay at h = 13 mod H
+        assert len(set(env.state()[1].tolist())) > 1
+        out = env.rollout(n2)
+        vs, vsa = env.visits()
+        res[(which, pipe)] = (out["last_obs"], out["reward_sum"], vs, vsa) + tuple(env.state())
+        env.close()
+    g = res[(L.ROLLOUT_GLOBAL, None)]
+    for pipe in ("0", "1"):
+        for x, y in zip(g, res[(L.ROLLOUT_LDS, pipe)]):
+            np.testing.assert_array_equal(x, y)
+    off = np.concatenate([[0], np.cumsum([m.n_states for m in models])])
+    for b in range(B):
+        e = O.OracleEnv(models[b], rng_mode=1, philox_key=int(keys[b]))
+        e.reset()
+        e.rollout(n1, trace=False)
+        if mask[b]:
+            e.reset()
+        r = e.rollout(n2, trace=False)
+        assert g[0][b] == r["last_obs"] and g[1][b] == r["reward_sum"], b
+        np.testing.assert_array_equal(g[2][off[b]:off[b + 1]], e.visits()[0])
+
+
 def test_lds_kernel_refused_when_not_eligible(need_gpu):
     m = make_model("FrozenLakeContinuous", seed=0, size=5, p_frozen=0.9)
     env = BatchedMDP([m], rng_mode=L.RNG_PHILOX, with_dp=False)
