@@ -21,6 +21,7 @@ OPT_LDS_GROUPS_PER_CU = 3
 OPT_DIAMETER_WORKSPACE_MB = 4
 OPT_CHAIN_EXACT_ORDER = 5
 DP_AUTO, DP_WORKGROUP, DP_REGISTER = 0, 1, 2
+DP_REGISTER_DISTINCT = 5  # K2U: register-resident, gathers deduplicated per state
 ROLLOUT_AUTO, ROLLOUT_GLOBAL, ROLLOUT_LDS = 0, 1, 2
 
 EXPORTS = [

@@ -91,7 +91,8 @@ struct cmdp {
   int max_S = 0;
   int64_t max_inst_nnz = 0;
   int max_row_nnz = 0;
-  int dp_kernel = 0;  // 0 auto, 1 LDS/global-CSR workgroup kernel, 2 register-resident kernel
+  int max_state_unique = 0;  // distinct successor columns of a state over its A rows (0: not computed / rows unsorted)
+  int dp_kernel = 0;  // 0 auto, 1 LDS/global-CSR workgroup kernel, 2 register-resident kernel K2R, 5 its distinct-successor form K2U (3, 4: diameter only)
 
   DevBuf<int64_t> d_state_off, d_entry_base, d_start_off, d_csr_ptr;
   DevBuf<RowDesc> d_row;
@@ -516,6 +517,27 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
             return fail(CMDP_ERR_INVALID, "csr_col out of range at %lld", (long long)k);
       }
     }
+    // K2U (k_dp_regu): distinct successor columns per STATE over its A rows, and whether every row lists its columns
+    // in strictly ascending order (the dense-over-the-distinct-set sum is the ascending-column sum)
+    h->max_state_unique = 0;
+    if (A <= 4 && h->max_row_nnz <= 8 && max_S <= 1024) {
+      bool sorted = true;
+      int32_t cols[32];
+      for (int64_t s = 0; s < d->state_off[B] && sorted; ++s) {
+        int n = 0;
+        for (int a = 0; a < A; ++a) {
+          const int64_t r = s * A + a;
+          for (int64_t k = d->csr_ptr[r]; k < d->csr_ptr[r + 1]; ++k) {
+            if (k > d->csr_ptr[r] && d->csr_col[k] <= d->csr_col[k - 1]) sorted = false;
+            cols[n++] = d->csr_col[k];
+          }
+        }
+        std::sort(cols, cols + n);
+        const int u = (int)(std::unique(cols, cols + n) - cols);
+        h->max_state_unique = std::max(h->max_state_unique, u);
+      }
+      if (!sorted) h->max_state_unique = 0;
+    }
     HIP_TRY(h->d_csr_ptr.upload(d->csr_ptr, R + 1, st));
     HIP_TRY(h->d_csr_col.upload(d->csr_col, N, st));
     HIP_TRY(h->d_csr_val.upload(d->csr_val, N, st));
@@ -752,7 +774,7 @@ int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
     h->lds_bytes = k1l_lds_bytes(h->lds_plan, g);
     return CMDP_OK;
   }
-  if (option == CMDP_OPT_DP_KERNEL && value >= 0 && value <= 4) {
+  if (option == CMDP_OPT_DP_KERNEL && value >= 0 && value <= 5) {
     h->dp_kernel = (int)value;
     return CMDP_OK;
   }
@@ -879,6 +901,34 @@ int run_sweeps(cmdp_t* h, int mode, bool diam, int scheme, DpTables t, int64_t u
     const size_t lds = 2 * sizeof(float) * 256 * (size_t)std::max(spt, 1) + sizeof(float) * 16;  // Va, Vb at fixed offsets
     bool launched = true;
     const dim3 grid((unsigned)units), block(256);
+    // K2U when the states' rows share their successors: U gathers instead of A x K (dp_kernel 5 forces it, 2 forbids it)
+    const int U = h->max_state_unique == 0 ? 0 : (h->max_state_unique <= 5 ? 5 : (h->max_state_unique <= 8 ? 8 : 0));
+    const bool want_u = U > 0 && K > 0 && spt > 0 && spt * U <= 16 && h->dp_kernel != 2 &&
+                        (h->dp_kernel == 5 || 2 * U <= A * K);
+    if (h->dp_kernel == 5 && !want_u)
+      return fail(CMDP_ERR_UNSUPPORTED, "no distinct-successor instantiation (A=%d, %d distinct successors per state, %d states)",
+                  A, h->max_state_unique, h->max_S);
+    if (want_u) {
+      bool done = true;
+#define REGU_CASE(AT, UT, KT, ST)                                                                             \
+  if (A == AT && U == UT && K == KT && spt == ST) {                                                           \
+    if (mode == DP_VI) hipLaunchKernelGGL((k_dp_regu<DP_VI, AT, UT, KT, ST>), grid, block, lds, st, t);        \
+    else hipLaunchKernelGGL((k_dp_regu<DP_PE, AT, UT, KT, ST>), grid, block, lds, st, t);                      \
+  } else
+      REGU_CASE(2, 5, 4, 1) REGU_CASE(2, 5, 4, 2) REGU_CASE(2, 5, 8, 1) REGU_CASE(2, 5, 8, 2)
+      REGU_CASE(3, 5, 4, 1) REGU_CASE(3, 5, 4, 2) REGU_CASE(3, 5, 8, 1) REGU_CASE(3, 5, 8, 2)
+      REGU_CASE(4, 5, 4, 1) REGU_CASE(4, 5, 4, 2) REGU_CASE(4, 5, 8, 1) REGU_CASE(4, 5, 8, 2)
+      REGU_CASE(3, 8, 8, 1) REGU_CASE(3, 8, 8, 2) REGU_CASE(4, 8, 4, 1) REGU_CASE(4, 8, 4, 2)
+      REGU_CASE(4, 8, 8, 1) REGU_CASE(4, 8, 8, 2)
+      { done = false; }
+#undef REGU_CASE
+      if (done) {
+        HIP_TRY(hipGetLastError());
+        return CMDP_OK;
+      }
+      if (h->dp_kernel == 5)
+        return fail(CMDP_ERR_UNSUPPORTED, "no distinct-successor instantiation for A=%d, U=%d, %d non-zeros/row, %d states", A, U, h->max_row_nnz, h->max_S);
+    }
 #define REG_CASE(AT, KT, ST)                                                                                  \
   if (A == AT && K == KT && spt == ST) {                                                                      \
     if (mode == DP_VI) hipLaunchKernelGGL((k_dp_reg<DP_VI, AT, KT, ST>), grid, block, lds, st, t);             \
@@ -1126,7 +1176,7 @@ int cmdp_diameter(cmdp_t* h, double epsilon, int scheme, int64_t max_sweeps, flo
   t.gamma = 1.0f; t.eps = epsilon; t.max_abs = 0.0; t.max_sweeps = max_sweeps;
   t.Q = nullptr; t.V = nullptr; t.sweeps = nullptr; t.per_target = h->d_per_target.p; t.status = h->d_status.p;
   const size_t v_need = 2 * sizeof(float) * (size_t)h->max_S + sizeof(float) * 4 * (kDpBlock / 64);
-  const bool lanes = sch == CMDP_SCHEME_JACOBI && (h->dp_kernel >= 3 || v_need > (size_t)kLdsBudget);
+  const bool lanes = sch == CMDP_SCHEME_JACOBI && (h->dp_kernel == 3 || h->dp_kernel == 4 || v_need > (size_t)kLdsBudget);
   if (lanes) {
     if (int rc = diameter_lanes(h, t, 0, NS)) return rc;
   } else if (int rc = run_sweeps(h, DP_VI, true, sch, t, NS)) return rc;

@@ -1450,6 +1450,170 @@ __global__ void __launch_bounds__(256) k_dp_reg(DpTables t) {
   }
 }
 
+// K2U: K2R with the gathers of a state DEDUPLICATED.  The A rows of a state mostly name the same few successor
+// states (grid worlds: the four neighbours and the state itself, whatever the action), so K2R's A x KMAX gathers fetch
+// the same <= U values over and over -- and the kernel is bound by exactly that LDS gather traffic.  Here a thread keeps,
+// per owned state, the sorted list of its U distinct successor columns and a DENSE A x U coefficient matrix over them
+// (both built in registers when the kernel starts); a sweep gathers U values once and every action's expectation is the
+// ascending-column sum over all U of them.  The terms a row does not have carry the coefficient +0.0 and leave the
+// partial sum unchanged, so the result equals the row's own in-order accumulation (the same argument as K2R's
+// padding; values are finite: `max_abs_value` / gamma < 1).  U gathers and 2 A U float operations instead of A x KMAX and
+// 2 A KMAX.  Chosen by run_sweeps when the batch's states have <= 8 distinct successors and U <= A KMAX / 2.
+// (Packed-FP32 arithmetic, two actions per v_pk_mul_f32 / v_pk_add_f32, was measured 3 % slower: the kernel is bound by
+// the latency of its gather -> sum -> reduce -> barrier chain at 4 workgroups per CU, not by VALU throughput.)
+template <int MODE, int A_T, int U_T, int KMAX, int SPT>
+__global__ void __launch_bounds__(256) k_dp_regu(DpTables t) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int b = blockIdx.x;
+  const int64_t soff = t.state_off[b];
+  const int S = (int)(t.state_off[b + 1] - soff);
+  const int64_t row0 = soff * A_T;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  constexpr int NW = 4;
+  constexpr int VB_OFF = SPT * 256 * 4;
+  constexpr int SENT = 0x7fffffff;
+  float* red = reinterpret_cast<float*>(smem + 2 * VB_OFF);  // [2][NW][2]
+
+  int32_t col4[SPT][U_T];
+  float W[SPT][A_T][U_T];
+  float Rr[SPT][A_T], Pi[SPT][A_T];
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {
+    const int s = tid + j * 256;
+    int32_t ucol[U_T];
+#pragma unroll
+    for (int u = 0; u < U_T; ++u) ucol[u] = SENT;
+    int32_t ecol[A_T][KMAX];
+    float ecf[A_T][KMAX];
+#pragma unroll
+    for (int a = 0; a < A_T; ++a) {
+      const int64_t r = row0 + (int64_t)s * A_T + a;
+      int64_t lo = 0, hi = 0;
+      if (s < S) { lo = t.csr_ptr[r]; hi = t.csr_ptr[r + 1]; }
+      Rr[j][a] = (s < S) ? t.R[r] : 0.0f;
+      Pi[j][a] = (MODE == DP_PE && s < S) ? t.pi[r] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        const bool in = lo + k < hi;
+        ecol[a][k] = in ? t.csr_col[lo + k] : SENT;
+        const float v = in ? t.csr_val[lo + k] : 0.0f;
+        ecf[a][k] = (MODE == DP_PE) ? __fmul_rn(t.gamma, v) : v;
+        // sorted insertion without duplicates: the larger of (carried, slot) moves on
+        int32_t c = ecol[a][k];
+#pragma unroll
+        for (int u = 0; u < U_T; ++u) {
+          const int32_t cur = ucol[u];
+          const bool dup = c == cur;
+          const bool less = c < cur;
+          ucol[u] = less ? c : cur;
+          c = dup ? SENT : (less ? cur : c);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U_T; ++u) {
+      col4[j][u] = ucol[u] == SENT ? 0 : 4 * ucol[u];
+#pragma unroll
+      for (int a = 0; a < A_T; ++a) {
+        float w = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) w = (ecol[a][k] == ucol[u] && ucol[u] != SENT) ? ecf[a][k] : w;
+        W[j][a][u] = w;
+      }
+    }
+  }
+  for (int i = tid; i < 2 * SPT * 256; i += 256) reinterpret_cast<float*>(smem)[i] = 0.0f;
+  __syncthreads();
+
+  const bool track_abs = t.max_abs > 0.0;
+  int64_t it = 0;
+  int status = -5;
+  auto backup_all = [&](auto rd_tag, int j, float (&q)[A_T]) {
+    constexpr int RD = decltype(rd_tag)::value;
+    float v[U_T];
+#pragma unroll
+    for (int u = 0; u < U_T; ++u) v[u] = *reinterpret_cast<const float*>(smem + RD + col4[j][u]);
+#pragma unroll
+    for (int a = 0; a < A_T; ++a) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int u = 0; u < U_T; ++u) acc = __fadd_rn(acc, __fmul_rn(W[j][a][u], v[u]));
+      q[a] = (MODE == DP_VI) ? __fadd_rn(Rr[j][a], __fmul_rn(t.gamma, acc)) : __fadd_rn(Rr[j][a], acc);
+    }
+  };
+  auto sweep = [&](auto rd_tag) -> int {
+    constexpr int RD = decltype(rd_tag)::value, WR = VB_OFF - RD;
+    ++it;
+    float dmax = 0.0f, vabs = 0.0f;
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+      const int s = tid + j * 256;
+      if (s < S) {
+        float q[A_T];
+        backup_all(rd_tag, j, q);
+        float v = 0.0f;
+#pragma unroll
+        for (int a = 0; a < A_T; ++a) {
+          if (MODE == DP_VI) {
+            v = (a == 0) ? q[a] : fmaxf(v, q[a]);
+          } else {
+            const float qp = __fmul_rn(q[a], Pi[j][a]);
+            v = (a == 0) ? qp : __fadd_rn(v, qp);
+          }
+        }
+        *reinterpret_cast<float*>(smem + WR + 4 * s) = v;
+        dmax = fmaxf(dmax, fabsf(*reinterpret_cast<const float*>(smem + RD + 4 * s) - v));
+        if (track_abs) vabs = fmaxf(vabs, fabsf(v));
+      }
+    }
+    dmax = wave_max_lane63(dmax);
+    if (track_abs) vabs = wave_max_lane63(vabs);
+    float* rbuf = red + (it & 1) * 2 * NW;
+    if (lane == 63) {
+      rbuf[wave] = dmax;
+      if (track_abs) rbuf[NW + wave] = vabs;
+    }
+    __syncthreads();
+    const float4 d4 = *reinterpret_cast<const float4*>(rbuf);
+    const float diff = fmaxf(fmaxf(d4.x, d4.y), fmaxf(d4.z, d4.w));
+    float vmax = 0.0f;
+    if (track_abs) {
+      const float4 a4 = *reinterpret_cast<const float4*>(rbuf + NW);
+      vmax = fmaxf(fmaxf(a4.x, a4.y), fmaxf(a4.z, a4.w));
+    }
+    if (track_abs && (double)vmax > t.max_abs) return 2;
+    if ((double)diff < t.eps) return 1;
+    return 0;
+  };
+  using Even = std::integral_constant<int, 0>;
+  using Odd = std::integral_constant<int, VB_OFF>;
+  int newest = 0;
+  while (it < t.max_sweeps) {
+    int rc = sweep(Even{});
+    newest = VB_OFF;
+    if (rc == 0 && it < t.max_sweeps) {
+      rc = sweep(Odd{});
+      newest = 0;
+    }
+    if (rc) { status = (rc == 1) ? 0 : -7; break; }
+  }
+  if (tid == 0) {
+    t.status[b] = status;
+    if (t.sweeps) t.sweeps[b] = it;
+  }
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {
+    const int s = tid + j * 256;
+    if (s < S) {
+      t.V[soff + s] = *reinterpret_cast<const float*>(smem + newest + 4 * s);
+      float q[A_T];
+      if (newest == VB_OFF) backup_all(Even{}, j, q); else backup_all(Odd{}, j, q);
+#pragma unroll
+      for (int a = 0; a < A_T; ++a) t.Q[row0 + (int64_t)s * A_T + a] = q[a];
+    }
+  }
+}
+
 // K3: Gauss-Seidel sweeps (numba paths of the reference), one wavefront per unit, V in LDS, states in
 // order.  Lane a < A backs up action a of the current state; later states see the updated V.
 template <int MODE, bool DIAM>

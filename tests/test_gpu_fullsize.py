@@ -56,14 +56,15 @@ def test_c3_full_size_4096_frozenlake20_vi(need_gpu):
     B = 4096
     fl = frozenlake_dp_tables(np.arange(B), 20, workers=min(16, os.cpu_count() or 1), context="spawn")
     dp = BatchedMDP(tables=fl, with_env=False)
-    dp.set_dp_kernel(L.DP_REGISTER)
+    dp.set_dp_kernel(L.DP_REGISTER_DISTINCT)   # K2U, what the automatic choice takes for this batch
     Q, V, sw = dp.value_iteration(0.99, 1e-6)
-    dp.set_dp_kernel(L.DP_WORKGROUP)
-    Q2, V2, sw2 = dp.value_iteration(0.99, 1e-6)
-    # (i) register-resident and LDS/HBM workgroup kernels: identical bits, identical sweep counts
-    np.testing.assert_array_equal(V, V2)
-    np.testing.assert_array_equal(Q, Q2)
-    np.testing.assert_array_equal(sw, sw2)
+    # (i) the distinct-successor, per-row register-resident and LDS/HBM workgroup kernels: identical bits and sweep counts
+    for which in (L.DP_REGISTER, L.DP_WORKGROUP, L.DP_AUTO):
+        dp.set_dp_kernel(which)
+        Q2, V2, sw2 = dp.value_iteration(0.99, 1e-6)
+        np.testing.assert_array_equal(V, V2)
+        np.testing.assert_array_equal(Q, Q2)
+        np.testing.assert_array_equal(sw, sw2)
     # (ii) fixed point: one more Bellman backup (numpy, float64) moves no value by more than the stopping threshold
     ptr, col, val, R = fl["csr_ptr"], fl["csr_col"], fl["csr_val"], fl["R"]
     row_state = np.repeat(np.arange(len(R)) // 4, np.diff(ptr))          # flat state of every non-zero's row

@@ -331,7 +331,8 @@ def test_vi_frozenlake20_vs_reference(need_gpu):
 
 
 def test_register_resident_sweeps_equal_workgroup_kernel_and_oracle(need_gpu):
-    """K2R (CSR in registers) vs K2 (CSR in LDS/HBM) vs the oracle on A = 2, 3, 4, ragged batches, VI and PE."""
+    """K2R (CSR in registers), K2U (its distinct-successor form) vs K2 (CSR in LDS/HBM) vs the oracle on A = 2, 3, 4,
+    ragged batches, VI and PE."""
     batches = [
         [make_model("DeepSeaContinuous", seed=s, size=sz, p_rand=0.2) for s, sz in ((0, 9), (1, 14), (2, 23))],
         [make_model("MiniGridEmptyContinuous", seed=s, size=sz, p_rand=0.1, p_lazy=0.05) for s, sz in ((0, 4), (1, 7), (2, 9))],
@@ -342,13 +343,21 @@ def test_register_resident_sweeps_equal_workgroup_kernel_and_oracle(need_gpu):
         A = models[0].n_actions
         dp = BatchedMDP(models, with_env=False)
         outs = {}
-        for which in (L.DP_WORKGROUP, L.DP_REGISTER):
+        n_distinct = 0
+        for which in (L.DP_WORKGROUP, L.DP_REGISTER, L.DP_REGISTER_DISTINCT):
             dp.set_dp_kernel(which)
             pis = [np.random.RandomState(5 + i).dirichlet(np.ones(A), m.n_states).astype(np.float32) for i, m in enumerate(models)]
-            outs[which] = (dp.value_iteration(0.99, 1e-5, L.SCHEME_JACOBI), dp.policy_evaluation(pis, 0.95, 1e-6, L.SCHEME_JACOBI))
-        for x, y in zip(outs[L.DP_WORKGROUP], outs[L.DP_REGISTER]):
-            for u, v in zip(x, y):
-                np.testing.assert_array_equal(u, v)
+            try:
+                outs[which] = (dp.value_iteration(0.99, 1e-5, L.SCHEME_JACOBI), dp.policy_evaluation(pis, 0.95, 1e-6, L.SCHEME_JACOBI))
+            except L.CmdpError as e:  # K2U exists for <= 8 distinct successors per state; it must say so otherwise
+                assert which == L.DP_REGISTER_DISTINCT and e.code == L.ERR_UNSUPPORTED
+                continue
+            n_distinct += which == L.DP_REGISTER_DISTINCT
+        for which in outs:
+            for x, y in zip(outs[L.DP_WORKGROUP], outs[which]):
+                for u, v in zip(x, y):
+                    np.testing.assert_array_equal(u, v)
+        n_k2u = locals().get("n_k2u", 0) + n_distinct
         (Q, V, sw), (Qp, Vp, swp) = outs[L.DP_REGISTER]
         for i, m in enumerate(models):
             oQ, oV, oit, _ = O.vi_discounted(m.n_states, A, m.csr(), m.reward_matrix(), 0.99, 1e-5, 1)
@@ -359,6 +368,7 @@ def test_register_resident_sweeps_equal_workgroup_kernel_and_oracle(need_gpu):
             np.testing.assert_array_equal(dp.split_states(Vp)[i], oV)
             assert swp[i] == oit
         dp.close()
+    assert n_k2u >= 2  # the distinct-successor kernel really ran for some of the batches
 
 
 def test_episodic_dp_vs_reference(need_gpu):
