@@ -1461,8 +1461,13 @@ __global__ void __launch_bounds__(256) k_dp_reg(DpTables t) {
 // 2 A KMAX.  Chosen by run_sweeps when the batch's states have <= 8 distinct successors and U <= A KMAX / 2.
 // (Packed-FP32 arithmetic, two actions per v_pk_mul_f32 / v_pk_add_f32, was measured 3 % slower: the kernel is bound by
 // the latency of its gather -> sum -> reduce -> barrier chain at 4 workgroups per CU, not by VALU throughput.)
+// Occupancy: the sweep is a latency chain (gather -> sums -> wave reduce -> barrier), so one more workgroup per CU pays
+// for a few spilled registers: measured at C3 (A=4, U=5, SPT=2: 103 VGPRs unconstrained) 4 / 5 / 6 waves per SIMD =
+// 2.93 / 2.65 / 2.75 ms.  The cap follows the registers the resident tables need.
+#define K2U_WAVES(A, U, SPT) (((SPT) * ((A) * (U) + (U) + (A)) + 30) <= 96 ? 5 : (((SPT) * ((A) * (U) + (U) + (A)) + 30) <= 128 ? 4 : 3))
 template <int MODE, int A_T, int U_T, int KMAX, int SPT>
-__global__ void __launch_bounds__(256) k_dp_regu(DpTables t) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K2U_WAVES(A_T, U_T, SPT), K2U_WAVES(A_T, U_T, SPT))))
+k_dp_regu(DpTables t) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int b = blockIdx.x;
   const int64_t soff = t.state_off[b];
