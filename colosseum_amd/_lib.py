@@ -132,3 +132,30 @@ def ptr(a):
 
 def carr(a, dtype):
     return None if a is None else np.ascontiguousarray(a, dtype)
+
+
+_hip = None
+
+
+def pinned_empty(n, dtype):
+    """A page-locked host array (hipHostMalloc) for results that are fetched repeatedly: device-to-host copies into it
+    run as one DMA at PCIe rate and touch no fresh pages (a new `np.zeros` costs a page fault per 4 KiB inside the copy).
+    Freed when the array is garbage collected."""
+    import weakref
+
+    global _hip
+    load()  # libcmdp.so has mapped the HIP runtime
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+        _hip.hipHostFree.argtypes = [C.c_void_p]
+    dt = np.dtype(dtype)
+    nbytes = max(1, int(n)) * dt.itemsize
+    p = C.c_void_p()
+    rc = _hip.hipHostMalloc(C.byref(p), nbytes, 0)
+    if rc != 0 or not p.value:
+        raise MemoryError(f"hipHostMalloc({nbytes}) failed with {rc}")
+    buf = (C.c_char * nbytes).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dt, count=int(n))
+    weakref.finalize(buf, _hip.hipHostFree, C.c_void_p(p.value))
+    return arr

@@ -271,11 +271,22 @@ class BatchedMDP:
         return L.carr(np.concatenate([np.asarray(x, np.float32).ravel() for x in per_instance]), np.float32)
 
     # -- dynamic programming ----------------------------------------------------------------------------------
+    def dp_buffers(self, pinned=True):
+        """(Q, V, sweeps) result buffers to pass as `out=` to value_iteration / policy_evaluation when they are called
+        repeatedly: page-locked by default (one DMA per array, no page faults inside the copy)."""
+        mk = L.pinned_empty if pinned else np.empty
+        return (mk(int(self.row_off[-1]), np.float32), mk(int(self.state_off[-1]), np.float32), mk(self.B, np.int64))
+
     def value_iteration(self, gamma=0.99, epsilon=1e-3, scheme=L.SCHEME_AUTO, max_sweeps=1_000_000,
-                        max_abs_value=None, R=None):
-        Q = np.zeros(int(self.row_off[-1]), np.float32)
-        V = np.zeros(int(self.state_off[-1]), np.float32)
-        sw = np.zeros(self.B, np.int64)
+                        max_abs_value=None, R=None, out=None):
+        if out is not None:
+            Q, V, sw = out
+            assert Q.dtype == np.float32 and V.dtype == np.float32 and sw.dtype == np.int64
+            assert len(Q) == int(self.row_off[-1]) and len(V) == int(self.state_off[-1]) and len(sw) == self.B
+        else:
+            Q = np.zeros(int(self.row_off[-1]), np.float32)
+            V = np.zeros(int(self.state_off[-1]), np.float32)
+            sw = np.zeros(self.B, np.int64)
         Rov = self._flat_rows(R)
         L.check(self._lib.cmdp_vi_discounted(self._h, gamma, epsilon, scheme, max_sweeps,
                                              0.0 if max_abs_value is None else float(max_abs_value), L.ptr(Rov),

@@ -108,6 +108,37 @@ __device__ __forceinline__ float wave_max_lane63(float v) {
 #undef CMDP_DPP_MAX
   return __int_as_float(x);
 }
+// The same reduction with the DPP modifier on the max itself (one VALU instruction per step plus the two wait states a
+// DPP read of a just-written VGPR needs) and no NaN canonicalisation: for values that are never NaN.
+__device__ __forceinline__ float wave_max_lane63_nn(float v) {
+#define CMDP_DPP_MAX_NN(ctrl) \
+  asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(v))
+  CMDP_DPP_MAX_NN("quad_perm:[1,0,3,2]");
+  CMDP_DPP_MAX_NN("quad_perm:[2,3,0,1]");
+  CMDP_DPP_MAX_NN("row_ror:4");
+  CMDP_DPP_MAX_NN("row_ror:8");
+  CMDP_DPP_MAX_NN("row_bcast:15");
+  CMDP_DPP_MAX_NN("row_bcast:31");
+#undef CMDP_DPP_MAX_NN
+  return v;
+}
+// max / max3 / max(a, |b|) of values that are never NaN: the bare instructions (fmaxf adds a canonicalising
+// v_max_f32 x, x per operand that may be a signalling NaN)
+__device__ __forceinline__ float fmax_nn(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float fmax3_nn(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float fmax_abs_nn(float a, float b) {  // max(a, |b|)
+  float r;
+  asm("v_max_f32 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));

@@ -1479,7 +1479,12 @@ k_dp_regu(DpTables t) {
   constexpr int SENT = 0x7fffffff;
   float* red = reinterpret_cast<float*>(smem + 2 * VB_OFF);  // [2][NW][2]
 
-  int32_t col4[SPT][U_T];
+  // LDS pointers (address space 3) of the distinct successors' values in vector A; the other vector is VB_OFF bytes on,
+  // which folds into the instruction's offset field
+  typedef const __attribute__((address_space(3))) float* lds_cf;
+  typedef __attribute__((address_space(3))) float* lds_f;
+  const lds_f vbase = (lds_f)(__attribute__((address_space(3))) unsigned char*)smem;
+  lds_cf vp[SPT][U_T];
   float W[SPT][A_T][U_T];
   float Rr[SPT][A_T], Pi[SPT][A_T];
 #pragma unroll
@@ -1517,7 +1522,7 @@ k_dp_regu(DpTables t) {
     }
 #pragma unroll
     for (int u = 0; u < U_T; ++u) {
-      col4[j][u] = ucol[u] == SENT ? 0 : 4 * ucol[u];
+      vp[j][u] = vbase + (ucol[u] == SENT ? 0 : ucol[u]);
 #pragma unroll
       for (int a = 0; a < A_T; ++a) {
         float w = 0.0f;
@@ -1537,7 +1542,7 @@ k_dp_regu(DpTables t) {
     constexpr int RD = decltype(rd_tag)::value;
     float v[U_T];
 #pragma unroll
-    for (int u = 0; u < U_T; ++u) v[u] = *reinterpret_cast<const float*>(smem + RD + col4[j][u]);
+    for (int u = 0; u < U_T; ++u) v[u] = vp[j][u][RD / 4];
 #pragma unroll
     for (int a = 0; a < A_T; ++a) {
       float acc = 0.0f;
@@ -1557,22 +1562,25 @@ k_dp_regu(DpTables t) {
         float q[A_T];
         backup_all(rd_tag, j, q);
         float v = 0.0f;
+        if (MODE == DP_VI) {  // values are never NaN: bare max instructions
+          if constexpr (A_T == 2) v = fmax_nn(q[0], q[1]);
+          else if constexpr (A_T == 3) v = fmax3_nn(q[0], q[1], q[2]);
+          else v = fmax_nn(fmax3_nn(q[0], q[1], q[2]), q[A_T - 1]);
+        } else {
 #pragma unroll
-        for (int a = 0; a < A_T; ++a) {
-          if (MODE == DP_VI) {
-            v = (a == 0) ? q[a] : fmaxf(v, q[a]);
-          } else {
+          for (int a = 0; a < A_T; ++a) {
             const float qp = __fmul_rn(q[a], Pi[j][a]);
             v = (a == 0) ? qp : __fadd_rn(v, qp);
           }
         }
-        *reinterpret_cast<float*>(smem + WR + 4 * s) = v;
-        dmax = fmaxf(dmax, fabsf(*reinterpret_cast<const float*>(smem + RD + 4 * s) - v));
-        if (track_abs) vabs = fmaxf(vabs, fabsf(v));
+        const float vold = vbase[RD / 4 + s];
+        vbase[WR / 4 + s] = v;
+        dmax = fmax_abs_nn(dmax, vold - v);
+        if (track_abs) vabs = fmax_abs_nn(vabs, v);
       }
     }
-    dmax = wave_max_lane63(dmax);
-    if (track_abs) vabs = wave_max_lane63(vabs);
+    dmax = wave_max_lane63_nn(dmax);
+    if (track_abs) vabs = wave_max_lane63_nn(vabs);
     float* rbuf = red + (it & 1) * 2 * NW;
     if (lane == 63) {
       rbuf[wave] = dmax;
@@ -1580,11 +1588,11 @@ k_dp_regu(DpTables t) {
     }
     __syncthreads();
     const float4 d4 = *reinterpret_cast<const float4*>(rbuf);
-    const float diff = fmaxf(fmaxf(d4.x, d4.y), fmaxf(d4.z, d4.w));
+    const float diff = fmax_nn(fmax3_nn(d4.x, d4.y, d4.z), d4.w);
     float vmax = 0.0f;
     if (track_abs) {
       const float4 a4 = *reinterpret_cast<const float4*>(rbuf + NW);
-      vmax = fmaxf(fmaxf(a4.x, a4.y), fmaxf(a4.z, a4.w));
+      vmax = fmax_nn(fmax3_nn(a4.x, a4.y, a4.z), a4.w);
     }
     if (track_abs && (double)vmax > t.max_abs) return 2;
     if ((double)diff < t.eps) return 1;
@@ -1610,7 +1618,7 @@ k_dp_regu(DpTables t) {
   for (int j = 0; j < SPT; ++j) {
     const int s = tid + j * 256;
     if (s < S) {
-      t.V[soff + s] = *reinterpret_cast<const float*>(smem + newest + 4 * s);
+      t.V[soff + s] = vbase[newest / 4 + s];
       float q[A_T];
       if (newest == VB_OFF) backup_all(Even{}, j, q); else backup_all(Odd{}, j, q);
 #pragma unroll

@@ -733,3 +733,20 @@ def test_custom_mdp_trajectories_on_device(need_gpu):
         np.testing.assert_array_equal(vs, z[k + "visits_s"])
         np.testing.assert_array_equal(vsa.reshape(-1, env.A), z[k + "visits_sa"])
         env.close()
+
+
+def test_value_iteration_into_pinned_buffers(need_gpu):
+    """`out=` with page-locked result buffers (BatchedMDP.dp_buffers): same bits as the freshly allocated arrays, and the
+    buffers are reusable."""
+    models = [make_model("FrozenLakeContinuous", seed=s, size=8, p_frozen=0.9, p_rand=0.1) for s in range(5)]
+    dp = BatchedMDP(models, with_env=False)
+    Q0, V0, sw0 = dp.value_iteration(0.95, 1e-5)
+    bufs = dp.dp_buffers()
+    for _ in range(2):
+        Q, V, sw = dp.value_iteration(0.95, 1e-5, out=bufs)
+        assert Q is bufs[0] and V is bufs[1] and sw is bufs[2]
+        np.testing.assert_array_equal(Q, Q0)
+        np.testing.assert_array_equal(V, V0)
+        np.testing.assert_array_equal(sw, sw0)
+        Q[:] = -1.0
+    dp.close()
