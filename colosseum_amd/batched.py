@@ -293,10 +293,16 @@ class BatchedMDP:
                                              L.ptr(Q), L.ptr(V), L.ptr(sw)))
         return Q, V, sw
 
-    def policy_evaluation(self, pi, gamma=0.99, epsilon=1e-7, scheme=L.SCHEME_AUTO, max_sweeps=1_000_000, R=None):
-        Q = np.zeros(int(self.row_off[-1]), np.float32)
-        V = np.zeros(int(self.state_off[-1]), np.float32)
-        sw = np.zeros(self.B, np.int64)
+    def policy_evaluation(self, pi, gamma=0.99, epsilon=1e-7, scheme=L.SCHEME_AUTO, max_sweeps=1_000_000, R=None,
+                          out=None):
+        if out is not None:
+            Q, V, sw = out
+            assert Q.dtype == np.float32 and V.dtype == np.float32 and sw.dtype == np.int64
+            assert len(Q) == int(self.row_off[-1]) and len(V) == int(self.state_off[-1]) and len(sw) == self.B
+        else:
+            Q = np.zeros(int(self.row_off[-1]), np.float32)
+            V = np.zeros(int(self.state_off[-1]), np.float32)
+            sw = np.zeros(self.B, np.int64)
         p = self._flat_rows(pi)
         Rov = self._flat_rows(R)
         L.check(self._lib.cmdp_pe_discounted(self._h, L.ptr(p), gamma, epsilon, scheme, max_sweeps, L.ptr(Rov),
