@@ -711,11 +711,16 @@ __global__ void __launch_bounds__(K1P_THREADS) k_rollout_pipe(EnvTables t, LdsPl
     const unsigned char* acts = ring + ((size_t)cb * p.G + lane) * AS;
     uint16_t* tr = reinterpret_cast<uint16_t*>(trace + ((size_t)cb * p.G + lane) * TS);
     int hs = uniform_h ? __builtin_amdgcn_readfirstlane(h) : 0, nres_s = 0;
+    int pend = 0;
     // flavours as in K1L: T0 no episode logic, T1 scalar episode test, T2 per-lane
     auto step = [&](int s, int a, auto mode_tag) {
       constexpr int MODE = decltype(mode_tag)::value;
       const int word = *reinterpret_cast<const uint16_t*>(base + cur + 2 * a);  // the one load on the dependency chain
-      tr[s] = (uint16_t)(word + 2 * a);  // arrival row under the action taken (base.py:1302-1303) | reward code
+      // The trace entry of the PREVIOUS transition is stored now, behind this transition's read in the LDS queue:
+      // stored in its own transition it sits in front of the next read, on the dependency chain.  (The slot before a
+      // chunk's first entry is the padding of the neighbouring ring row.)
+      tr[s - 1] = (uint16_t)pend;
+      pend = word + 2 * a;  // arrival row under the action taken (base.py:1302-1303) | reward code
       const int nxt = word & smask;
       if (MODE == 0) {
         cur = nxt;
@@ -769,6 +774,7 @@ __global__ void __launch_bounds__(K1P_THREADS) k_rollout_pipe(EnvTables t, LdsPl
       const int a = acts[s0];
       if (uniform_h) step(s0, a, T1{}); else step(s0, a, T2{});
     }
+    tr[len - 1] = (uint16_t)pend;
     if (uniform_h) { h = hs; n_resets += nres_s; }
   };
   // counts (wave 1): the chunk the chain traced into buffer `tb`
