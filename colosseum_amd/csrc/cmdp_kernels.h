@@ -616,13 +616,14 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
 // K1L's walker is bound by the instructions one wavefront issues per transition (~17; a lone wavefront issues one
 // every 4-8 cycles), not by the dependent LDS read.  Here a transition's work is split over the wavefronts of the
 // workgroup, one chunk of p.ch transitions apart:
-//   wave 0    CHAIN     action byte -> successor word (the dependent LDS read) -> trace entry `word + 2 action`
-//                       (= byte offset of the arrival row under the action taken | reward code << code_shift),
-//                       episode bookkeeping
-//   wave 1    COUNTS    8-bit visit counters of the traced rows (+ overflow list), one chunk behind the chain
-//   wave 2    REWARDS   adds the traced reward codes' values in transition order (bit-equal to the sequential sum)
-//   waves 3-5 PRODUCERS Philox action bytes of the chunk after the chain's (lane i: instance i; the blocks of a window
-//                       are dealt round-robin to the three waves)
+//   wave 0        CHAIN     action byte -> successor word (the dependent LDS read) -> trace entry `word + 2 action`
+//                           (= byte offset of the arrival row under the action taken | reward code << code_shift),
+//                           stored one transition late so that it queues behind the next read; episode bookkeeping
+//   wave 1        COUNTS    8-bit visit counters of the traced rows (+ overflow list), one chunk behind the chain
+//   wave 4        REWARDS   adds the traced reward codes' values in transition order (bit-equal to the sequential sum)
+//   waves 2,3,6,7 PRODUCERS Philox action bytes of the chunk after the chain's (lane i: instance i; the blocks of a
+//                           window are dealt round-robin to the four waves)
+//   wave 5        idle (waves w and w + 4 share a SIMD: the chain and the counters keep theirs almost to themselves)
 // Lane i of every wave owns instance i of the group.  Rings (actions, trace) are double-buffered; one barrier per chunk.
 // The successor field of the table word is the successor's row base as a BYTE offset (2 A s'), so the chain's
 // address is one add3.  LDS per instance: slot_bytes + 2 (p.ch + 4) + 2 (2 p.ch + 4); the odd strides keep the
