@@ -903,7 +903,7 @@ int run_sweeps(cmdp_t* h, int mode, bool diam, int scheme, DpTables t, int64_t u
     const dim3 grid((unsigned)units), block(256);
     // K2U when the states' rows share their successors: U gathers instead of A x K (dp_kernel 5 forces it, 2 forbids it)
     const int U = h->max_state_unique == 0 ? 0 : (h->max_state_unique <= 5 ? 5 : (h->max_state_unique <= 8 ? 8 : 0));
-    const bool want_u = U > 0 && K > 0 && spt > 0 && spt * U <= 16 && h->dp_kernel != 2 &&
+    const bool want_u = U > 0 && K > 0 && spt > 0 && spt * U <= 20 && h->dp_kernel != 2 &&
                         (h->dp_kernel == 5 || 2 * U <= A * K);
     if (h->dp_kernel == 5 && !want_u)
       return fail(CMDP_ERR_UNSUPPORTED, "no distinct-successor instantiation (A=%d, %d distinct successors per state, %d states)",
@@ -918,6 +918,7 @@ int run_sweeps(cmdp_t* h, int mode, bool diam, int scheme, DpTables t, int64_t u
       REGU_CASE(2, 5, 4, 1) REGU_CASE(2, 5, 4, 2) REGU_CASE(2, 5, 8, 1) REGU_CASE(2, 5, 8, 2)
       REGU_CASE(3, 5, 4, 1) REGU_CASE(3, 5, 4, 2) REGU_CASE(3, 5, 8, 1) REGU_CASE(3, 5, 8, 2)
       REGU_CASE(4, 5, 4, 1) REGU_CASE(4, 5, 4, 2) REGU_CASE(4, 5, 8, 1) REGU_CASE(4, 5, 8, 2)
+      REGU_CASE(2, 5, 4, 4) REGU_CASE(3, 5, 4, 4) REGU_CASE(4, 5, 4, 4) REGU_CASE(4, 5, 8, 4)
       REGU_CASE(3, 8, 8, 1) REGU_CASE(3, 8, 8, 2) REGU_CASE(4, 8, 4, 1) REGU_CASE(4, 8, 4, 2)
       REGU_CASE(4, 8, 8, 1) REGU_CASE(4, 8, 8, 2)
       { done = false; }
