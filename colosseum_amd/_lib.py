@@ -20,13 +20,15 @@ OPT_DP_KERNEL = 2
 OPT_LDS_GROUPS_PER_CU = 3
 OPT_DIAMETER_WORKSPACE_MB = 4
 OPT_CHAIN_EXACT_ORDER = 5
+STAT_DP_KERNEL_MS, STAT_DP_KERNEL = 1, 2
+CALIB_LDS_READ, CALIB_LDS_CHAIN = 0, 1
 DP_AUTO, DP_WORKGROUP, DP_REGISTER = 0, 1, 2
 DP_REGISTER_DISTINCT = 5  # K2U: register-resident, gathers deduplicated per state
 ROLLOUT_AUTO, ROLLOUT_GLOBAL, ROLLOUT_LDS = 0, 1, 2
 
 EXPORTS = [
-    "cmdp_version", "cmdp_last_error", "cmdp_device_count", "cmdp_set_device", "cmdp_create", "cmdp_destroy",
-    "cmdp_stream", "cmdp_reset", "cmdp_step", "cmdp_rollout", "cmdp_rollout_async", "cmdp_synchronize", "cmdp_set_option", "cmdp_lds_plan",
+    "cmdp_version", "cmdp_build_id", "cmdp_last_error", "cmdp_device_count", "cmdp_set_device", "cmdp_create", "cmdp_destroy",
+    "cmdp_stream", "cmdp_reset", "cmdp_step", "cmdp_rollout", "cmdp_rollout_async", "cmdp_synchronize", "cmdp_stat", "cmdp_calibrate", "cmdp_set_option", "cmdp_lds_plan",
     "cmdp_visits", "cmdp_reset_visits", "cmdp_state", "cmdp_last_start", "cmdp_vi_discounted", "cmdp_pe_discounted",
     "cmdp_vi_episodic", "cmdp_pe_episodic", "cmdp_diameter", "cmdp_diameter_episodic", "cmdp_value_norm", "cmdp_gth", "cmdp_qlearning_create", "cmdp_qlearning_destroy", "cmdp_qlearning_run",
     "cmdp_qlearning_tables", "cmdp_qlearning_evaluate", "cmdp_greedy_policy_episodic", "cmdp_qlearning_continuous_create",
@@ -60,6 +62,36 @@ class DynamicProgrammingMaxIterationExceeded(Exception):
 _lib = None
 
 
+def source_files():
+    """The files libcmdp.so is compiled from, in the order their hash is taken."""
+    csrc = os.path.join(HERE, "csrc")
+    files = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h"))]
+    files.append(os.path.join(os.path.dirname(HERE), "include", "cmdp.h"))
+    return files
+
+
+def source_hash():
+    """SHA-256 over the library's sources: what `cmdp_build_id()` of an up-to-date build returns."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in source_files():
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def built_id(path=LIB_PATH):
+    """The build id stamped into the library file at `path`, read from the file's bytes (no dlopen: a process that
+    rebuilds the library must not have the old image mapped under the same name); None if missing or unstamped."""
+    import re
+
+    if not os.path.exists(path):
+        return None
+    m = re.search(rb"CMDP_BUILD_ID=([0-9a-f]{64})", open(path, "rb").read())
+    return m.group(1).decode() if m else None
+
+
 def load():
     """Returns the loaded library; raises if it has not been built (python __graft_entry__.py / build())."""
     global _lib
@@ -69,6 +101,12 @@ def load():
                 f"{LIB_PATH} is missing: build the HIP extension first "
                 f"(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
         L = C.CDLL(LIB_PATH)
+        L.cmdp_build_id.restype = C.c_char_p
+        bid, want = L.cmdp_build_id().decode(), source_hash()
+        if bid != want and os.environ.get("CMDP_ALLOW_STALE_LIB") != "1":
+            raise ImportError(
+                f"{LIB_PATH} was built from other sources (build id {bid[:16]}, tree {want[:16]}): rebuild it "
+                f"(python -c 'import __graft_entry__ as g; g.build()').")
         vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
         L.cmdp_version.restype = C.c_int
         L.cmdp_last_error.restype = C.c_char_p
@@ -83,6 +121,8 @@ def load():
         L.cmdp_rollout.argtypes = [vp, i32, vp, i64, vp, vp, vp, vp, vp]
         L.cmdp_rollout_async.argtypes = [vp, i32, i64]
         L.cmdp_synchronize.argtypes = [vp]
+        L.cmdp_stat.argtypes = [vp, i32, vp]
+        L.cmdp_calibrate.argtypes = [i32, i64, vp]
         L.cmdp_set_option.argtypes = [vp, i32, i64]
         L.cmdp_lds_plan.argtypes = [vp, vp]
         L.cmdp_visits.argtypes = [vp, vp, vp]

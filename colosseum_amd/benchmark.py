@@ -110,6 +110,14 @@ def _build_models(instances: Sequence[Instance], workers: int):
     return [_build_one(i) for i in instances]
 
 
+def build_shard_models(instances: Sequence[Instance], rank: int = 0, world: int = 1, workers: int = 0) -> Dict[int, Any]:
+    """{global instance index: TabularModel} of this rank's contiguous shard (fork()ed pool: call it before anything
+    initialises the HIP runtime or RCCL in this process)."""
+    lo, hi = shard_range(len(instances), rank, world)
+    mine = list(range(lo, hi))
+    return dict(zip(mine, _build_models([instances[i] for i in mine], workers)))
+
+
 def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_mode, device):
     L.check(L.load().cmdp_set_device(device))
     stochastic = any(not m.deterministic_rewards for m in models)
@@ -131,13 +139,15 @@ def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_m
 def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, rank: int = 0, world: int = 1,
                   agent_configs: Optional[Dict[str, Dict[str, Any]]] = None, rng_mode: int = L.RNG_MT_COMPAT,
                   device: int = 0, max_concurrent_groups: int = 6, build_workers: int = 0, progress=None,
-                  max_batch: int = 128):
-    """Runs this rank's contiguous shard; returns {global instance index: logger rows}."""
+                  max_batch: int = 128, models: Optional[Dict[int, Any]] = None):
+    """Runs this rank's contiguous shard; returns {global instance index: logger rows}.  `models` = the shard's
+    models from `build_shard_models` (a caller that must initialise RCCL between the fork()ed build and the first HIP
+    call builds them itself)."""
     agent_configs = agent_configs or DEFAULT_AGENT_CONFIGS
     lo, hi = shard_range(len(instances), rank, world)
     mine = list(range(lo, hi))
-    models = _build_models([instances[i] for i in mine], build_workers)
-    models = dict(zip(mine, models))
+    if models is None:
+        models = build_shard_models(instances, rank, world, build_workers)
     groups: Dict[tuple, List[int]] = {}
     from .hardness import _vi_rule
 

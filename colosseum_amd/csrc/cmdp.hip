@@ -92,6 +92,9 @@ struct cmdp {
   int64_t max_inst_nnz = 0;
   int max_row_nnz = 0;
   int max_state_unique = 0;  // distinct successor columns of a state over its A rows (0: not computed / rows unsorted)
+  bool known_reset = false;  // every instance is known to be past reset() (cmdp_rollout_async checks once, cmdp_step clears)
+  hipEvent_t ev_dp0 = nullptr, ev_dp1 = nullptr;  // around the sweep kernel of the last discounted solve (cmdp_stat)
+  int last_dp_kernel = 0;     // CMDP_STAT_DP_KERNEL: 1 K2, 2 K2R, 5 K2U, 6 K3 (Gauss-Seidel)
   int dp_kernel = 0;  // 0 auto, 1 LDS/global-CSR workgroup kernel, 2 register-resident kernel K2R, 5 its distinct-successor form K2U (3, 4: diameter only)
 
   DevBuf<int64_t> d_state_off, d_entry_base, d_start_off, d_csr_ptr;
@@ -112,7 +115,8 @@ struct cmdp {
   DevBuf<uint8_t> d_tr_type, d_mask;
   // LDS-resident rollout (K1L)
   bool lds_ok = false;
-  int lds_G1 = 0, lds_G2 = 0;  // instances per workgroup at one / two workgroups per CU
+  int lds_G1 = 0, lds_G2 = 0;  // LDS capacity in instances per workgroup at one / two workgroups per CU
+  int cus = 256;
   int rollout_kernel = 0;  // CMDP_OPT_ROLLOUT_KERNEL
   LdsPlan lds_plan{};
   size_t lds_bytes = 0;
@@ -184,6 +188,11 @@ int set_lds(K kernel, size_t bytes) {
 extern "C" {
 
 int cmdp_version(void) { return CMDP_ABI_VERSION; }
+#ifndef CMDP_BUILD_ID
+#define CMDP_BUILD_ID "unstamped"
+#endif
+static const char k_build_id[] = "CMDP_BUILD_ID=" CMDP_BUILD_ID;  /* the tag lets build() read the stamp from the file */
+const char* cmdp_build_id(void) { return k_build_id + 14; }
 
 const char* cmdp_last_error(void) { return g_err.c_str(); }
 
@@ -201,6 +210,10 @@ int cmdp_set_device(int device) {
 void* cmdp_stream(cmdp_t* h) { return h ? (void*)h->stream : nullptr; }
 
 int cmdp_destroy(cmdp_t* h) {
+  if (h && h->ev_dp0) {
+    (void)hipEventDestroy(h->ev_dp0);
+    (void)hipEventDestroy(h->ev_dp1);
+  }
   if (!h) return CMDP_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) {
@@ -420,6 +433,7 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
         if (cus < 1) cus = 256;
+        h->cus = cus;
         double best_cost = -1.0;
         int best_cap = 0;  // LDS capacity (instances per workgroup) of the chosen candidate
         p.ch = 256;
@@ -591,6 +605,7 @@ int cmdp_reset(cmdp_t* h, const uint8_t* mask, int32_t* obs_out) {
   HIP_TRY(hipGetLastError());
   if (obs_out) HIP_TRY(hipMemcpyAsync(obs_out, h->d_last_obs.p, sizeof(int32_t) * h->B, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  if (!mask) h->known_reset = true;
   return CMDP_OK;
 }
 
@@ -630,6 +645,7 @@ int cmdp_step(cmdp_t* h, const int32_t* actions, int auto_reset, int32_t* obs, d
   HIP_TRY(hipStreamSynchronize(st));
   if (f & 2) return fail(CMDP_ERR_INVALID, "action out of range [0, %d)", h->A);
   if (f & 1) return fail(CMDP_ERR_NEEDS_RESET, "step() on an instance that needs reset()");
+  h->known_reset = false;  // a step may end an episode (LAST): the async rollout re-checks before its next launch
   hipLaunchKernelGGL(k_step, dim3(grid_for(B, 256)), dim3(256), 0, st, h->env(), d_act, auto_reset, d_obs,
                      h->d_f64_scratch.p, h->d_u8_scratch.p);
   HIP_TRY(hipGetLastError());
@@ -718,6 +734,7 @@ int cmdp_rollout(cmdp_t* h, int policy, const void* policy_arg, int64_t n_steps,
   bool any = false;
   if (int rc = any_needs_reset(h, &any)) return rc;
   if (any) return fail(CMDP_ERR_NEEDS_RESET, "rollout() on an instance that needs reset()");
+  h->known_reset = true;  // the fused loop resets at once after every terminating step
   hipStream_t st = h->stream;
   const int B = h->B;
   const size_t NB = (size_t)n_steps * B;
@@ -756,6 +773,12 @@ int cmdp_rollout_async(cmdp_t* h, int policy, int64_t n_steps) {
   if (!h->has_env) return fail(CMDP_ERR_INVALID, "handle was created without the sampler half");
   if (policy != CMDP_POLICY_RANDOM) return fail(CMDP_ERR_INVALID, "rollout_async supports CMDP_POLICY_RANDOM only");
   if (n_steps < 0) return fail(CMDP_ERR_INVALID, "n_steps < 0");
+  if (!h->known_reset) {  // one 4-byte read-back on the first call after create / cmdp_step, none afterwards
+    bool any = false;
+    if (int rc = any_needs_reset(h, &any)) return rc;
+    if (any) return fail(CMDP_ERR_NEEDS_RESET, "rollout_async() on an instance that needs reset()");
+    h->known_reset = true;
+  }
   if (h->d_rsum.n < (size_t)h->B) HIP_TRY(h->d_rsum.alloc(h->B));
   if (h->d_last_obs.n < (size_t)h->B) HIP_TRY(h->d_last_obs.alloc(h->B));
   return launch_rollout(h, policy, nullptr, n_steps, h->d_rsum.p, h->d_last_obs.p, nullptr, nullptr, nullptr);
@@ -767,9 +790,16 @@ int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
     h->rollout_kernel = (int)value;
     return CMDP_OK;
   }
-  if (option == CMDP_OPT_LDS_GROUPS_PER_CU && (value == 1 || value == 2) && h->lds_ok) {
-    const int g = value == 1 ? h->lds_G1 : h->lds_G2;
-    if (g < 1) return fail(CMDP_ERR_INVALID, "no room for %lld workgroups per CU", (long long)value);
+  if (option == CMDP_OPT_LDS_GROUPS_PER_CU && (value == 1 || value == 2)) {
+    if (!h->lds_ok) return fail(CMDP_ERR_INVALID, "the batch is not eligible for the LDS-resident rollout kernels");
+    if (h->lds_plan.pipe)
+      return fail(CMDP_ERR_UNSUPPORTED, "this handle runs the pipeline kernel K1P, one workgroup per CU by construction "
+                  "(its successor table is encoded for K1P at cmdp_create: set CMDP_K1L_PIPE=0 before creating the handle to use K1L)");
+    const int cap = value == 1 ? h->lds_G1 : h->lds_G2;
+    if (cap < 1) return fail(CMDP_ERR_INVALID, "no room for %lld workgroups per CU", (long long)value);
+    // the fewest instances per workgroup that keep the round count at this many groups per CU (as cmdp_create does)
+    const int64_t slots = (int64_t)h->cus * value, wgs = (h->B + cap - 1) / cap, rounds = (wgs + slots - 1) / slots;
+    const int g = (int)std::min<int64_t>(cap, std::max<int64_t>(1, (h->B + rounds * slots - 1) / (rounds * slots)));
     h->lds_plan.G = g;
     h->lds_bytes = k1l_lds_bytes(h->lds_plan, g);
     return CMDP_OK;
@@ -801,6 +831,53 @@ int cmdp_lds_plan(cmdp_t* h, int32_t plan[4]) {
 int cmdp_synchronize(cmdp_t* h) {
   if (int rc = bind(h)) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return CMDP_OK;
+}
+
+int cmdp_stat(cmdp_t* h, int which, double* out) {
+  if (int rc = bind(h)) return rc;
+  if (!out) return fail(CMDP_ERR_INVALID, "null output");
+  if (which == CMDP_STAT_DP_KERNEL_MS) {
+    if (!h->ev_dp0) return fail(CMDP_ERR_INVALID, "no discounted solve has run on this handle");
+    HIP_TRY(hipEventSynchronize(h->ev_dp1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev_dp0, h->ev_dp1));
+    *out = ms;
+    return CMDP_OK;
+  }
+  if (which == CMDP_STAT_DP_KERNEL) {
+    *out = h->last_dp_kernel;
+    return CMDP_OK;
+  }
+  return fail(CMDP_ERR_INVALID, "unknown statistic %d", which);
+}
+
+int cmdp_calibrate(int what, int64_t n_steps, double* ns_per_step) {
+  if (!ns_per_step || n_steps < 1 || n_steps > 10000000) return fail(CMDP_ERR_INVALID, "bad argument");
+  if (what != CMDP_CALIB_LDS_READ && what != CMDP_CALIB_LDS_CHAIN) return fail(CMDP_ERR_INVALID, "unknown calibration %d", what);
+  int dev = 0, cus = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  DevBuf<int32_t> sink;
+  HIP_TRY(sink.alloc((size_t)cus * 64));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  const size_t lds = 64 * 1024;
+  for (int rep = 0; rep < 2; ++rep) {  // the first launch warms the code object up
+    const int n = rep == 0 ? 1000 : (int)n_steps;
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    if (what == CMDP_CALIB_LDS_READ) hipLaunchKernelGGL(k_calib_lds_chain<0>, dim3(cus), dim3(64), lds, nullptr, n, 30, sink.p);
+    else hipLaunchKernelGGL(k_calib_lds_chain<1>, dim3(cus), dim3(64), lds, nullptr, n, 30, sink.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+  }
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ns_per_step = (double)ms * 1e6 / (double)n_steps;
   return CMDP_OK;
 }
 
@@ -919,12 +996,14 @@ int run_sweeps(cmdp_t* h, int mode, bool diam, int scheme, DpTables t, int64_t u
       REGU_CASE(3, 5, 4, 1) REGU_CASE(3, 5, 4, 2) REGU_CASE(3, 5, 8, 1) REGU_CASE(3, 5, 8, 2)
       REGU_CASE(4, 5, 4, 1) REGU_CASE(4, 5, 4, 2) REGU_CASE(4, 5, 8, 1) REGU_CASE(4, 5, 8, 2)
       REGU_CASE(2, 5, 4, 4) REGU_CASE(3, 5, 4, 4) REGU_CASE(4, 5, 4, 4) REGU_CASE(4, 5, 8, 4)
+      REGU_CASE(2, 5, 8, 4) REGU_CASE(3, 5, 8, 4)
       REGU_CASE(3, 8, 8, 1) REGU_CASE(3, 8, 8, 2) REGU_CASE(4, 8, 4, 1) REGU_CASE(4, 8, 4, 2)
       REGU_CASE(4, 8, 8, 1) REGU_CASE(4, 8, 8, 2)
       { done = false; }
 #undef REGU_CASE
       if (done) {
         HIP_TRY(hipGetLastError());
+        h->last_dp_kernel = 5;
         return CMDP_OK;
       }
       if (h->dp_kernel == 5)
@@ -945,6 +1024,7 @@ int run_sweeps(cmdp_t* h, int mode, bool diam, int scheme, DpTables t, int64_t u
 #undef REG_CASE
     if (launched) {
       HIP_TRY(hipGetLastError());
+      h->last_dp_kernel = 2;
       return CMDP_OK;
     }
     if (h->dp_kernel == 2) return fail(CMDP_ERR_UNSUPPORTED, "no register-resident instantiation for A=%d, %d non-zeros/row, %d states", A, h->max_row_nnz, h->max_S);
@@ -973,6 +1053,7 @@ int run_sweeps(cmdp_t* h, int mode, bool diam, int scheme, DpTables t, int64_t u
     else if (mode == DP_VI) LAUNCH_BLOCK(DP_VI, false);
     else LAUNCH_BLOCK(DP_PE, false);
 #undef LAUNCH_BLOCK
+    h->last_dp_kernel = 1;
   } else {
     if (v_bytes > (size_t)kLdsBudget)
       return fail(CMDP_ERR_UNSUPPORTED, "instance with %d states does not fit the LDS-resident sweep", h->max_S);
@@ -986,6 +1067,7 @@ int run_sweeps(cmdp_t* h, int mode, bool diam, int scheme, DpTables t, int64_t u
     else if (mode == DP_VI) LAUNCH_WAVE(DP_VI, false);
     else LAUNCH_WAVE(DP_PE, false);
 #undef LAUNCH_WAVE
+    h->last_dp_kernel = 6;
   }
   HIP_TRY(hipGetLastError());
   return CMDP_OK;
@@ -1024,7 +1106,13 @@ int discounted(cmdp_t* h, int mode, const float* pi, float gamma, double eps, in
   t.csr_val = h->d_csr_val.p; t.R = R_override ? h->d_Rov.p : h->d_R.p; t.pi = pi ? h->d_pi.p : nullptr;
   t.unit_off = nullptr; t.gamma = gamma; t.eps = eps; t.max_abs = max_abs; t.max_sweeps = max_sweeps;
   t.Q = h->d_Q.p; t.V = h->d_V.p; t.sweeps = h->d_sweeps.p; t.per_target = nullptr; t.status = h->d_status.p;
+  if (!h->ev_dp0) {
+    HIP_TRY(hipEventCreate(&h->ev_dp0));
+    HIP_TRY(hipEventCreate(&h->ev_dp1));
+  }
+  HIP_TRY(hipEventRecord(h->ev_dp0, st));
   if (int rc = run_sweeps(h, mode, false, sch, t, h->B)) return rc;
+  HIP_TRY(hipEventRecord(h->ev_dp1, st));
   HIP_TRY(hipMemcpyAsync(Q, h->d_Q.p, sizeof(float) * R, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(V, h->d_V.p, sizeof(float) * NS, hipMemcpyDeviceToHost, st));
   if (sweeps) HIP_TRY(hipMemcpyAsync(sweeps, h->d_sweeps.p, sizeof(int64_t) * h->B, hipMemcpyDeviceToHost, st));
@@ -1102,11 +1190,19 @@ static int diameter_lanes(cmdp_t* h, DpTables t, int64_t unit_lo, int64_t unit_h
     }
   }
   const size_t G = inst.size();
+  // the workspace is also bounded by what the device has free right now (other handles / ranks sharing the GPU):
+  // 80 % of the free bytes plus what this handle already holds for the purpose; fewer groups per launch, same results
+  size_t ws_cap = h->dl_ws_bytes;
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+      ws_cap = std::min(ws_cap, h->d_dl_v.n * sizeof(float) + free_b / 5 * 4);
+  }
   size_t g0 = 0;
   while (g0 < G) {
     size_t g1 = g0, floats = 0;
     std::vector<int64_t> voff;
-    while (g1 < G && (g1 == g0 || (floats + (size_t)vfl[g1]) * sizeof(float) <= h->dl_ws_bytes)) {
+    while (g1 < G && (g1 == g0 || (floats + (size_t)vfl[g1]) * sizeof(float) <= ws_cap)) {
       voff.push_back((int64_t)floats);
       floats += (size_t)vfl[g1];
       ++g1;

@@ -2172,3 +2172,37 @@ __global__ void __launch_bounds__(NW * 64) k_diam_lanes_ell(DpTables t, DiamLane
     t.status[soff + target] = status;
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Calibration of the rollout kernels' latency floor (cmdp_calibrate; no reference counterpart): one wavefront per
+// workgroup, every lane follows its own uint16 successor table in LDS for `steps` DEPENDENT reads.
+//   CHAIN = 0: ds_read_u16 -> mask -> address, nothing else (the bare dependent LDS read);
+//   CHAIN = 1: what a deterministic-dynamics transition cannot avoid on its dependency chain -- action bit into the
+//              address, the successor read, the field mask, the in-episode step count and the episode-end select
+//              (K1P's chain stage does exactly this plus the trace store, which is off the chain).
+template <int CHAIN>
+__global__ void __launch_bounds__(64) k_calib_lds_chain(int steps, int H, int32_t* __restrict__ sink) {
+  extern __shared__ unsigned short calib_tab[];
+  constexpr int kPer = 512;  // entries per lane: 64 lanes x 512 x 2 B = 64 KiB
+  unsigned x = 12345u + blockIdx.x * 977u + threadIdx.x;
+  for (int i = 0; i < kPer; ++i) {
+    x = x * 1664525u + 1013904223u;
+    calib_tab[threadIdx.x * kPer + i] = (unsigned short)(((x >> 8) % (kPer / 2)) * 2);
+  }
+  __syncthreads();
+  const int base = threadIdx.x * kPer;
+  int cur = 0, h = 0;
+  for (int s = 0; s < steps; ++s) {
+    if (CHAIN == 0) {
+      cur = calib_tab[base + cur] & (kPer - 1);
+    } else {
+      const int a = (s * 7 + threadIdx.x) & 1;
+      const int nxt = calib_tab[base + cur + a] & (kPer - 2);
+      ++h;
+      const bool term = h >= H;
+      cur = term ? 0 : nxt;
+      h = term ? 0 : h;
+    }
+  }
+  sink[blockIdx.x * 64 + threadIdx.x] = cur + h;
+}

@@ -411,6 +411,8 @@ class SimpleGrid(Family):
                  optimal_distribution=None, sub_optimal_distribution=None, other_distribution=None,
                  make_reward_stochastic=False, reward_variance_multiplier=1.0):
         assert n_starting_states <= (size - 1) ** 2 and optimal_mean_reward - 0.1 > sub_optimal_mean_reward
+        if isinstance(reward_type, str):  # the enum member's name, as the parameter hash / gin files spell it
+            reward_type = {"AND": 0, "NAND": 1, "OR": 2, "XOR": 3}[reward_type.split(".")[-1]]
         self.size, self.reward_type, self.n_starting_states = size, int(reward_type), n_starting_states
         m = reward_variance_multiplier
         self.sub, self.opt, self.other = _three_dists(

@@ -135,6 +135,10 @@ typedef struct cmdp_desc {
 
 /* ---- library / device -------------------------------------------------------------------------- */
 int cmdp_version(void);
+/* SHA-256 (hex) over the sources this binary was compiled from (csrc files by name order, then this header), stamped by
+   build() through -DCMDP_BUILD_ID; colosseum_amd/_lib.py refuses a library whose id differs from the tree's hash, so a
+   stale prebuilt .so cannot pass for the sources next to it.  No reference counterpart. */
+const char* cmdp_build_id(void);
 const char* cmdp_last_error(void);
 int cmdp_device_count(void);
 int cmdp_set_device(int device);
@@ -171,6 +175,19 @@ int cmdp_rollout(cmdp_t* h, int policy, const void* policy_arg, int64_t n_steps,
 int cmdp_rollout_async(cmdp_t* h, int policy, int64_t n_steps);
 int cmdp_synchronize(cmdp_t* h);
 
+/* Measurements taken inside the library (for bench.py's roofline objects; no reference counterpart).
+   CMDP_STAT_DP_KERNEL_MS: HIP-event time, on the handle's stream, of the sweep kernel of the last
+   cmdp_vi_discounted / cmdp_pe_discounted (kernel only: no upload, no result copy).
+   CMDP_STAT_DP_KERNEL: which kernel that was -- 1 K2 (workgroup, CSR in LDS/HBM), 2 K2R, 5 K2U, 6 K3 (Gauss-Seidel). */
+enum { CMDP_STAT_DP_KERNEL_MS = 1, CMDP_STAT_DP_KERNEL = 2 };
+int cmdp_stat(cmdp_t* h, int which, double* out);
+/* Latency floor of the LDS-resident rollout kernels, measured on the current device: one wavefront per CU follows
+   per-lane uint16 tables in LDS for n_steps dependent reads.  CMDP_CALIB_LDS_READ: the bare dependent ds_read_u16
+   (read, mask, address); CMDP_CALIB_LDS_CHAIN: the minimal dependency chain of one deterministic transition (action
+   bit, successor read, mask, in-episode step, episode-end select).  ns_per_step = launch time / n_steps. */
+enum { CMDP_CALIB_LDS_READ = 0, CMDP_CALIB_LDS_CHAIN = 1 };
+int cmdp_calibrate(int what, int64_t n_steps, double* ns_per_step);
+
 /* Tuning knobs (never change results).  CMDP_OPT_ROLLOUT_KERNEL: 0 = automatic, 1 = lane-per-instance
    kernel with the tables in HBM, 2 = LDS-resident kernel (fails with CMDP_ERR_UNSUPPORTED when the batch is
    not eligible: deterministic dynamics, one start state, equal state counts <= 65535, <= 256 distinct reward
@@ -188,8 +205,10 @@ int cmdp_synchronize(cmdp_t* h);
    chains with hundreds of states.
    CMDP_OPT_DIAMETER_WORKSPACE_MB: HBM the value arrays of K5S may take per launch (default 24576; 512 bytes per
    state per group of 64 targets; more groups in flight = more of the GPU busy).
-   CMDP_OPT_LDS_GROUPS_PER_CU: 1 or 2 workgroups of the LDS-resident rollout kernel per CU (default: whichever
-   needs fewer rounds of workgroups for the batch). */
+   CMDP_OPT_LDS_GROUPS_PER_CU: 1 or 2 workgroups of the fused-walker kernel K1L per CU (default: whichever needs
+   fewer rounds of workgroups for the batch).  Setting it re-plans the handle onto K1L with the
+   balanced number of instances per workgroup for that many groups (the pipeline kernel K1P always runs one workgroup
+   per CU); CMDP_ERR_INVALID when the batch is not eligible for the LDS-resident kernels or two groups do not fit. */
 enum { CMDP_OPT_ROLLOUT_KERNEL = 1, CMDP_OPT_DP_KERNEL = 2, CMDP_OPT_LDS_GROUPS_PER_CU = 3,
        CMDP_OPT_DIAMETER_WORKSPACE_MB = 4, CMDP_OPT_CHAIN_EXACT_ORDER = 5 };
 int cmdp_set_option(cmdp_t* h, int option, int64_t value);

@@ -369,81 +369,123 @@ def _parse_cached_name(fname):
 
 
 def g5():
-    """Known-answer table.  A row is kept only if constructing the reference class with the parsed
-    kwargs reproduces the file's hash (legacy '-defaultH' suffix stripped, SURVEY 8c caveat 4)."""
+    """Known-answer table over ALL fourteen cached folders and all four measures (diameter, value_norm, n_states,
+    suboptimal_gaps).  The file name is the reference's own key (`hardness/analysis.py:386`:
+    `{measure}_{mdp_shell.hash}.txt`, hash = the cleaned `parameters` values, `mdp/base.py:297-306`,
+    `utils/formatter.py:21-75`); the constructor keywords are parsed back from it and a row is kept with
+    `hash_match = "full"` only if a reference shell (`instantiate_mdp=False`, as analysis.py:375-377 builds it)
+    constructed from those keywords reproduces the hash (legacy '-defaultH' suffix stripped, SURVEY 8c caveat 4).
+    Files written by older reference versions whose DEFAULT reward distributions differ from today's reproduce every
+    token but the distribution strings: they are kept as `hash_match = "structural"` for the measures that do not
+    depend on rewards (diameter, n_states) and dropped otherwise."""
     base = os.path.join(ref_env.REFERENCE, "colosseum", "benchmark", "cached_hardness_measures")
     rows = []
+    # family -> (own constructor keywords in `parameters` order, number of trailing distribution tokens)
     fam_fields = {
-        "DeepSea": ["size", "optimal_return", "suboptimal_return"],
-        "FrozenLake": ["size", "p_frozen", "optimal_return", "suboptimal_return", "is_slippery"],
-        "MiniGridEmpty": ["size", "n_starting_states"],
-        "MiniGridRooms": ["room_size", "n_rooms", "n_starting_states"],
+        "DeepSea": (["size", "optimal_return", "suboptimal_return"], 3),
+        "FrozenLake": (["size", "p_frozen", "optimal_return", "suboptimal_return", "is_slippery"], 2),
+        "MiniGridEmpty": (["size", "n_starting_states"], 2),
+        "MiniGridRooms": (["room_size", "n_rooms", "n_starting_states"], 2),
+        "RiverSwim": (["size", "optimal_mean_reward", "sub_optimal_mean_reward"], 3),
+        "SimpleGrid": (["size", "reward_type", "n_starting_states", "optimal_mean_reward", "sub_optimal_mean_reward"], 3),
+        "Taxi": (["size", "length", "width", "space", "n_locations", "optimal_mean_reward", "sub_optimal_mean_reward"], 3),
     }
-    seen = set()
-    n_skipped = 0
+    int_fields = {"size", "room_size", "n_rooms", "n_starting_states", "length", "width", "space", "n_locations"}
+    from colosseum.mdp.simple_grid.base import SimpleGridReward
+
+    shells = {}
+    stats = {}
+
+    def skip(why):
+        stats[why] = stats.get(why, 0) + 1
+
     for cls_name, cls in CLASSES.items():
         folder = os.path.join(base, cls_name)
         fam = cls_name.replace("Continuous", "").replace("Episodic", "")
+        fields, n_dist = fam_fields[fam]
+        episodic = "Episodic" in cls_name
         for fname in sorted(os.listdir(folder)):
+            if "_mdp_" not in fname or not fname.endswith(".txt"):
+                skip("not a cache file")
+                continue
             measure, c, hashed = _parse_cached_name(fname)
-            if measure not in ("diameter", "value_norm", "n_states"):
+            if measure not in ("diameter", "value_norm", "n_states", "suboptimal_gaps"):
+                skip("malformed measure name")  # a few files carry a VALUE where the measure name belongs
                 continue
             legacy = hashed.endswith("-defaultH")
             h = hashed[: -len("-defaultH")] if legacy else hashed
             toks = h.split("-")
+            has_H = episodic and not legacy
+            if len(toks) != 7 + len(fields) + n_dist + (1 if has_H else 0):
+                skip("token count")
+                continue
             try:
                 seed, ra, p_lazy, p_rand = (_parse_num(t) for t in toks[:4])
                 rr = toks[4]
                 mrs, rvm = _parse_num(toks[5]), _parse_num(toks[6])
-                fam_vals = [_parse_num(t) for t in toks[7: 7 + len(fam_fields[fam])]]
+                fam_vals = [t if k == "reward_type" else _parse_num(t) for k, t in zip(fields, toks[7: 7 + len(fields)])]
             except Exception:
-                n_skipped += 1
+                skip("unparsable")
                 continue
             if rr != "0_0__1_0":
-                n_skipped += 1
+                skip("rewards range")
                 continue
             kw = dict(seed=seed, randomize_actions=ra, p_lazy=p_lazy, p_rand=p_rand,
                       make_reward_stochastic=mrs, reward_variance_multiplier=rvm)
-            kw.update(dict(zip(fam_fields[fam], fam_vals)))
-            if fam == "MiniGridEmpty":
-                # MiniGridEmpty.parameters lists size, n_starting_states (minigrid_empty/base.py:268-276)
-                pass
-            # size guard: keep the table to MDPs the CPU suite can sweep in seconds
-            approx_S = {
-                "DeepSea": lambda k: k["size"] * (k["size"] + 1) // 2,
-                "FrozenLake": lambda k: k["size"] ** 2,
-                "MiniGridEmpty": lambda k: 4 * k["size"] ** 2,
-                "MiniGridRooms": lambda k: 4 * (k["n_rooms"] * k["room_size"] ** 2 + 2 * int(k["n_rooms"] ** 0.5) * (int(k["n_rooms"] ** 0.5) - 1)),
-            }[fam](kw)
-            if approx_S > 450:
-                n_skipped += 1
+            kw.update(dict(zip(fields, fam_vals)))
+            extra = {}
+            if has_H:
+                extra["H"] = _parse_num(toks[-1])
+            sig = (cls_name, json.dumps(kw, sort_keys=True), legacy, json.dumps(extra))
+            if sig not in shells:
+                ckw = dict(kw)
+                if "reward_type" in ckw:
+                    ckw["reward_type"] = SimpleGridReward[ckw["reward_type"]]
+                try:
+                    shell = cls(**ckw, **extra, instantiate_mdp=False,
+                                **(dict(exclude_horizon_from_parameters=legacy) if episodic else {}))
+                    shells[sig] = shell.hash.split(f"mdp_{cls_name}_", 1)[1]
+                except Exception:  # the constructor rejects the parsed keywords
+                    shells[sig] = None
+                if shells[sig] is not None:
+                    try:  # what instantiate_MDP would assert first (mdp/base.py:467): files written by older
+                        shell._check_parameters_in_input()  # reference versions can name MDPs today's code rejects
+                    except AssertionError:
+                        shells[sig] = "rejected"
+            ref_hash = shells[sig]
+            if ref_hash is None:
+                skip("constructor rejects")
                 continue
-            sig = (cls_name, json.dumps(kw, sort_keys=True))
-            try:
-                if sig not in seen:
-                    mdp = cls(**{k: v for k, v in kw.items()}, exclude_horizon_from_parameters=legacy) \
-                        if "Episodic" in cls_name else cls(**kw)
-                    ref_hash = mdp.hash.split(f"mdp_{cls_name}_", 1)[1]
-                    ok = ref_hash == h
-                    seen.add(sig)
-                    if not ok:
-                        seen.add(sig + ("bad",))
-                if sig + ("bad",) in seen:
-                    n_skipped += 1
-                    continue
-            except Exception as e:  # constructor rejects the parsed kwargs
-                seen.add(sig)
-                seen.add(sig + ("bad",))
-                n_skipped += 1
+            if ref_hash == "rejected":
+                skip("today's _check_parameters_in_input rejects")
+                continue
+            nd = 7 + len(fields)
+            rtoks = ref_hash.split("-")
+            if ref_hash == h:
+                match = "full"
+            elif (rtoks[:nd] == toks[:nd] and rtoks[nd + n_dist:] == toks[nd + n_dist:]
+                  and measure in ("diameter", "n_states")):
+                match = "structural"
+            else:
+                skip("hash differs (%s)" % measure)
                 continue
             with open(os.path.join(folder, fname)) as f:
                 txt = f.read().strip()
             if not txt:  # a few cached files are empty in the reference tree
-                n_skipped += 1
+                skip("empty file")
                 continue
             val = float(txt)
-            rows.append(dict(cls=cls_name, kwargs=kw, measure=measure, value=val, legacy_defaultH=legacy, file=fname))
-    print(f"  G5: kept {len(rows)} cached values, skipped {n_skipped}")
+            # keywords as a constructor takes them: integral sizes the analysis scripts passed as numpy floats
+            # ('11_0') become ints; the hash check above used the parsed form
+            okw = {k: (int(v) if k in int_fields and isinstance(v, float) and v == int(v) else v) for k, v in kw.items()}
+            okw.update(extra)
+            rows.append(dict(cls=cls_name, kwargs=okw, measure=measure, value=val, legacy_defaultH=legacy,
+                             hash_match=match, file=fname))
+    kept = {}
+    for r in rows:
+        k = "%s/%s" % (r["measure"], r["hash_match"])
+        kept[k] = kept.get(k, 0) + 1
+    print(f"  G5: kept {len(rows)} cached values {kept}; skipped {stats}")
     with open(os.path.join(OUT, "G5_hardness_kat.json"), "w") as f:
         json.dump(rows, f, indent=0)
 

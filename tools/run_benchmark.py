@@ -53,22 +53,28 @@ def main():
             ins.mdp_scope = f"b{k}_{ins.mdp_scope}" if len(benchmarks) > 1 else ins.mdp_scope
             instances.append(ins)
     t0 = time.time()
-    # NOTE: run_instances builds the models with a fork()ed pool first; RCCL / HIP are initialised only afterwards
+    # order matters: (1) host model construction in a fork()ed pool, (2) the process group -- right away and with a
+    # generous timeout, so that no rank waits in rendezvous while another is still running its shard, and a rank that
+    # dies mid-run is noticed at the gather -- (3) only then the first HIP call of this process
+    models = bm.build_shard_models(instances, rank, world, workers=max(1, min(16, (os.cpu_count() or 1) // world)))
+    if world > 1:
+        import datetime
+
+        import torch
+        import torch.distributed as dist
+
+        timeout = datetime.timedelta(hours=6)
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=timeout)
+        else:
+            dist.init_process_group(args.dist_backend, timeout=timeout)
     results = bm.run_instances(instances, n_steps, log_every, rank, world, device=local, max_concurrent_groups=args.concurrent_groups, max_batch=args.max_batch,
-                               build_workers=max(1, min(16, (os.cpu_count() or 1) // world)),
+                               models=models,
                                progress=lambda msg: print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True))
     t_run = time.time() - t0
     bm.write_csv_logs(args.out, instances, results, workers=max(1, min(32, (os.cpu_count() or 1) // world)))
     print(f"[rank {rank}] instances done in {t_run:.1f} s, logs written in {time.time() - t0 - t_run:.1f} s", file=sys.stderr, flush=True)
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-
-        if args.dist_backend == "nccl":
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(args.dist_backend)
     lo, hi = shard_range(len(instances), rank, world)
     local_vec = np.stack([bm.summary_vector(results[i]) for i in range(lo, hi)]) if hi > lo else np.zeros((0, 3))
     allv = gather_instances(local_vec, len(instances), dist,

@@ -40,13 +40,17 @@ def main():
                    n_starting_states=2, p_lazy=0.1)
     S, A = m.n_states, m.n_actions
     t_build = time.time() - t0
+    if args.share_gpu:
+        local = 0
     if world > 1:
         import torch
         import torch.distributed as dist
 
-        dist.init_process_group(args.dist_backend)
-    if args.share_gpu:
-        local = 0
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.dist_backend)
     L.check(L.load().cmdp_set_device(local))
     dp = BatchedMDP([m], with_env=False)
     if args.workspace_mb:
