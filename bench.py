@@ -2,24 +2,35 @@
 """bench.py -- the headline measurement (BASELINE.json: env steps/s on 65 536 parallel DeepSea(size=30)
 instances, random policy + value-iteration sweeps/s), one rank per GPU.
 
-    python bench.py --gpus 1 --steps 30 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...          (no WORLD_SIZE in the environment: spawns N child ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-A "step" is one fused rollout launch: `--launch-steps` (default 5000) transitions of every instance of the
-rank's shard (default 65 536 instances per GPU -> weak scaling), inputs resident in HBM.  K timed steps are
-bracketed by barrier + device synchronise on both sides, the max over ranks is taken, rank 0 prints ONE JSON
-line.  `value` = transitions of all ranks / that time.
+A "step" is one pass of the hot path over the batch = SURVEY 8(d)'s C2 job: ONE fused rollout launch of
+`--launch-steps` (default 30 000 = 1 000 episodes) transitions of every instance of the rank's shard (65 536
+instances per GPU -> weak scaling), inputs resident in HBM.  K timed steps are bracketed by barrier + device
+synchronise on both sides, the max over ranks is taken, rank 0 prints ONE JSON line.  `value` = transitions of all
+ranks / that time.
 
-Extra objects on the line (prompt section 4):
-  roofline      dominant kernel (k_rollout): algorithmic bytes per launch / HIP-event launch time vs 8 TB/s
+Objects on the line (prompt section 4; DESIGN.md section 4 explains every figure):
+  roofline      the dominant kernel.  The default layout keeps the tables in LDS, so it is bound by the latency of
+                the dependent LDS read of a transition, not by HBM: bound = "lds_latency", achieved = transitions/s,
+                peak = chains the LDS can hold / the dependent-read chain latency CALIBRATED IN THIS RUN
+                (cmdp_calibrate), frac <= 1.  The HBM view (algorithmic bytes and PMC traffic against 8 TB/s) is the
+                sub-object roofline.hbm.
+  dense         the north star's layout (per-instance dense float32 P[s,a,:] rows streamed from HBM, K1D): its own
+                roofline, bound = "hbm".
+  vi            config C3 (FrozenLake 20x20 discounted value iteration to 1e-6): sweeps/s + its own roofline
+                (bound = "valu_issue": the CSR stays in registers, V in LDS).
   cpu_baseline  the CPU oracle (oracle/cmdp_oracle.c, "port") timed on this host, one core, bounded sample
-  vi            config C3: FrozenLake 20x20 discounted value iteration to 1e-6, sweeps/s (secondary metric)
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,7 +39,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+N_CUS = 256
+CLOCK_HZ = 2.4e9        # MI355X peak engine clock
+VALU_CYCLES = 2         # MI355X_MICROARCH.md, per-instruction constants: wave64 v_fma_f32 = 2 cycles per SIMD
+LDS_BYTES = 160 * 1024  # per CU
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
 
 
 class HipEvents:
@@ -63,24 +79,66 @@ def frozenlake_dp_tables(seeds, size, workers):
     return build(seeds, size, workers, context="fork")
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: N child ranks of this very script, started BEFORE this process
+    makes any HIP / RCCL call; rank 0's stdout (the JSON line) is relayed, the exit code is the worst child's."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def pmc_entry(kernel_prefix, units_per_launch, build_id):
+    """HBM bytes per launch of a kernel from the committed summary of this round's `--pmc FETCH_SIZE` / `--pmc
+    WRITE_SIZE` passes (their own rocprofv3 runs, tools/collect_profiles.sh).  Returned only when the summary was
+    collected on the same workload; `current` says whether it was collected on THIS build of the library."""
+    try:
+        j = json.load(open(PMC_FILE))
+    except Exception:
+        return None
+    for k in j.get("kernels", []):
+        if k["kernel"].startswith(kernel_prefix) and k.get("units_per_launch") == units_per_launch:
+            return dict(bytes=k["hbm_bytes_per_launch"], read=k["hbm_read_bytes_per_launch"], write=k["hbm_write_bytes_per_launch"],
+                        current=j.get("build_id") == build_id, source="profiles/" + os.path.basename(PMC_FILE),
+                        collected_on_build=j.get("build_id", "")[:16])
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--instances", type=int, default=65536, help="instances per GPU (weak scaling)")
     ap.add_argument("--size", type=int, default=30)
-    ap.add_argument("--launch-steps", type=int, default=5000, help="transitions per instance per launch (one bench step)")
+    ap.add_argument("--launch-steps", type=int, default=30000,
+                    help="transitions per instance per launch = one bench step (SURVEY 8d C2: 30 000 = 1 000 episodes)")
     ap.add_argument("--vi-instances", type=int, default=4096, help="FrozenLake instances per GPU for the VI leg (0: skip)")
-    ap.add_argument("--cpu-instances", type=int, default=4096, help="instances of the CPU-oracle sample (0: skip)")
+    ap.add_argument("--dense-instances", type=int, default=65536, help="instances of the dense-row leg (0: skip)")
+    ap.add_argument("--dense-launch-steps", type=int, default=200)
+    ap.add_argument("--dense-steps", type=int, default=10)
+    ap.add_argument("--cpu-instances", type=int, default=512, help="instances of the CPU-oracle sample (0: skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (CPU rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: ranks share the visible GPUs (device = local_rank %% n_devices)")
-    ap.add_argument("--lds-groups", type=int, default=0, help="LDS rollout workgroups per CU (0: library default)")
+    ap.add_argument("--lds-groups", type=int, default=0, help="K1L workgroups per CU (0: library default; needs CMDP_K1L_PIPE=0)")
     ap.add_argument("--rollout-kernel", type=int, default=0, help="0 auto, 1 HBM tables, 2 LDS-resident")
     ap.add_argument("--layout", default="csr", choices=["csr", "dense"],
-                    help="csr (default, fastest) or dense = per-instance float32 P[s,a,:] rows in HBM (north-star layout)")
+                    help="layout of the HEADLINE leg: csr (default, fastest) or dense (then --launch-steps applies to K1D)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -116,7 +174,8 @@ def main():
     from colosseum_amd.batched import BatchedMDP
     from colosseum_amd.mdp.fast_batch import deepsea_episodic_tables
 
-    lib = L.load()
+    lib = L.load()  # raises if the binary's build id is not the hash of the sources in the tree
+    build_id = lib.cmdp_build_id().decode()
     assert lib.cmdp_device_count() > 0, "no HIP device visible: the product path has no CPU fallback"
     L.check(lib.cmdp_set_device(device_index))
 
@@ -124,49 +183,66 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        import torch
+
+        t = torch.tensor([x], dtype=torch.float64, device=coll_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(x):
+        if dist is None:
+            return x
+        import torch
+
+        t = torch.tensor([x], dtype=torch.float64, device=coll_device)
+        dist.all_reduce(t)
+        return float(t.item())
+
+    ev = HipEvents()
+
+    def timed_launches(env, n_launch, launch_steps, warmup):
+        """W untimed + K timed fused-rollout launches; (wall seconds incl. barriers, per-launch HIP-event ms)."""
+        stream = env.stream
+        for _ in range(warmup):
+            env.rollout_async(launch_steps)
+        env.synchronize()
+        marks = [ev.create() for _ in range(n_launch + 1)]
+        barrier()
+        env.synchronize()
+        t0 = time.perf_counter()
+        ev.record(marks[0], stream)
+        for k in range(n_launch):
+            env.rollout_async(launch_steps)
+            ev.record(marks[k + 1], stream)
+        env.synchronize()
+        barrier()
+        wall = time.perf_counter() - t0
+        return wall, [ev.elapsed_ms(marks[k], marks[k + 1]) for k in range(n_launch)]
+
     # ---- C2 workload: this rank's shard of DeepSeaEpisodic(seed=i, size=30), i in [rank*B, (rank+1)*B) ----
     B = args.instances
     seeds = np.arange(rank * B, (rank + 1) * B, dtype=np.int64)
     t_build = time.time()
-    dense = args.layout == "dense"
-    tables = deepsea_episodic_tables(seeds, args.size, with_dp=dense)
+    dense_headline = args.layout == "dense"
+    tables = deepsea_episodic_tables(seeds, args.size, with_dp=dense_headline)
     keys = seeds.astype(np.uint64)  # Philox key = global instance id
     env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX, philox_keys=keys,
-                     layout=L.LAYOUT_DENSE if dense else L.LAYOUT_CSR)
+                     layout=L.LAYOUT_DENSE if dense_headline else L.LAYOUT_CSR)
     env.reset()
     if args.rollout_kernel:
         env.set_rollout_kernel(args.rollout_kernel)
     if args.lds_groups:
         env.set_option(L.OPT_LDS_GROUPS_PER_CU, args.lds_groups)
     t_build = time.time() - t_build
-    S = int(env.n_states[0])
-    plan = env.lds_plan() if not dense else dict(kernel="", eligible=False)
+    S, A = int(env.n_states[0]), 2
+    plan = env.lds_plan() if not dense_headline else dict(kernel="", eligible=False)
     lds_kernel = plan["kernel"]
 
-    ev = HipEvents()
-    stream = env.stream
-    for _ in range(args.warmup):
-        env.rollout_async(args.launch_steps)
-    env.synchronize()
-    marks = [ev.create() for _ in range(args.steps + 1)]
-    barrier()
-    env.synchronize()
-    t0 = time.perf_counter()
-    ev.record(marks[0], stream)
-    for k in range(args.steps):
-        env.rollout_async(args.launch_steps)
-        ev.record(marks[k + 1], stream)
-    env.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    launch_ms = [ev.elapsed_ms(marks[k], marks[k + 1]) for k in range(args.steps)]
-
-    if dist is not None:
-        import torch
-
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, launch_ms = timed_launches(env, args.steps, args.launch_steps, args.warmup)
+    elapsed = max_over_ranks(elapsed)
 
     # ---- final gather over RCCL (the only collective): per-instance episode counts = visits of the start state ----
     vs, _ = env.visits(sa=False)
@@ -187,25 +263,57 @@ def main():
         gather_ms = (time.perf_counter() - g0) * 1e3
         assert bool((allv[rank * B:(rank + 1) * B] == local).all())
 
-    total_steps = world * B * args.launch_steps * args.steps
+    units_per_launch = B * args.launch_steps
+    total_steps = world * units_per_launch * args.steps
     value = total_steps / elapsed
     avg_launch_s = float(np.mean(launch_ms)) * 1e-3
-    # SURVEY 8(d), CSR companion figure: 8 (row pointer pair) + 8*nnz(s,a) + 28 B per transition = 44 B at C2
-    bytes_per_step = (4 * S + 28) if dense else (8 + 8 * 1 + 28)  # dense-row figure / CSR figure
-    algo_bytes = bytes_per_step * B * args.launch_steps
-    achieved = algo_bytes / avg_launch_s / 1e9
-    # HBM bytes per launch from the PMC counters: they need their own rocprofv3 passes (--pmc FETCH_SIZE,
-    # --pmc WRITE_SIZE), so the figure is read from the committed summary of those passes when the workload
-    # is the one they were collected on; null otherwise.
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_rollout_pmc.json")
-    if os.path.exists(pmc):
-        try:
-            j = json.load(open(pmc))
-            if j.get("transitions_per_launch") == B * args.launch_steps and args.size == 30 and not dense:
-                traffic = j.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    kernel_rate = units_per_launch / avg_launch_s  # transitions/s of this rank's kernel
+
+    def hbm_view(bytes_per_unit, accounting, kernel_prefix, units, launch_s):
+        """Algorithmic bytes (SURVEY 8d per-unit figure x units per launch) and PMC traffic against the HBM peak."""
+        pm = pmc_entry(kernel_prefix, units, build_id)
+        algo = bytes_per_unit * units / launch_s / 1e9
+        return {
+            "algorithmic_bytes_per_unit": bytes_per_unit, "accounting": accounting,
+            "algorithmic_GBps": algo, "algorithmic_over_peak": algo / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "traffic": pm["bytes"] if pm else None,
+            "traffic_GBps": pm["bytes"] / launch_s / 1e9 if pm else None,
+            "traffic_frac": pm["bytes"] / launch_s / 1e9 / HBM_PEAK_GBS if pm else None,
+            "traffic_source": ("%s (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate --pmc passes; collected on "
+                               "build %s = %s build)" % (pm["source"], pm["collected_on_build"], "this" if pm["current"] else "ANOTHER")) if pm else None,
+            "traffic_current": pm["current"] if pm else None,
+        }
+
+    if dense_headline:
+        bytes_per_step = 4 * S + 28
+        hv = hbm_view(bytes_per_step, "SURVEY 8(d) dense-row figure (4*S+28 B/transition)", "k_rollout_dense", units_per_launch, avg_launch_s)
+        roofline = {"bound": "hbm", "kernel": "k_rollout_dense<0,NV>", "achieved": hv["algorithmic_GBps"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": hv["algorithmic_over_peak"], "traffic": hv["traffic"], "hbm": hv}
+    else:
+        # The LDS-resident kernels: what bounds a launch is (instances / chains resident on the chip) x transitions x
+        # the latency of the dependent LDS read chain of one transition.  The chain latency is measured in this run.
+        ns_read, ns_chain = C.c_double(), C.c_double()
+        L.check(lib.cmdp_calibrate(L.CALIB_LDS_READ, 200000, C.byref(ns_read)))
+        L.check(lib.cmdp_calibrate(L.CALIB_LDS_CHAIN, 200000, C.byref(ns_chain)))
+        min_footprint = 2 * S * A + S * A  # uint16 successor words + 8-bit visit-count deltas: what a chain needs in LDS
+        chains_per_cu = LDS_BYTES // min_footprint
+        peak = N_CUS * chains_per_cu / (ns_chain.value * 1e-9)  # transitions/s with every CU's LDS full of chains
+        hv = hbm_view(8 + 8 * 1 + 28, "SURVEY 8(d) CSR figure (8 + 8*nnz + 28 = 44 B/transition); the tables are LDS-resident, so "
+                      "these bytes never cross HBM -- reported as an equivalent rate, NOT a roofline fraction",
+                      lds_kernel if args.rollout_kernel != 1 else "k_rollout<", units_per_launch, avg_launch_s)
+        roofline = {
+            "bound": "lds_latency",
+            "kernel": lds_kernel if args.rollout_kernel != 1 else "k_rollout<0,false>",
+            "achieved": kernel_rate / 1e9, "peak": peak / 1e9, "unit": "G transitions/s (one dependent LDS read each)",
+            "frac": kernel_rate / peak,
+            "model": "peak = %d CUs x floor(160 KiB / %d B of tables+count deltas per instance) = %d resident chains per CU / "
+                     "calibrated dependent-read chain latency" % (N_CUS, min_footprint, chains_per_cu),
+            "calibrated_chain_ns": ns_chain.value, "calibrated_bare_lds_read_ns": ns_read.value,
+            "resident_chains_per_cu": plan.get("instances_per_workgroup"), "lds_plan": plan,
+            "traffic": hv["traffic"], "hbm": hv,
+        }
+    roofline["launch_ms_avg"] = avg_launch_s * 1e3
+    roofline["launch_ms_min"] = float(np.min(launch_ms))
 
     line = {
         "metric": "env steps/sec (whole node) + value-iteration sweeps/sec, DeepSea size=%d x%d" % (args.size, B),
@@ -223,23 +331,44 @@ def main():
         "config": {
             "workload": "C2: DeepSeaEpisodic(seed=i,size=%d), %d instances per GPU, on-device uniform random policy "
                         "(Philox-4x32-10), %d transitions per instance per step, auto-reset at h>=H" % (args.size, B, args.launch_steps),
-            "instances_per_gpu": B, "states": S, "actions": 2, "horizon": int(env.H),
+            "instances_per_gpu": B, "states": S, "actions": A, "horizon": int(env.H),
             "transitions_per_instance_per_step": args.launch_steps, "layout": args.layout, "rng": "philox4x32-10",
             "build_s": round(t_build, 2),
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "k_rollout_dense<0,NV>" if dense else (lds_kernel if args.rollout_kernel != 1 else "k_rollout<0,false>"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "lds_plan": plan,
-            "algorithmic_bytes_per_transition": bytes_per_step, "accounting": "SURVEY 8(d) dense-row figure (4*S+28 B/transition)" if dense else "SURVEY 8(d) CSR figure (44 B/transition)",
-            "launch_ms_avg": avg_launch_s * 1e3, "launch_ms_min": float(np.min(launch_ms)),
-            # what actually crosses the HBM interface (PMC), as a fraction of peak: the LDS-resident kernels keep the
-            # tables on chip, so `frac` (algorithmic bytes) can exceed 1 while this stays small
-            "traffic_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-        },
+        "build_id": build_id[:16],
+        "roofline": roofline,
+        "parity_notes": "state indices / visit counts bit-exact; Jacobi VI/PE bit-exact incl. sweep counts; Gauss-Seidel VI/PE and "
+                        "episodic values within 2e-6 of the reference (NOT the 1e-6 of the north star: the reference sums rows "
+                        "with BLAS sgemv, whose accumulation order is not reproduced)",
     }
     if gather_ms is not None:
         line["gather_ms"] = gather_ms
+
+    # ---- dense-row leg (north-star layout, K1D): same instances, rows streamed from HBM -------------------------
+    dense_env = None
+    if args.dense_instances > 0 and not dense_headline:
+        Bd = args.dense_instances
+        td = time.time()
+        dseeds = seeds[:Bd]
+        dtables = deepsea_episodic_tables(dseeds, args.size, with_dp=True)
+        dense_env = BatchedMDP(tables=dtables, rng_mode=L.RNG_PHILOX, philox_keys=dseeds.astype(np.uint64), layout=L.LAYOUT_DENSE)
+        dense_env.reset()
+        td = time.time() - td
+        d_wall, d_ms = timed_launches(dense_env, args.dense_steps, args.dense_launch_steps, 2)
+        d_wall = max_over_ranks(d_wall)
+        d_units = Bd * args.dense_launch_steps
+        d_launch_s = float(np.mean(d_ms)) * 1e-3
+        hv = hbm_view(4 * S + 28, "SURVEY 8(d) dense-row figure (4*S+28 = %d B/transition)" % (4 * S + 28), "k_rollout_dense", d_units, d_launch_s)
+        line["dense"] = {
+            "workload": "C2 in the north star's layout: per-instance dense float32 P[s,a,:] rows in HBM (%.0f GB), wavefront "
+                        "prefix-sum CDF lookup, %d instances per GPU, %d transitions per instance per launch, %d launches"
+                        % (Bd * S * A * 512 * 4 / 1e9, Bd, args.dense_launch_steps, args.dense_steps),
+            "value": world * d_units * args.dense_steps / d_wall, "unit": "env steps/s", "build_s": round(td, 2),
+            "roofline": {"bound": "hbm", "kernel": "k_rollout_dense<0,NV>", "achieved": hv["algorithmic_GBps"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": hv["algorithmic_over_peak"], "traffic": hv["traffic"], "traffic_frac": hv["traffic_frac"],
+                         "traffic_source": hv["traffic_source"], "traffic_current": hv["traffic_current"],
+                         "algorithmic_bytes_per_transition": 4 * S + 28, "launch_ms_avg": d_launch_s * 1e3, "launch_ms_min": float(np.min(d_ms))},
+        }
 
     # ---- VI leg (config C3): FrozenLake 20x20, gamma .99, eps 1e-6, the reference's own scheme rule --------
     if args.vi_instances > 0:
@@ -252,23 +381,46 @@ def main():
         t1 = time.perf_counter()
         Q, V, sw = dp.value_iteration(0.99, 1e-6, out=bufs)
         barrier()
-        vi_s = time.perf_counter() - t1
-        sweeps = float(sw.sum())
-        if dist is not None:
-            import torch
-
-            tt = torch.tensor([vi_s], dtype=torch.float64, device=coll_device)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            vi_s = float(tt[0].item())
-            ts = torch.tensor([sweeps], dtype=torch.float64, device=coll_device)
-            dist.all_reduce(ts)
-            sweeps = float(ts.item())
+        vi_s = max_over_ranks(time.perf_counter() - t1)
+        my_sweeps = float(sw.sum())
+        sweeps = sum_over_ranks(my_sweeps)
+        kms, kid = C.c_double(), C.c_double()
+        L.check(lib.cmdp_stat(dp.handle, L.STAT_DP_KERNEL_MS, C.byref(kms)))
+        L.check(lib.cmdp_stat(dp.handle, L.STAT_DP_KERNEL, C.byref(kid)))
+        kname = {1: "k_dp_block", 2: "k_dp_reg", 5: "k_dp_regu", 6: "k_dp_wave_gs"}.get(int(kid.value), "?")
+        nS = int(np.max(np.diff(fl["state_off"])))
+        nnz = int(len(fl["csr_col"])) / args.vi_instances
         line["vi"] = {
             "workload": "C3: FrozenLakeContinuous(seed=i,size=20,p_frozen=0.9,is_slippery=True,p_rand=0.1), %d instances "
                         "per GPU, discounted VI gamma=0.99 eps=1e-6, scheme by the reference rule (Jacobi)" % args.vi_instances,
             "sweeps_per_s": sweeps / vi_s, "instances_per_s": world * args.vi_instances / vi_s, "total_sweeps": sweeps,
             "wall_ms": vi_s * 1e3, "includes": "H2D of nothing, D2H of Q,V,sweeps into reused page-locked host buffers", "build_s": round(tb, 2),
+            "kernel_ms": kms.value, "kernel_sweeps_per_s": my_sweeps / (kms.value * 1e-3),
         }
+        # VI roofline.  The CSR is read from HBM once per solve and kept in registers, V lives in LDS: neither HBM nor MFMA
+        # is in play.  The sweep is bound by VALU issue; the instruction count per workgroup-sweep comes from the
+        # committed SQ_INSTS_VALU pass of this kernel (profiles/r02_pmc.json), sweeps and kernel time are live.
+        vr = {"bound": "valu_issue", "kernel": kname, "peak": N_CUS * 4 * CLOCK_HZ / VALU_CYCLES / 1e9,
+              "unit": "G wave-instructions/s", "achieved": None, "frac": None,
+              "model": "peak = %d CUs x 4 SIMDs x %.1f GHz / %d cycles per wave64 VALU instruction" % (N_CUS, CLOCK_HZ / 1e9, VALU_CYCLES),
+              "hbm": {"bytes_per_sweep_csr_figure": 8 * nnz + 4 * (nS * 4 + 1) + 4 * nS * 4 + 8 * nS,
+                      "note": "SURVEY 8(d) CSR figure; read from HBM once per SOLVE, not per sweep -- not a roofline"}}
+        try:
+            j = json.load(open(PMC_FILE))
+            for k in j.get("kernels", []):
+                if k["kernel"].startswith(kname) and "valu_insts_per_sweep" in k:
+                    inst = k["valu_insts_per_sweep"] * my_sweeps
+                    vr["achieved"] = inst / (kms.value * 1e-3) / 1e9
+                    vr["frac"] = vr["achieved"] / vr["peak"]
+                    vr["valu_wave_insts_per_workgroup_sweep"] = k["valu_insts_per_sweep"]
+                    vr["counter_source"] = "profiles/%s: SQ_INSTS_VALU / total sweeps, collected on build %s = %s build" % (
+                        os.path.basename(PMC_FILE), j.get("build_id", "")[:16], "this" if j.get("build_id") == build_id else "ANOTHER")
+                    for extra in ("lds_insts_per_sweep", "lds_idx_active_frac", "lds_bank_conflict_frac", "valu_active_frac"):
+                        if extra in k:
+                            vr[extra] = k[extra]
+        except Exception:
+            pass
+        line["vi"]["roofline"] = vr
         dp.close()
 
     # ---- CPU baseline: the oracle, one core, bounded sample of the same workload (rank 0, N = 1 only) -----
@@ -284,6 +436,13 @@ def main():
         verified = bool(np.array_equal(cvs, vs[: n * S]))
         assert verified, "GPU visit counts differ from the CPU oracle"
         line["verified_against_oracle"] = "state-visit counts of instances 0..%d after %d transitions: bit-equal" % (n - 1, n_steps)
+        if dense_env is not None:
+            nd = min(64, args.dense_instances)
+            d_steps = args.dense_launch_steps * (args.dense_steps + 2)
+            _, _, dcvs, _ = O.batch_rollout(dtables, 0, nd, d_steps, rng_mode=1, philox_keys=keys, want_visits=True)
+            dvs, _ = dense_env.visits(sa=False)
+            assert np.array_equal(dcvs, dvs[: nd * S]), "dense-layout visit counts differ from the CPU oracle"
+            line["dense"]["verified_against_oracle"] = "state-visit counts of instances 0..%d after %d transitions: bit-equal" % (nd - 1, d_steps)
         line["cpu_baseline"] = {
             "value": n * n_steps / cpu_s, "unit": "env steps/s", "cores": 1, "kind": "port",
             "sample": "instances 0..%d of the same batch, %d transitions each (same Philox streams), reset included; "
@@ -305,7 +464,7 @@ def main():
         if cores > 1:
             from concurrent.futures import ThreadPoolExecutor
 
-            n_mt = min(B, 1024 * cores)
+            n_mt = min(B, 128 * cores)
             per = -(-n_mt // cores)
             ranges = [(lo, min(n_mt, lo + per)) for lo in range(0, n_mt, per)]
             c0 = time.perf_counter()
@@ -329,6 +488,8 @@ def main():
             cv = time.perf_counter() - c0
             line["vi"]["cpu_baseline"] = {"value": float(swc.sum()) / cv, "unit": "sweeps/s", "cores": 1, "kind": "port",
                                           "sample": "instances 0..%d, %.1f s" % (nv - 1, cv)}
+    if dense_env is not None:
+        dense_env.close()
     env.close()
     if rank == 0:
         print(json.dumps(line), flush=True)

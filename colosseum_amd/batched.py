@@ -103,6 +103,11 @@ class BatchedMDP:
         L.check(lib.cmdp_create(C.byref(self._h), C.byref(d)))
         self._lib = lib
 
+    @property
+    def handle(self):
+        """The cmdp_t* (for C-ABI calls this class has no method for, e.g. cmdp_stat)."""
+        return self._h
+
     # -- life cycle --------------------------------------------------------------------------------------
     def _register_agent(self, agent):
         import weakref
