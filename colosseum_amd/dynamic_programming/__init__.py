@@ -12,6 +12,35 @@ from ..dp_handle import DPBatch, csr_from_dense
 DP_MAX_ITERATION = int(1e6)
 ARGMAX_SEED = 42
 
+# The reference's functions take dense arrays and own no state; an `MDPLoop` calls them with the SAME (T, R) at every
+# logging step.  The device handle of a (T, R) pair (CSR extraction, allocation, upload) is therefore kept and found
+# again by content: a few of them, least recently used first out.
+_HANDLES = {}
+_MAX_HANDLES = 4
+
+
+def _handle(T, R):
+    import hashlib
+
+    T = np.ascontiguousarray(T, np.float32)
+    R = np.ascontiguousarray(R, np.float32)
+    key = (T.shape, hashlib.blake2b(T.data, digest_size=16).digest(), hashlib.blake2b(R.data, digest_size=16).digest())
+    dp = _HANDLES.pop(key, None)
+    if dp is None:
+        S, A, _ = T.shape
+        dp = DPBatch([(S, A, csr_from_dense(T), R)])
+        dp.nnz = int(dp._keep["csr_ptr"][-1])
+        while len(_HANDLES) >= _MAX_HANDLES:
+            _HANDLES.pop(next(iter(_HANDLES))).close()
+    _HANDLES[key] = dp  # most recently used last
+    return dp
+
+
+def release_handles():
+    """Frees the cached device handles (they are also freed at interpreter exit)."""
+    while _HANDLES:
+        _HANDLES.popitem()[1].close()
+
 
 def _vi_rule(T_size, nnz, sparse_n_states_threshold, sparse_nnz_per_threshold):
     """reference infinite_horizon.py:28-36."""
@@ -24,15 +53,14 @@ def discounted_value_iteration(T, R, gamma=0.99, epsilon=1e-3, max_abs_value=Non
                                sparse_n_states_threshold=300 * 3 * 300, sparse_nnz_per_threshold=0.2):
     """reference infinite_horizon.py:14-44.  Returns (Q [S,A], V [S]) float32, or None."""
     S, A, _ = T.shape
-    csr = csr_from_dense(T)
-    scheme = _vi_rule(T.size, len(csr[1]), sparse_n_states_threshold, sparse_nnz_per_threshold)
-    with DPBatch([(S, A, csr, np.asarray(R, np.float32))]) as dp:
-        try:
-            Q, V, _ = dp.value_iteration(gamma, epsilon, scheme, DP_MAX_ITERATION, max_abs_value)
-        except L.CmdpError as e:
-            if e.code == L.ERR_MAX_VALUE:
-                return None
-            raise
+    dp = _handle(T, R)
+    scheme = _vi_rule(T.size, dp.nnz, sparse_n_states_threshold, sparse_nnz_per_threshold)
+    try:
+        Q, V, _ = dp.value_iteration(gamma, epsilon, scheme, DP_MAX_ITERATION, max_abs_value)
+    except L.CmdpError as e:
+        if e.code == L.ERR_MAX_VALUE:
+            return None
+        raise
     return Q.reshape(S, A), V
 
 
@@ -40,11 +68,10 @@ def discounted_policy_evaluation(T, R, pi, gamma=0.99, epsilon=1e-7, sparse_n_st
                                  sparse_nnz_per_threshold=0.2):
     """reference infinite_horizon.py:47-64."""
     S, A, _ = T.shape
-    csr = csr_from_dense(T)
-    scheme = (L.SCHEME_JACOBI if (S > sparse_n_states_threshold and len(csr[1]) / T.size < sparse_nnz_per_threshold)
+    dp = _handle(T, R)
+    scheme = (L.SCHEME_JACOBI if (S > sparse_n_states_threshold and dp.nnz / T.size < sparse_nnz_per_threshold)
               else L.SCHEME_GAUSS_SEIDEL)
-    with DPBatch([(S, A, csr, np.asarray(R, np.float32))]) as dp:
-        Q, V, _ = dp.policy_evaluation(np.asarray(pi, np.float32).ravel(), gamma, epsilon, scheme, DP_MAX_ITERATION)
+    Q, V, _ = dp.policy_evaluation(np.asarray(pi, np.float32).ravel(), gamma, epsilon, scheme, DP_MAX_ITERATION)
     return Q.reshape(S, A), V
 
 
@@ -52,8 +79,7 @@ def episodic_value_iteration(H, T, R, max_value=None):
     """reference finite_horizon.py:11-26.  Returns (Q [H+1,S,A], V [H+1,S]) or None when a value exceeds
     `max_value`."""
     S, A, _ = T.shape
-    with DPBatch([(S, A, csr_from_dense(T), np.asarray(R, np.float32))]) as dp:
-        Q, V = dp.episodic_value_iteration(int(H))
+    Q, V = _handle(T, R).episodic_value_iteration(int(H))
     Q, V = Q.reshape(H + 1, S, A), V.reshape(H + 1, S)
     if max_value is not None and (V > max_value).any():
         return None
@@ -63,8 +89,7 @@ def episodic_value_iteration(H, T, R, max_value=None):
 def episodic_policy_evaluation(H, T, R, policy):
     """reference finite_horizon.py:29-42; policy [H,S,A]."""
     S, A, _ = T.shape
-    with DPBatch([(S, A, csr_from_dense(T), np.asarray(R, np.float32))]) as dp:
-        Q, V = dp.episodic_policy_evaluation(np.asarray(policy, np.float32).ravel(), int(H))
+    Q, V = _handle(T, R).episodic_policy_evaluation(np.asarray(policy, np.float32).ravel(), int(H))
     return Q.reshape(H + 1, S, A), V.reshape(H + 1, S)
 
 

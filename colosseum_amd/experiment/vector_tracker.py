@@ -4,8 +4,8 @@ The reference computes its 18 indicators with Python/numpy *scalars* (agent_mdp_
 `np.float32`, some `np.float64`, some plain Python floats, and under NEP 50 the type of every intermediate decides the
 rounding of every operation (e.g. the cumulative regret of an episodic run is accumulated in float32, and in the
 continuous setting the type even differs between instances, because the stationary distribution of a chain with one
-recurrent class smaller than the state space is float32, markov_chain.py:98).  The per-instance tracker objects of
-`batched_loop` reproduce that by running the scalar code; this module reproduces it for B instances per numpy call:
+recurrent class smaller than the state space is float32, markov_chain.py:98).  This module reproduces that for B
+instances per numpy call (B = 1 is `MDPLoop`):
 
 * `MP` ("mixed precision") is an array of B emulated numpy scalars, each carrying its kind (Python float = weak,
   float32, float64).  A binary operation promotes like NEP 50 and rounds to float32 where the scalar code would have
@@ -15,7 +15,8 @@ recurrent class smaller than the state space is float32, markov_chain.py:98).  T
 * `BatchLog` / `LogTable` keep the rows column-wise ([n_logs, B] per indicator); `LogTable` is the per-instance
   sequence-of-dicts view (`InMemoryLogger.data`), `BatchLog.csv_text` the CSVLogger text.
 
-tests/test_vector_tracker.py drives these and the scalar trackers with the same inputs and requires identical rows."""
+tests/test_vector_tracker.py drives these with the inputs of golden G15 and requires the rows the reference's own
+indicator code produced from them: same values, same numpy types, same training freeze."""
 from time import time
 from typing import Dict, List, Sequence
 
@@ -279,6 +280,7 @@ class _VectorTracker:
             optimal_normalized_cumulative_expected_reward=n(t, opt),
             steps_per_second=MP(np.full(self.B, t / max(time() - self.timer, 1e-9)), WEAK),
         )
+        self.last_cols = cols  # un-rounded (MDPLoop.run returns them as `last_logs`)
         self.log.append(t, {k: v.round5() for k, v in cols.items()})
 
     def _after_log(self, t: int, T: int, nregret: MP, atol: float, recompute):

@@ -22,6 +22,7 @@ Fixture groups:
   G6  episodic/continuous diameter + value-norm recomputed by the reference here (small cases)
   G7  MDPLoop + QLearningEpisodic logger rows and action stream (config C1, plumbing)
   G14 emission maps (StateInfo, OneHotEncoding) and GaussianUncorrelated noise
+  G15 the reference's MDPLoop indicator code on synthetic inputs (value / type of every logged scalar, training freeze)
   G13 CustomMDP (user-given T_0, T, R)
   G12 RiverSwim / SimpleGrid / Taxi: structure, DP values, trajectories
   G10 MDPLoop + QLearningContinuous logger rows (continuous-setting regret via stationary distributions)
@@ -862,7 +863,206 @@ def g14():
     save("G14_emission_maps", **arrays)
 
 
-GROUPS = dict(G14=g14, G13=g13, G12=g12, G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11)
+def g15():
+    """The reference's OWN performance-indicator code (agent_mdp_interaction.py:304-578, indicators.py:29-45) driven with
+    synthetic inputs: values at in-episode time zero of a sequence of agent policies / average rewards of numpy scalar
+    types float32 and float64, start states, cumulative rewards.  Outputs: the 17 indicator columns the loop writes
+    (steps_per_second excluded) with their numpy types, and the is_training flag after every row.  Pins
+    colosseum_amd.experiment.vector_tracker (and through it MDPLoop and the batched loops) on the CPU."""
+    from colosseum.experiment import agent_mdp_interaction as ami
+    from colosseum.experiment import indicators as ind
+    from colosseum.utils.acme.in_memory_logger import InMemoryLogger
+
+    class Agent:
+        current_optimal_stochastic_policy = None
+
+    def new_loop(mdp, episodic, n_check):
+        loop = object.__new__(ami.MDPLoop)
+        loop.logger = InMemoryLogger()
+        loop._mdp, loop._agent, loop._episodic = mdp, Agent(), episodic
+        loop._n_steps_to_check_for_agent_optimality = n_check
+        loop._reset_run_variables()
+        return loop
+
+    def drive(loop, T, events, set_inputs):
+        """`events`: (t, payload, cumulative reward, steps since last log, inside the loop?) -- the lines of
+        MDPLoop.run that sit between two steps (:259-288), around the reference's own methods."""
+        flags = []
+        for t, payload, cum, n_since, in_loop in events:
+            set_inputs(loop, payload)
+            loop._cumulative_reward = cum
+            loop._n_steps_since_last_log = n_since
+            loop._update_performance_logs(t)
+            if in_loop:
+                loop._latest_expected_regrets.append(loop._normalized_regret)
+                if len(loop._latest_expected_regrets) > loop._n_steps_to_check_for_agent_optimality:
+                    loop._latest_expected_regrets.pop(0)
+                if loop._is_training and t > 0.2 * T and loop._is_policy_optimal():
+                    loop._is_training = False
+            flags.append(bool(loop._is_training))
+        return flags
+
+    def rows_of(loop):
+        keys = sorted(k for k in loop.logger.data[0] if k != "steps_per_second")
+        vals = np.array([[float(r[k]) for k in keys] for r in loop.logger.data], np.float64)
+        kinds = np.array([[1 if isinstance(r[k], np.float32) else 2 if isinstance(r[k], np.floating) else 0 for k in keys]
+                          for r in loop.logger.data], np.int8)
+        return keys, vals, kinds
+
+    arrays, cases = {}, []
+    # ---- episodic -------------------------------------------------------------------------------------------------
+    real_pe = ind.episodic_policy_evaluation
+    ind.episodic_policy_evaluation = lambda H, T, R, policy: (None, policy)  # the "policy" carries V of the agent's policy
+    try:
+        for seed in range(3):
+            rng = np.random.RandomState(100 + seed)
+            B, H, n_check, T, log_every = 6, 5 + seed, 4, 4000, 100
+            for b in range(B):
+                S = int(rng.randint(5, 12))
+                worst0 = rng.rand(S).astype(np.float32)
+                rand0 = (worst0 + rng.rand(S) * 2).astype(np.float32)
+                opt0 = (rand0 + 0.1 + rng.rand(S) * 3).astype(np.float32)
+                k = int(rng.randint(1, 4))
+                ss = rng.choice(S, k, replace=False)
+                pp = rng.dirichlet(np.ones(k))
+                ssd = np.zeros(S)
+                ssd[ss] = pp
+
+                class M:
+                    pass
+
+                m = M()
+                m.H, m.T, m.R = H, None, None
+                m.starting_state_distribution = ssd
+                m.optimal_value_functions = (None, opt0[None])
+                m.starting_nodes = [int(x) for x in ss]
+                m.node_to_index = {x: x for x in m.starting_nodes}
+                m.last_starting_node = m.starting_nodes[0]
+                m.parameters = {}
+                m.is_episodic = lambda: True
+                m.get_minimal_regret_for_starting_node = lambda n, o=opt0, w=worst0: o[n] - w[n]
+
+                def avg(v):  # mdp/base.py episodic_*_average_reward: sum over the start sampler's (node, prob) pairs / H
+                    acc = 0.0
+                    for sn, p in zip(ss.tolist(), pp.tolist()):
+                        acc += p * v[sn]
+                    return acc / H
+
+                m.episodic_optimal_average_reward = avg(opt0)
+                m.episodic_worst_average_reward = avg(worst0)
+                m.episodic_random_average_reward = avg(rand0)
+                # the agent's value improves towards optimal; instances 0 and 3 reach it exactly and get frozen
+                events, frozen_V = [], None
+                ts = list(range(log_every, T, log_every)) + [T - 1]
+                cum = 0.0
+                for i, t in enumerate(ts):
+                    frac = min(1.0, i / (0.5 * len(ts)))
+                    V0 = (worst0 + (opt0 - worst0) * np.float32(frac) * (1 if b in (0, 3) else 0.97)).astype(np.float32)
+                    if b in (0, 3) and frac >= 1.0:
+                        V0 = opt0.copy()
+                    start = int(ss[rng.randint(k)])
+                    cum += float(rng.rand() * log_every)
+                    events.append((t, (V0, start), cum, log_every if i else log_every, t != T - 1))
+                loop = new_loop(m, True, n_check)
+                state = {"frozenV": None}
+
+                def set_inputs(lp, payload, st=state):
+                    V0, start = payload
+                    if not lp._is_training:  # a frozen agent's policy no longer changes
+                        if st["frozenV"] is None:
+                            st["frozenV"] = V0
+                        V0 = st["frozenV"]
+                    lp._agent.current_optimal_stochastic_policy = V0[None]
+                    lp._mdp.last_starting_node = start
+
+                used_V = []
+
+                def set_and_record(lp, payload, _s=set_inputs, _u=used_V):
+                    _s(lp, payload)
+                    _u.append(lp._agent.current_optimal_stochastic_policy[0].copy())
+
+                flags = drive(loop, T, events, set_and_record)
+                keys, vals, kinds = rows_of(loop)
+                key = f"e{len(cases)}_"
+                arrays[key + "opt0"], arrays[key + "worst0"], arrays[key + "rand0"] = opt0, worst0, rand0
+                arrays[key + "start_states"], arrays[key + "start_probs"] = ss.astype(np.int64), pp
+                arrays[key + "t"] = np.array([e[0] for e in events], np.int64)
+                arrays[key + "V0"] = np.stack(used_V)
+                arrays[key + "last_start"] = np.array([e[1][1] for e in events], np.int64)
+                arrays[key + "cum"] = np.array([e[2] for e in events])
+                arrays[key + "n_since"] = np.array([e[3] for e in events], np.int64)
+                arrays[key + "in_loop"] = np.array([e[4] for e in events], np.bool_)
+                arrays[key + "rows"], arrays[key + "kinds"] = vals, kinds
+                arrays[key + "is_training"] = np.array(flags, np.bool_)
+                cases.append(dict(setting="episodic", group=seed, H=H, n_check=n_check, T=T, keys=keys))
+    finally:
+        ind.episodic_policy_evaluation = real_pe
+    # ---- continuous ------------------------------------------------------------------------------------------------
+    real_ar = ami.get_average_reward
+    ami.get_average_reward = lambda T, R, policy, start: policy  # the "policy" carries the average reward (numpy scalar)
+    try:
+        for seed in range(3):
+            rng = np.random.RandomState(200 + seed)
+            B, n_check, T, log_every = 6, 4, 3000, 100
+            for b in range(B):
+                def scalar(x, kind):
+                    return np.float32(x) if kind == 1 else np.float64(x)
+
+                kinds3 = rng.randint(1, 3, 3)
+                worst = scalar(rng.rand() * 0.2, kinds3[0])
+                rand = scalar(float(worst) + 0.05 + rng.rand() * 0.2, kinds3[1])
+                opt = scalar(float(rand) + 0.1 + rng.rand() * 0.5, kinds3[2])
+
+                class M:
+                    pass
+
+                m = M()
+                m.T = m.R = None
+                m.optimal_average_reward, m.worst_average_reward, m.random_average_reward = opt, worst, rand
+                m.node_to_index = {0: 0}
+                m.cur_node = 0
+                m.parameters = {}
+                m.is_episodic = lambda: False
+                ts = list(range(log_every, T, log_every)) + [T - 1]
+                events, cum = [], 0.0
+                for i, t in enumerate(ts):
+                    frac = min(1.0, i / (0.5 * len(ts)))
+                    kind = int(rng.randint(1, 3))  # float32 when the chain has one recurrent class smaller than S
+                    a = float(worst) + (float(opt) - float(worst)) * frac * (1 if b in (1, 4) else 0.9)
+                    if b in (1, 4) and frac >= 1.0:
+                        a = float(opt) - (2e-4 if b == 4 else 0.0)  # within the 1e-3 snap-to-zero of the regret
+                    cum += float(rng.rand() * log_every)
+                    events.append((t, scalar(a, kind), cum, log_every, t != T - 1))
+                loop = new_loop(m, False, n_check)
+                used, state = [], {"frozen": None}
+
+                def set_inputs(lp, payload, st=state, _u=used):
+                    lp._agent.current_optimal_stochastic_policy = payload
+                    _u.append(payload)
+
+                flags = drive(loop, T, events, set_inputs)
+                keys, vals, kinds = rows_of(loop)
+                key = f"c{len(cases)}_"
+                arrays[key + "baselines"] = np.array([float(opt), float(worst), float(rand)])
+                arrays[key + "baseline_kinds"] = np.array([kinds3[2], kinds3[0], kinds3[1]], np.int8)
+                arrays[key + "t"] = np.array([e[0] for e in events], np.int64)
+                arrays[key + "avg"] = np.array([float(x) for x in used])
+                arrays[key + "avg_kinds"] = np.array([1 if isinstance(x, np.float32) else 2 for x in used], np.int8)
+                arrays[key + "cum"] = np.array([e[2] for e in events])
+                arrays[key + "n_since"] = np.array([e[3] for e in events], np.int64)
+                arrays[key + "in_loop"] = np.array([e[4] for e in events], np.bool_)
+                arrays[key + "rows"], arrays[key + "kinds"] = vals, kinds
+                arrays[key + "is_training"] = np.array(flags, np.bool_)
+                cases.append(dict(setting="continuous", group=seed, n_check=n_check, T=T, keys=keys))
+    finally:
+        ami.get_average_reward = real_ar
+    n_frozen = sum(int(not arrays[k][-1]) for k in arrays if k.endswith("is_training"))
+    print(f"  G15: {len(cases)} synthetic runs through the reference's indicator code, {n_frozen} of them frozen by _is_policy_optimal")
+    arrays["cases"] = np.array(json.dumps(cases))
+    save("G15_indicators", **arrays)
+
+
+GROUPS = dict(G15=g15, G14=g14, G13=g13, G12=g12, G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

@@ -1,27 +1,22 @@
-"""The batched (numpy-vectorised) indicator code must reproduce the scalar MDPLoop indicator code row by row, value by
-value AND type by type (float32 / float64 decide the rounding of the reference's scalars under NEP 50).  CPU only."""
+"""colosseum_amd.experiment.vector_tracker (the indicator code behind MDPLoop and the batched loops) against the
+REFERENCE's own indicator code: golden G15 holds synthetic inputs and what agent_mdp_interaction.py:304-578 made of
+them -- 17 logged columns per row, the numpy TYPE of every value (float32 / float64 decide the rounding of the
+reference's scalars under NEP 50) and the training flag after every row, including runs that `_is_policy_optimal`
+freezes.  CPU only."""
 import csv
 import io
+import json
 
 import numpy as np
 import pytest
 
-from colosseum_amd.experiment.batched_loop import _ContinuousTracker, _ContinuousView, _InstanceView, _Tracker
+from conftest import load_golden
 from colosseum_amd.experiment.vector_tracker import (F32, F64, WEAK, MP, ContinuousVectorTracker, EpisodicVectorTracker)
 
 
 def _same(a, b, key):
     assert type(a) is type(b) or (isinstance(a, (int, np.integer)) and isinstance(b, (int, np.integer))), (key, type(a), type(b))
     assert (a == b) or (np.isnan(a) and np.isnan(b)), (key, a, b)
-
-
-def _ring(tr, t, T, in_loop):
-    if in_loop:  # agent_mdp_interaction.py:265-288
-        tr._latest_expected_regrets.append(tr._normalized_regret)
-        if len(tr._latest_expected_regrets) > tr._n_steps_to_check_for_agent_optimality:
-            tr._latest_expected_regrets.pop(0)
-        if tr._is_training and t > 0.2 * T and tr._is_policy_optimal():
-            tr._is_training = False
 
 
 def test_mp_arithmetic_matches_numpy_scalars():
@@ -54,150 +49,99 @@ def test_mp_arithmetic_matches_numpy_scalars():
         _same(got.scalar(i), (float(w.v[i]) - 5 * np.float32(x32.v[i])) / np.float32(x32.v[i]), i)
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2])
-def test_episodic_vector_tracker_equals_scalar_trackers(seed):
-    rng = np.random.default_rng(seed)
-    B, H, n_check, T, log_every = 7, 6, 4, 4000, 100
-    sizes = rng.integers(5, 12, B)
+def _groups(setting):
+    z, cases = load_golden("G15_indicators")
+    by = {}
+    for i, c in enumerate(cases):
+        if c["setting"] == setting:
+            by.setdefault(c["group"], []).append((("e" if setting == "episodic" else "c") + f"{i}_", c))
+    return z, by
+
+
+def _check_rows(z, members, tables, flags_seen):
+    for b, (key, c) in enumerate(members):
+        want, kinds = z[key + "rows"], z[key + "kinds"]
+        assert len(tables[b]) == len(want)
+        for i, row in enumerate(tables[b]):
+            for j, name in enumerate(c["keys"]):
+                got = row[name]
+                if name == "steps":
+                    assert int(got) == int(want[i, j])
+                    continue
+                assert float(got) == want[i, j] or (np.isnan(got) and np.isnan(want[i, j])), (key, i, name, got, want[i, j])
+                assert (1 if isinstance(got, np.float32) else 2) == kinds[i, j], (key, i, name, type(got), kinds[i, j])
+        np.testing.assert_array_equal(np.array([f[b] for f in flags_seen]), z[key + "is_training"], err_msg=key)
+
+
+def test_episodic_vector_tracker_equals_reference_indicator_code():
+    z, by = _groups("episodic")
+    assert len(by) == 3
+    n_frozen = 0
+    for g, members in by.items():
+        c0 = members[0][1]
+        sizes = [len(z[k + "opt0"]) for k, _ in members]
+        off = np.concatenate([[0], np.cumsum(sizes)])
+        flat = [np.concatenate([z[k + n] for k, _ in members]) for n in ("opt0", "worst0", "rand0")]
+        starts = [(z[k + "start_states"], z[k + "start_probs"]) for k, _ in members]
+        vt = EpisodicVectorTracker(c0["H"], off, *flat, starts, c0["n_check"])
+        ts = z[members[0][0] + "t"]
+        flags = []
+        for i, t in enumerate(ts):
+            V0 = np.concatenate([z[k + "V0"][i] for k, _ in members])
+            last = np.array([z[k + "last_start"][i] for k, _ in members])
+            cum = np.array([z[k + "cum"][i] for k, _ in members])
+            vt.update(int(t), c0["T"], V0, last, cum, int(z[members[0][0] + "n_since"][i]), bool(z[members[0][0] + "in_loop"][i]))
+            flags.append(vt.is_training.copy())
+        _check_rows(z, members, vt.tables(), flags)
+        n_frozen += int((~vt.is_training).sum())
+    assert n_frozen >= 4  # the freeze path of _is_policy_optimal is exercised
+
+
+def test_continuous_vector_tracker_equals_reference_indicator_code():
+    z, by = _groups("continuous")
+    assert len(by) == 3
+    n_frozen = 0
+    for g, members in by.items():
+        c0 = members[0][1]
+
+        def mp(j):
+            return MP.from_scalars([np.float32(z[k + "baselines"][j]) if z[k + "baseline_kinds"][j] == 1
+                                    else np.float64(z[k + "baselines"][j]) for k, _ in members])
+
+        vt = ContinuousVectorTracker(mp(0), mp(1), mp(2), c0["n_check"])
+        ts = z[members[0][0] + "t"]
+        flags = []
+        for i, t in enumerate(ts):
+            def averages(need, i=i):
+                return [np.float32(z[k + "avg"][i]) if z[k + "avg_kinds"][i] == 1 else np.float64(z[k + "avg"][i])
+                        for b, (k, _) in enumerate(members) if need[b]]
+            cum = np.array([z[k + "cum"][i] for k, _ in members])
+            vt.update(int(t), c0["T"], averages, cum, int(z[members[0][0] + "n_since"][i]), bool(z[members[0][0] + "in_loop"][i]))
+            flags.append(vt.is_training.copy())
+        _check_rows(z, members, vt.tables(), flags)
+        n_frozen += int((~vt.is_training).sum())
+    assert n_frozen >= 4
+
+
+def test_csv_text_matches_dictwriter():
+    """BatchLog.csv_text = what csv.DictWriter prints for the same rows (the reference's CSVLogger)."""
+    z, by = _groups("episodic")
+    members = by[0]
+    c0 = members[0][1]
+    sizes = [len(z[k + "opt0"]) for k, _ in members]
     off = np.concatenate([[0], np.cumsum(sizes)])
-    worst0 = rng.random(off[-1]).astype(np.float32)
-    rand0 = (worst0 + rng.random(off[-1]) * 2).astype(np.float32)
-    opt0 = (rand0 + 0.1 + rng.random(off[-1]) * 3).astype(np.float32)
-    starts = []
-    for b in range(B):
-        k = int(rng.integers(1, 4))
-        ss = rng.choice(sizes[b], k, replace=False)
-        pp = rng.dirichlet(np.ones(k))
-        starts.append((ss.astype(np.int64), pp))
-    vt = EpisodicVectorTracker(H, off, opt0, worst0, rand0, starts, n_check)
-    scal = []
-    for b in range(B):
-        sl = slice(off[b], off[b + 1])
-        view = _InstanceView(H, starts[b][0], starts[b][1], opt0[sl], worst0[sl], rand0[sl])
-        ssd = np.zeros(sizes[b])
-        ssd[starts[b][0]] = starts[b][1]
-        tr = _Tracker(view, ssd, n_check)
-        tr._reset_run_variables()
-        scal.append(tr)
-    vt.reset()
-    V0 = rand0.copy()
-    cum = np.zeros(B)
-    logs = list(range(log_every, T, log_every)) + [T - 1]
-    n_since = 0
-    for li, t in enumerate(logs):
-        in_loop = t != T - 1
-        # agents improve; instances 0..3 become optimal (exactly, or within the tolerance of the optimality check)
-        frozen = ~vt.is_training
-        for b in range(B):
-            if frozen[b]:
-                continue
-            sl = slice(off[b], off[b + 1])
-            if b < 2 and li > 12:
-                V0[sl] = opt0[sl]
-            elif b < 4 and li > 15:
-                V0[sl] = opt0[sl] - np.float32(1e-6) * rng.random(sizes[b]).astype(np.float32)
-            else:
-                V0[sl] = V0[sl] + (opt0[sl] - V0[sl]) * np.float32(0.1 * rng.random())
-        cum = cum + rng.random(B) * log_every
-        n_since = log_every if li else log_every + 0
-        start = np.array([rng.choice(starts[b][0]) for b in range(B)])
-        vt.update(t, T, V0.copy(), start, cum, n_since, in_loop)
-        for b, tr in enumerate(scal):
-            tr._mdp.last_starting_node = int(start[b])
-            tr.set_evaluation(V0[off[b]:off[b + 1]].copy())
-            tr._cumulative_reward = float(cum[b])
-            tr._n_steps_since_last_log = n_since
-            tr._update_performance_logs(t)
-            _ring(tr, t, T, in_loop)
-        assert [tr._is_training for tr in scal] == vt.is_training.tolist(), t
-    assert not vt.is_training[:2].any() and vt.is_training[4:].all()
+    flat = [np.concatenate([z[k + n] for k, _ in members]) for n in ("opt0", "worst0", "rand0")]
+    vt = EpisodicVectorTracker(c0["H"], off, *flat, [(z[k + "start_states"], z[k + "start_probs"]) for k, _ in members], c0["n_check"])
+    for i, t in enumerate(z[members[0][0] + "t"][:7]):
+        vt.update(int(t), c0["T"], np.concatenate([z[k + "V0"][i] for k, _ in members]),
+                  np.array([z[k + "last_start"][i] for k, _ in members]), np.array([z[k + "cum"][i] for k, _ in members]),
+                  int(z[members[0][0] + "n_since"][i]), True)
     tables = vt.tables()
-    text = vt.log.text_columns()
-    for b, tr in enumerate(scal):
-        assert len(tables[b]) == len(tr.logger.data) == len(logs)
-        for got, ref in zip(tables[b], tr.logger.data):
-            assert sorted(got) == sorted(ref)
-            for k in ref:
-                if k != "steps_per_second":
-                    _same(got[k], ref[k], (b, k, ref["steps"]))
-        # CSV text of the instance == csv.DictWriter on the scalar rows
+    for b in range(len(members)):
+        rows = list(tables[b])
         buf = io.StringIO()
-        w = csv.DictWriter(buf, fieldnames=sorted(tr.logger.data[0]))
+        w = csv.DictWriter(buf, fieldnames=sorted(rows[0].keys()))
         w.writeheader()
-        for r in tr.logger.data:
-            w.writerow({k: np.array(v) for k, v in r.items()})
-        drop = lambda s: [",".join(c for i, c in enumerate(line.split(",")) if i != sorted(r).index("steps_per_second"))
-                          for line in s.split("\r\n")]
-        assert drop(vt.log.csv_text(b, text)) == drop(buf.getvalue())
-
-
-@pytest.mark.parametrize("seed", [0, 1])
-def test_continuous_vector_tracker_equals_scalar_trackers(seed):
-    rng = np.random.default_rng(100 + seed)
-    B, n_check, T, log_every = 9, 3, 3000, 100
-    def scalar(x, k):
-        return np.float32(x) if k == 1 else np.float64(x)
-    opt = [scalar(0.6 + 0.3 * rng.random(), rng.integers(1, 3)) for _ in range(B)]
-    worst = [scalar(0.05 * rng.random(), rng.integers(1, 3)) for _ in range(B)]
-    rand = [scalar(0.2 + 0.1 * rng.random(), rng.integers(1, 3)) for _ in range(B)]
-    vt = ContinuousVectorTracker(MP.from_scalars(opt), MP.from_scalars(worst), MP.from_scalars(rand), n_check)
-    scal = []
-    for b in range(B):
-        tr = _ContinuousTracker(_ContinuousView(opt[b], worst[b], rand[b], {}), n_check)
-        tr._reset_run_variables()
-        scal.append(tr)
-    vt.reset()
-    cum = np.zeros(B)
-    logs = list(range(log_every, T, log_every)) + [T - 1]
-    calls = []
-    for li, t in enumerate(logs):
-        in_loop = t != T - 1
-        avgs = []
-        for b in range(B):
-            k = rng.integers(1, 3)  # the type of the agent's average reward changes with the chain structure
-            if b < 3 and li > 8:
-                x = float(opt[b]) - (0.0 if b == 0 else 5e-4 * rng.random())  # within the 1e-3 snap of the regret
-            elif b == 3 and li > 8:
-                x = float(opt[b]) + 0.01  # negative regret -> clipped to the int 0
-            else:
-                x = float(rand[b]) + (float(opt[b]) - float(rand[b])) * min(1.0, li / 20) * rng.random()
-            avgs.append(scalar(x, k))
-        cum = cum + rng.random(B) * log_every
-        n_since = log_every
-
-        def averages(need, avgs=avgs):
-            calls.append(need.copy())
-            return [avgs[b] for b in np.flatnonzero(need)]
-
-        was_training = vt.is_training.copy()
-        vt.update(t, T, averages, cum, n_since, in_loop)
-        for b, tr in enumerate(scal):
-            tr._avg = avgs[b]
-            tr._cumulative_reward = float(cum[b])
-            tr._n_steps_since_last_log = n_since
-            tr._update_performance_logs(t)
-            _ring(tr, t, T, in_loop)
-        assert [tr._is_training for tr in scal] == vt.is_training.tolist(), t
-    assert not vt.is_training[:4].any() and vt.is_training[4:].all()
-    assert not calls[-1][:4].any()  # frozen instances are no longer evaluated
-    for b, tr in enumerate(scal):
-        for got, ref in zip(vt.tables()[b], tr.logger.data):
-            for k in ref:
-                if k != "steps_per_second":
-                    _same(got[k], ref[k], (b, k, ref["steps"]))
-
-
-@pytest.mark.timeout(300)
-def test_parallel_csv_formatting_equals_serial():
-    from colosseum_amd.experiment.vector_tracker import BatchLog, csv_texts_parallel
-
-    B, n = 24, 200
-    log = BatchLog(B)
-    rng = np.random.default_rng(0)
-    for t in range(n):
-        log.append(t, {f"c{i}": MP(np.round(rng.random(B) * 1000, 5).astype(np.float32 if i % 2 else np.float64),
-                                  F32 if i % 2 else F64) for i in range(5)})
-    tc = log.text_columns()
-    ref = [log.csv_text(b, tc) for b in range(B)]
-    assert csv_texts_parallel([log], 1)[id(log)] == ref
-    assert csv_texts_parallel([log], 3, chunk=5)[id(log)] == ref
+        for r in rows:
+            w.writerow(r)
+        assert vt.log.csv_text(b) == buf.getvalue()

@@ -74,7 +74,13 @@ for k in sorted(names):
                  lds_insts_per_sweep=e["SQ_INSTS_LDS"] / sweeps, salu_insts_per_sweep=e.get("SQ_INSTS_SALU", 0) / sweeps,
                  lds_bank_conflict_frac=e["SQ_LDS_BANK_CONFLICT"] / max(e["SQ_LDS_IDX_ACTIVE"], 1))
         if "SQ_WAVE_CYCLES" in e:
-            e["valu_active_frac"] = e["SQ_ACTIVE_INST_VALU"] / e["SQ_WAVE_CYCLES"]
+            e["wave_cycles_waiting_frac"] = e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"]          # parked: s_waitcnt / barrier
+            e["wave_cycles_issue_stalled_frac"] = e["SQ_WAIT_INST_ANY"] / e["SQ_WAVE_CYCLES"]
+    if "GRBM_GUI_ACTIVE" in e and "SQ_LDS_IDX_ACTIVE" in e:
+        cyc = e["GRBM_GUI_ACTIVE"] / 8  # rocprofv3 sums the 8 XCDs
+        e["kernel_cycles"] = cyc
+        e["lds_idx_active_frac"] = e["SQ_LDS_IDX_ACTIVE"] / (256 * cyc)                     # LDS pipe busy, per CU
+        e["valu_issue_frac_at_2_cycles"] = e["SQ_INSTS_VALU"] * 2 / (1024 * cyc)            # 1024 SIMDs, wave64 fp32 op = 2 cycles
     if len(e) > 1 and ("rollout" in short or "dp_reg" in short):
         kernels.append(e)
 j = dict(build_id=None, tag=tag, kernels=kernels,
