@@ -110,15 +110,17 @@ def _build_models(instances: Sequence[Instance], workers: int):
     return [_build_one(i) for i in instances]
 
 
-def build_shard_models(instances: Sequence[Instance], rank: int = 0, world: int = 1, workers: int = 0) -> Dict[int, Any]:
+def build_shard_models(instances: Sequence[Instance], rank: int = 0, world: int = 1, workers: int = 0,
+                       skip: Optional[Sequence[int]] = None) -> Dict[int, Any]:
     """{global instance index: TabularModel} of this rank's contiguous shard (fork()ed pool: call it before anything
     initialises the HIP runtime or RCCL in this process)."""
     lo, hi = shard_range(len(instances), rank, world)
-    mine = list(range(lo, hi))
+    skip = set(skip or ())
+    mine = [i for i in range(lo, hi) if i not in skip]
     return dict(zip(mine, _build_models([instances[i] for i in mine], workers)))
 
 
-def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_mode, device):
+def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_mode, device, max_time=np.inf):
     L.check(L.load().cmdp_set_device(device))
     stochastic = any(not m.deterministic_rewards for m in models)
     # Beta rewards: sampled on the device in Philox mode (the reference-exact host sampler is a per-step path)
@@ -130,7 +132,9 @@ def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_m
     else:
         agent = BatchedQLearningContinuous(env, seeds, optimization_horizon=n_steps, **agent_kwargs)
         loop = BatchedContinuousLoop(env, agent)
-    rows = loop.run(n_steps, log_every)
+    rows = loop.run(n_steps, log_every, max_time)
+    for b, table in enumerate(rows):  # what MDPLoop.run returns first: where the time limit froze training (-1: it did not)
+        table.last_training_step = int(loop.last_training_step[b])
     agent.close()
     env.close()
     return rows
@@ -139,15 +143,19 @@ def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_m
 def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, rank: int = 0, world: int = 1,
                   agent_configs: Optional[Dict[str, Dict[str, Any]]] = None, rng_mode: int = L.RNG_MT_COMPAT,
                   device: int = 0, max_concurrent_groups: int = 6, build_workers: int = 0, progress=None,
-                  max_batch: int = 128, models: Optional[Dict[int, Any]] = None):
+                  max_batch: int = 128, models: Optional[Dict[int, Any]] = None, max_time: float = np.inf,
+                  skip: Optional[Sequence[int]] = None):
     """Runs this rank's contiguous shard; returns {global instance index: logger rows}.  `models` = the shard's
     models from `build_shard_models` (a caller that must initialise RCCL between the fork()ed build and the first HIP
-    call builds them itself)."""
+    call builds them itself).  `max_time`: the experiment's `max_interaction_time_s` (training of an instance is frozen
+    once its batch has run that long, agent_mdp_interaction.py:160-177).  `skip`: global indices not to run -- instances
+    whose log file already exists (`unfinished_instances`), as the reference's resume does."""
     agent_configs = agent_configs or DEFAULT_AGENT_CONFIGS
     lo, hi = shard_range(len(instances), rank, world)
-    mine = list(range(lo, hi))
+    skip = set(skip or ())
+    mine = [i for i in range(lo, hi) if i not in skip]
     if models is None:
-        models = build_shard_models(instances, rank, world, build_workers)
+        models = build_shard_models(instances, rank, world, build_workers, skip)
     groups: Dict[tuple, List[int]] = {}
     from .hardness import _vi_rule
 
@@ -165,7 +173,7 @@ def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, r
         ins = instances[idx[0]]
         t0 = time.time()
         rows = _run_group([models[i] for i in idx], [instances[i].seed for i in idx], ins.agent_cls,
-                          agent_configs[ins.agent_cls], n_steps, log_every, rng_mode, device)
+                          agent_configs[ins.agent_cls], n_steps, log_every, rng_mode, device, max_time)
         if progress:
             progress(f"{ins.label}: {len(idx)} instances, S={models[idx[0]].n_states}, H={models[idx[0]].H}, "
                      f"{time.time() - t0:.1f} s")
@@ -215,12 +223,34 @@ def write_csv_logs(folder: str, instances: Sequence[Instance], results: Dict[int
         with open(os.path.join(d, f"seed{ins.seed}_logs.csv"), "w", newline="") as f:
             if isinstance(rows, LogTable):
                 f.write(texts[id(rows.log)][rows.b])
-                continue
-            fields = sorted(rows[0].keys())
-            w = csv.DictWriter(f, fieldnames=fields, extrasaction="ignore")
-            w.writeheader()
-            for r in rows:
-                w.writerow({k: np.array(v) for k, v in r.items()})
+            else:
+                fields = sorted(rows[0].keys())
+                w = csv.DictWriter(f, fieldnames=fields, extrasaction="ignore")
+                w.writeheader()
+                for r in rows:
+                    w.writerow({k: np.array(v) for k, v in r.items()})
+        last = getattr(rows, "last_training_step", -1)
+        if last != -1:  # the ledger run_experiment_instance appends to (experiment_instances.py:218-222)
+            with open(os.path.join(d, "time_exceeded.txt"), "a") as f:
+                f.write(f"last training step at ({last}) for {os.path.join(d, f'seed{ins.seed}_logs.csv')}\n")
+
+
+def log_file(folder: str, ins: Instance) -> str:
+    """ExperimentInstance's log file (experiment_instance.py:67-82)."""
+    return os.path.join(folder, "logs", ins.label, f"seed{ins.seed}_logs.csv")
+
+
+def unfinished_instances(folder: str, instances: Sequence[Instance]) -> List[int]:
+    """Indices of the instances whose log file does not exist yet: the reference only (re-)creates those
+    (`does_log_file_exists`, folder_structuring.py:102), which is how an interrupted benchmark resumes."""
+    return [i for i, ins in enumerate(instances) if not os.path.exists(log_file(folder, ins))]
+
+
+def read_summary(folder: str, ins: Instance) -> np.ndarray:
+    """`summary_vector` of an instance from its log file (instances skipped by a resumed run)."""
+    with open(log_file(folder, ins), newline="") as f:
+        last = list(csv.DictReader(f))[-1]
+    return np.array([float(last["steps"]), float(last["normalized_cumulative_regret"]), float(last["cumulative_reward"])])
 
 
 def summary_vector(rows) -> np.ndarray:

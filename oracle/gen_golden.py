@@ -579,10 +579,36 @@ def g7():
             return a
 
         agent.select_action = select_action
-        loop = MDPLoop(mdp, agent)
+        # the rows go to the in-memory logger AND through the reference's own CSVLogger (utils/acme/csv_logger.py, as
+        # run_experiment_instance sets it up, experiment_instances.py:205-210): its file is the wire format
+        import tempfile
+
+        from colosseum.utils.acme.csv_logger import CSVLogger
+        from colosseum.utils.acme.in_memory_logger import InMemoryLogger
+
+        class Tee:
+            def __init__(self, *loggers):
+                self.loggers = loggers
+
+            def write(self, data):
+                for lg in self.loggers:
+                    lg.write(data)
+
+            def reset(self):
+                self.loggers[0].reset()
+
+            def close(self):
+                for lg in self.loggers:
+                    lg.close()
+
+        tmp = tempfile.mkdtemp()
+        mem = InMemoryLogger()
+        csv_logger = CSVLogger(tmp, add_uid=False, label="prms_0-X____prms_0-Y", file_name=f"seed{mdp_kw['seed']}_logs")
+        loop = MDPLoop(mdp, agent, Tee(mem, csv_logger))
         last_training_step, last_logs = loop.run(T=T, log_every=log_every)
-        rows = [{k: float(v) for k, v in r.items() if k != "steps_per_second"} for r in loop.logger.data]
-        cases.append(dict(mdp_cls=mdp_cls, mdp_kwargs=mdp_kw, agent="QLearningEpisodic",
+        csv_text = open(csv_logger.file_path, newline="").read()
+        rows = [{k: float(v) for k, v in r.items() if k != "steps_per_second"} for r in mem.data]
+        cases.append(dict(mdp_cls=mdp_cls, mdp_kwargs=mdp_kw, agent="QLearningEpisodic", csv_text=csv_text,
                           agent_kwargs=dict(seed=mdp_kw["seed"], optimization_horizon=T, **hp_used), T=T, log_every=log_every,
                           last_training_step=int(last_training_step), rows=rows, actions=actions,
                           Q_final=np.asarray(agent._mdp_model.Q, np.float64).tolist(),  # float32 values, exact in JSON

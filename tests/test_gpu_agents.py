@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, assert_csv_matches
 from colosseum_amd import _lib as L
 from colosseum_amd import timestep as ts_
 from colosseum_amd.agents import BatchedQLearningEpisodic
@@ -111,7 +111,11 @@ def test_batched_episodic_loop_matches_reference_logger_rows(need_gpu):
         kw = dict(c["agent_kwargs"])
         seed = kw.pop("seed")
         ag = BatchedQLearningEpisodic(env, [seed, seed, seed], **kw)
-        rows = BatchedEpisodicLoop(env, ag).run(T=c["T"], log_every=c["log_every"])
+        loop = BatchedEpisodicLoop(env, ag)
+        rows = loop.run(T=c["T"], log_every=c["log_every"])
+        assert (loop.last_training_step == -1).all()
+        for b in range(3):  # the batched runner's CSV text against the file the reference's own CSVLogger wrote
+            assert_csv_matches(loop.vt.log.csv_text(b), c["csv_text"])
         for inst in rows:
             assert len(inst) == len(c["rows"])
             for got, ref in zip(inst, c["rows"]):

@@ -66,3 +66,96 @@ def test_batched_run_equals_per_instance_host_loop(need_gpu):
                 if k != "steps_per_second":
                     assert float(got[k]) == pytest.approx(float(ref[k]), rel=1e-6, abs=1e-5), (ins.label, ins.seed, k)
         mdp.close()
+
+
+def test_time_limit_ledger_and_resume(need_gpu, tmp_path):
+    """Run control of a benchmark: an exhausted time budget freezes training and is recorded in
+    `time_exceeded.txt` next to the log file (experiment_instances.py:218-222), frozen instances keep logging; a second
+    invocation skips the instances whose log file exists (experiment_instance.py:67-82, folder_structuring.py:102)."""
+    instances = bm.enumerate_instances(_configs("benchmark_episodic_quick_test"), n_seeds=1)
+    assert bm.unfinished_instances(str(tmp_path), instances) == [0, 1, 2, 3]
+    # max_time 0: fewer than 0.5 s remain at the first logging step -> training stops there for every instance
+    results = bm.run_instances(instances, n_steps=2000, log_every=500, max_time=0.0)
+    bm.write_csv_logs(str(tmp_path), instances, results)
+    for i, ins in enumerate(instances):
+        assert results[i].last_training_step == 500 and len(results[i]) == 4
+        d = tmp_path / "logs" / ins.label
+        ledger = (d / "time_exceeded.txt").read_text()
+        assert ledger == f"last training step at (500) for {d / f'seed{ins.seed}_logs.csv'}\n"
+    # without a limit nothing is recorded, and the rows differ from the frozen run's (training went on)
+    free = bm.run_instances(instances[:1], n_steps=2000, log_every=500)
+    assert free[0].last_training_step == -1
+    assert free[0][-1]["cumulative_regret"] != results[0][-1]["cumulative_regret"]
+    # resume: everything is on disk -> nothing left to do; remove one file -> exactly that instance is run again
+    assert bm.unfinished_instances(str(tmp_path), instances) == []
+    os.remove(bm.log_file(str(tmp_path), instances[2]))
+    todo = bm.unfinished_instances(str(tmp_path), instances)
+    assert todo == [2]
+    again = bm.run_instances(instances, n_steps=2000, log_every=500, skip=[i for i in range(4) if i not in todo])
+    assert sorted(again) == [2]
+    bm.write_csv_logs(str(tmp_path), instances, again)
+    assert bm.unfinished_instances(str(tmp_path), instances) == []
+    np.testing.assert_array_equal(bm.read_summary(str(tmp_path), instances[2]), bm.summary_vector(again[2]))
+
+
+def test_c4_full_enumeration_of_the_four_default_suites(need_gpu):
+    """Config C4 with the FULL instance enumeration of the reference's four default benchmark suites (every family x gin
+    setting x 20 seeds = 1 000 instances; `benchmark/experiment_config.yml`) at a reduced step count, and one instance of
+    every (suite, MDP class, setting) cross-checked against the per-instance path `GpuMDP` + `MDPLoop` + numpy agent
+    (bit-equal to the reference loop, tests/test_gpu_mdploop.py) where the batch runs reference-exact streams
+    (deterministic rewards -> MT_COMPAT); Beta-reward settings run Philox streams on the device and are compared with
+    the same instance run alone."""
+    from colosseum_amd.experiment import MDPLoop, make_mdp_spec
+    from colosseum_amd.mdp import gpu_mdp
+    from helpers_agents import QLearningContinuous, QLearningEpisodic
+
+    suites = ["benchmark_episodic_ergodic", "benchmark_episodic_communicating",
+              "benchmark_continuous_ergodic", "benchmark_continuous_communicating"]
+    n_steps, log_every = 1500, 500
+    total = checked = invariants = 0
+    settings = set()
+    for suite in suites:
+        allcfg = json.load(open(os.path.join(GOLDEN, "G11_benchmark_configs.json")))[suite]
+        assert allcfg["experiment_config"]["n_seeds"] == 20
+        instances = bm.enumerate_instances(allcfg["mdp_configs"], n_seeds=20)
+        total += len(instances)
+        results = bm.run_instances(instances, n_steps=n_steps, log_every=log_every)
+        assert sorted(results) == list(range(len(instances)))
+        seen = set()
+        for i, ins in enumerate(instances):
+            rows = results[i]
+            assert [r["steps"] for r in rows] == [500, 1000, 1499]
+            last = rows[-1]
+            assert last["cumulative_regret"] >= 0 and last["worst_normalized_cumulative_regret"] == pytest.approx(n_steps, rel=1e-4)
+            assert last["optimal_normalized_cumulative_expected_reward"] == pytest.approx(n_steps - 1, rel=1e-3, abs=2.0)
+            key = (suite, ins.mdp_cls, ins.mdp_scope)
+            settings.add(key)
+            if key in seen:
+                continue
+            seen.add(key)
+            if ins.mdp_kwargs.get("make_reward_stochastic"):
+                # Beta rewards: the batch samples them on the device from the instance's Philox stream (the
+                # reference-exact Beta stream is a per-step host path), so the cross-check is the same instance run
+                # ALONE: a row may not depend on what else is in the device batch
+                alone = bm.run_instances([ins], n_steps=n_steps, log_every=log_every)[0]
+                for got, ref in zip(rows, alone):
+                    for k in ref:
+                        if k != "steps_per_second":
+                            assert got[k] == ref[k] and type(got[k]) is type(ref[k]), (key, ins.seed, k)
+                invariants += 1
+                continue
+            mdp = getattr(gpu_mdp, ins.mdp_cls)(seed=ins.seed, **ins.mdp_kwargs)
+            agent_cls = QLearningEpisodic if ins.agent_cls == "QLearningEpisodic" else QLearningContinuous
+            agent = agent_cls(seed=ins.seed, mdp_specs=make_mdp_spec(mdp), optimization_horizon=n_steps,
+                              **bm.DEFAULT_AGENT_CONFIGS[ins.agent_cls])
+            loop = MDPLoop(mdp, agent)
+            loop.run(T=n_steps, log_every=log_every)
+            for got, ref in zip(rows, loop.logger.data):
+                for k in ref:
+                    if k != "steps_per_second":
+                        assert float(got[k]) == pytest.approx(float(ref[k]), rel=1e-6, abs=1e-5), (key, ins.seed, k)
+            checked += 1
+            mdp.close()
+    print(f"C4: {total} instances over {len(settings)} (suite, class, setting) triples; {checked} cross-checked against "
+          f"the per-instance host loop, {invariants} Beta-reward settings against the instance run alone")
+    assert total == 1000 and len(settings) == 50 and checked == 16 and invariants == 34

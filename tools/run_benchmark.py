@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--max-batch", type=int, default=128, help="instances per device batch (larger groups are split)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0")
+    ap.add_argument("--max-time", type=float, help="seconds of training per instance (default: the experiment's max_interaction_time_s)")
+    ap.add_argument("--overwrite", action="store_true",
+                    help="run every instance; default: skip those whose log file exists, as the reference's resume does")
     args = ap.parse_args()
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
     dist = None
@@ -47,16 +50,19 @@ def main():
     n_steps = args.steps or cfg["n_steps"]
     n_seeds = args.seeds or cfg["n_seeds"]
     log_every = args.log_every or cfg["log_performance_indicators_every"]
+    max_time = args.max_time if args.max_time is not None else float(cfg.get("max_interaction_time_s", float("inf")))
     instances = []
     for k, mdp_cfg in enumerate(benchmarks):
         for ins in bm.enumerate_instances(mdp_cfg, n_seeds):
             ins.mdp_scope = f"b{k}_{ins.mdp_scope}" if len(benchmarks) > 1 else ins.mdp_scope
             instances.append(ins)
+    todo = set(range(len(instances)) if args.overwrite else bm.unfinished_instances(args.out, instances))
+    skip = [i for i in range(len(instances)) if i not in todo]
     t0 = time.time()
     # order matters: (1) host model construction in a fork()ed pool, (2) the process group -- right away and with a
     # generous timeout, so that no rank waits in rendezvous while another is still running its shard, and a rank that
     # dies mid-run is noticed at the gather -- (3) only then the first HIP call of this process
-    models = bm.build_shard_models(instances, rank, world, workers=max(1, min(16, (os.cpu_count() or 1) // world)))
+    models = bm.build_shard_models(instances, rank, world, workers=max(1, min(16, (os.cpu_count() or 1) // world)), skip=skip)
     if world > 1:
         import datetime
 
@@ -70,17 +76,18 @@ def main():
         else:
             dist.init_process_group(args.dist_backend, timeout=timeout)
     results = bm.run_instances(instances, n_steps, log_every, rank, world, device=local, max_concurrent_groups=args.concurrent_groups, max_batch=args.max_batch,
-                               models=models,
+                               models=models, max_time=max_time, skip=skip,
                                progress=lambda msg: print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True))
     t_run = time.time() - t0
     bm.write_csv_logs(args.out, instances, results, workers=max(1, min(32, (os.cpu_count() or 1) // world)))
     print(f"[rank {rank}] instances done in {t_run:.1f} s, logs written in {time.time() - t0 - t_run:.1f} s", file=sys.stderr, flush=True)
     lo, hi = shard_range(len(instances), rank, world)
-    local_vec = np.stack([bm.summary_vector(results[i]) for i in range(lo, hi)]) if hi > lo else np.zeros((0, 3))
+    local_vec = (np.stack([bm.summary_vector(results[i]) if i in results else bm.read_summary(args.out, instances[i])
+                           for i in range(lo, hi)]) if hi > lo else np.zeros((0, 3)))
     allv = gather_instances(local_vec, len(instances), dist,
                             device="cuda" if dist is not None and args.dist_backend == "nccl" else None)
     if rank == 0:
-        print(json.dumps(dict(instances=len(instances), steps_each=n_steps, wall_s=time.time() - t0,
+        print(json.dumps(dict(instances=len(instances), skipped_existing=len(skip), steps_each=n_steps, wall_s=time.time() - t0,
                               agent_steps_per_s=len(instances) * n_steps / (time.time() - t0),
                               mean_normalized_cumulative_regret=float(allv[:, 1].mean()))))
     if dist is not None:
