@@ -3,8 +3,11 @@
 strongly connected components instead of networkx's `attracting_components`: the same sets); the stationary
 distribution of every recurrent class is computed on the GPU by the GTH kernel (`cmdp_gth`).
 
-Deviation, documented: above 500 x 500 the reference switches to ARPACK's shift-invert eigen solver
-(`_eigen_method`, :188-203; parity-unpinned in SURVEY 8c); GTH is used here for every size -- the two agree to ~1e-8."""
+GTH for every size IS the reference's behaviour: above 500 x 500 entries `_get_stationary_distribution`
+(markov_chain.py:206-233) first calls ARPACK's shift-invert solver (`_eigen_method`, :188-203), but when that succeeds the
+function does not return -- it falls through to `sd = _gth_solve_numba(tps)` (:230), which overwrites the result; when it
+fails, the fallback inside the branch is GTH as well.  Golden G9 holds a 576-state chain (S*S > 500*500) produced by the
+reference: its distribution equals the GTH result to 1e-12, not the float32 eigenvector ARPACK returns (1e-8 off)."""
 from typing import Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np

@@ -661,12 +661,15 @@ def g9():
         ("MiniGridEmptyContinuous", dict(seed=0, size=5, p_rand=0.1, n_starting_states=2)),
         ("MiniGridEmptyContinuous", dict(seed=2, size=6)),
         ("MiniGridRoomsContinuous", dict(seed=0, room_size=3, n_rooms=4, p_lazy=0.1, n_starting_states=2)),
+        # 576 states: S*S > 500*500, the branch that goes through ARPACK's shift-invert solver (markov_chain.py:210-228)
+        ("MiniGridEmptyContinuous", dict(seed=1, size=12, p_rand=0.1)),
     ]
     cases, arrays = [], {}
     for cls, kw in specs:
         mdp = CLASSES[cls](**kw)
         key = f"c{len(cases)}_"
         T, R = mdp.transition_matrix_and_rewards
+        T = np.asarray(T.todense() if hasattr(T, "todense") else T)
         info = dict(cls=cls, kwargs=kw, n_states=mdp.n_states,
                     optimal_average_reward=float(mdp.optimal_average_reward),
                     worst_average_reward=float(mdp.worst_average_reward),
