@@ -20,6 +20,7 @@ OPT_DP_KERNEL = 2
 OPT_LDS_GROUPS_PER_CU = 3
 OPT_DIAMETER_WORKSPACE_MB = 4
 OPT_CHAIN_EXACT_ORDER = 5
+OPT_MIXING_PATH = 6
 STAT_DP_KERNEL_MS, STAT_DP_KERNEL = 1, 2
 CALIB_LDS_READ, CALIB_LDS_CHAIN = 0, 1
 DP_AUTO, DP_WORKGROUP, DP_REGISTER = 0, 1, 2

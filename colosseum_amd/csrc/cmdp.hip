@@ -2,6 +2,7 @@
 #include "../../include/cmdp.h"
 
 #include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
 #include <cstdlib>
 
 #include <algorithm>
@@ -133,6 +134,7 @@ struct cmdp {
   DevBuf<unsigned long long> d_n_obs;
   int obs_F = 0, obs_time_indexed = 0;
   // cmdp_average_reward workspace (K9)
+  int mixing_path = 0;       // CMDP_OPT_MIXING_PATH: 0 auto, 1 matrix powers, 2 stepping
   bool chain_exact = false;  // CMDP_OPT_CHAIN_EXACT_ORDER
   DevBuf<double> d_ch_work, d_ch_avg;
   DevBuf<int64_t> d_ch_off;
@@ -810,6 +812,10 @@ int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
   }
   if (option == CMDP_OPT_CHAIN_EXACT_ORDER && (value == 0 || value == 1)) {
     h->chain_exact = value == 1;
+    return CMDP_OK;
+  }
+  if (option == CMDP_OPT_MIXING_PATH && value >= 0 && value <= 2) {
+    h->mixing_path = (int)value;
     return CMDP_OK;
   }
   if (option == CMDP_OPT_DIAMETER_WORKSPACE_MB && value >= 1) {
@@ -1686,14 +1692,152 @@ int cmdp_observe(cmdp_t* h, double noise_scale, float* obs) {
   return CMDP_OK;
 }
 
+}  // extern "C"
+
+// Mixing time of one instance by matrix powers (see cmdp.h).  d(t) = max_s TV(P^t(s, .), pi) is non-increasing in t, so:
+// square A_k = P^(2^k) until d(2^K) <= threshold (then t_mix lies in (2^(K-1), 2^K]), walk back down multiplying the
+// stored powers in (binary search on t, one dgemm per bit), and finish the last 2^r steps -- r = the lowest power still
+// held when HBM ran out of S x S buffers -- with sparse steps.
+static int mixing_time_dense(cmdp_t* h, int b, const int64_t* d_cptr, const int32_t* d_crow, const double* d_cval,
+                             const double* d_stat, double threshold, int64_t max_steps, int64_t* t_mix, double* tv_at) {
+  hipStream_t st = h->stream;
+  const int64_t so = h->state_off[b];
+  const int S = (int)(h->state_off[b + 1] - so);
+  const size_t bytes = sizeof(double) * (size_t)S * (size_t)S;
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  int cap = (int)std::min<size_t>(24, (free_b / 10 * 9) / bytes);
+  if (const char* e = std::getenv("CMDP_MIX_MAX_BUFFERS")) cap = std::min(cap, std::atoi(e));  // tests: force the sparse tail
+  if (cap < 3)
+    return fail(CMDP_ERR_UNSUPPORTED, "mixing time of %d states needs three %zu-byte matrices, %zu bytes are free", S, bytes, free_b);
+  std::vector<DevBuf<double>> pool((size_t)cap);
+  std::vector<int> free_list;
+  for (int i = 0; i < cap; ++i) free_list.push_back(i);
+  auto take = [&](int* idx) -> int {
+    *idx = free_list.back();
+    free_list.pop_back();
+    if (!pool[(size_t)*idx].p) {
+      if (hipError_t e = pool[(size_t)*idx].alloc((size_t)S * S); e != hipSuccess)
+        return fail(CMDP_ERR_HIP, "mixing-time matrix of %zu bytes: %s", bytes, hipGetErrorString(e));
+    }
+    return CMDP_OK;
+  };
+  DevBuf<unsigned long long> d_tv;
+  HIP_TRY(d_tv.alloc(1));
+  MixDense m{S, so, d_cptr, d_crow, d_cval, d_stat, d_tv.p};
+  auto tv_of = [&](const double* X, double* out) -> int {
+    HIP_TRY(d_tv.zero(st));
+    hipLaunchKernelGGL(k_mixd_tv, dim3((unsigned)S), dim3(256), 0, st, m, X);
+    HIP_TRY(hipGetLastError());
+    unsigned long long bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, d_tv.p, sizeof bits, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::memcpy(out, &bits, sizeof(double));
+    return CMDP_OK;
+  };
+  rocblas_handle blas = nullptr;
+  if (rocblas_create_handle(&blas) != rocblas_status_success) return fail(CMDP_ERR_HIP, "rocblas_create_handle failed");
+  struct BlasGuard { rocblas_handle h; ~BlasGuard() { rocblas_destroy_handle(h); } } guard{blas};
+  if (rocblas_set_stream(blas, st) != rocblas_status_success) return fail(CMDP_ERR_HIP, "rocblas_set_stream failed");
+  // row-major Z = X * Y  <=>  column-major Z^T = Y^T * X^T
+  auto matmul = [&](const double* X, const double* Y, double* Z) -> int {
+    const double one = 1.0, zero = 0.0;
+    if (rocblas_dgemm(blas, rocblas_operation_none, rocblas_operation_none, S, S, S, &one, Y, S, X, S, &zero, Z, S) !=
+        rocblas_status_success)
+      return fail(CMDP_ERR_HIP, "rocblas_dgemm failed");
+    return CMDP_OK;
+  };
+  *t_mix = -1;
+  if (tv_at) *tv_at = 0.0;
+  std::vector<int> power;  // power[i] = pool index of A_(r+i)
+  int r = 0, idx = 0;
+  if (int rc = take(&idx)) return rc;
+  HIP_TRY(hipMemsetAsync(pool[(size_t)idx].p, 0, bytes, st));
+  hipLaunchKernelGGL(k_mixd_build, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, m, pool[(size_t)idx].p);
+  HIP_TRY(hipGetLastError());
+  power.push_back(idx);
+  double d = 0.0;
+  if (int rc = tv_of(pool[(size_t)idx].p, &d)) return rc;
+  if (tv_at) *tv_at = d;
+  if (d <= threshold) {
+    *t_mix = 1;
+    return CMDP_OK;
+  }
+  // ---- doubling: A_(K) = A_(K-1)^2 until mixed ------------------------------------------------------------------
+  int K = 0;  // the newest power is A_K, t = 2^K, not mixed
+  while (true) {
+    if (((int64_t)1 << K) >= max_steps) return CMDP_OK;  // not mixed at 2^K >= max_steps: -1
+    if (free_list.empty()) {  // drop the lowest power: the final stretch of sparse steps doubles
+      free_list.push_back(power.front());
+      power.erase(power.begin());
+      ++r;
+    }
+    if (int rc = take(&idx)) return rc;
+    const double* prev = pool[(size_t)power.back()].p;
+    if (int rc = matmul(prev, prev, pool[(size_t)idx].p)) return rc;
+    power.push_back(idx);
+    ++K;
+    if (int rc = tv_of(pool[(size_t)idx].p, &d)) return rc;
+    if (std::getenv("CMDP_MIX_DEBUG")) std::fprintf(stderr, "[mixing] t = 2^%d: max TV %.6g (%d powers held from 2^%d)\n", K, d, (int)power.size(), r);
+    if (d <= threshold) break;
+    if (tv_at) *tv_at = d;
+  }
+  // ---- binary search on t: cur = P^lo (not mixed), lo + 2^k' mixed for the current k' ----------------------------------
+  int64_t lo = (int64_t)1 << (K - 1);
+  int cand = power.back();              // A_K: mixed, its buffer is scratch from here on
+  int cur = power[power.size() - 2];    // A_(K-1)
+  double d_hi = d;                      // TV at the smallest t known to be mixed
+  for (int k = K - 2; k >= r; --k) {
+    const double* Ak = pool[(size_t)power[(size_t)(k - r)]].p;
+    if (int rc = matmul(pool[(size_t)cur].p, Ak, pool[(size_t)cand].p)) return rc;
+    if (int rc = tv_of(pool[(size_t)cand].p, &d)) return rc;
+    if (d > threshold) {
+      std::swap(cur, cand);  // A_(K-1)'s buffer becomes scratch: no lower step multiplies by it again
+      lo += (int64_t)1 << k;
+      if (tv_at) *tv_at = d;
+    } else {
+      d_hi = d;
+    }
+  }
+  // ---- the last 2^r steps one at a time ---------------------------------------------------------------------------------
+  const int64_t last = (int64_t)1 << r;
+  for (int64_t i = 1; i <= last; ++i) {
+    if (i == last) {  // lo + 2^r is known to be mixed
+      d = d_hi;
+    } else {
+      HIP_TRY(d_tv.zero(st));
+      hipLaunchKernelGGL(k_mixd_step, dim3((unsigned)S), dim3(256), 0, st, m, pool[(size_t)cur].p, pool[(size_t)cand].p);
+      HIP_TRY(hipGetLastError());
+      unsigned long long bits = 0;
+      HIP_TRY(hipMemcpyAsync(&bits, d_tv.p, sizeof bits, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      std::memcpy(&d, &bits, sizeof(double));
+      std::swap(cur, cand);
+    }
+    if (d <= threshold) {
+      if (lo + i <= max_steps) {
+        *t_mix = lo + i;
+        if (tv_at) *tv_at = d;
+      }
+      return CMDP_OK;
+    }
+    if (tv_at) *tv_at = d;
+  }
+  return fail(CMDP_ERR_HIP, "mixing-time search lost its bracket (total variation is not monotone?)");
+}
+
+extern "C" {
+
 int cmdp_mixing_time(cmdp_t* h, const float* pi, const double* stationary, double threshold, int64_t max_steps,
                      int64_t* t_mix, double* tv_at) {
   if (int rc = bind(h)) return rc;
   if (!h->has_dp) return fail(CMDP_ERR_INVALID, "handle was created without the DP half");
   if (!stationary || !t_mix) return fail(CMDP_ERR_INVALID, "null argument");
   if (!(threshold > 0.0) || max_steps < 1) return fail(CMDP_ERR_INVALID, "threshold <= 0 or max_steps < 1");
-  if (sizeof(double) * (size_t)h->max_S > (size_t)kLdsBudget - 1024)
-    return fail(CMDP_ERR_UNSUPPORTED, "a row of X (%d states, float64) does not fit LDS", h->max_S);
+  const bool fits_lds = sizeof(double) * (size_t)h->max_S <= (size_t)kLdsBudget - 1024;
+  if (h->mixing_path == 2 && !fits_lds)
+    return fail(CMDP_ERR_UNSUPPORTED, "a row of X (%d states, float64) does not fit LDS: the stepping path cannot run", h->max_S);
+  const bool dense_path = h->mixing_path == 1 || (h->mixing_path == 0 && (!fits_lds || h->max_S > 1024));
   hipStream_t st = h->stream;
   const int B = h->B, A = h->A;
   const int64_t NS = h->n_states, NR = h->n_rows;
@@ -1727,8 +1871,12 @@ int cmdp_mixing_time(cmdp_t* h, const float* pi, const double* stationary, doubl
             rowacc[col[k]] += w * (double)val[k];
           }
         }
+        // the float32 probabilities of a row sum to 1 only within ~1e-7: without this, X_t would lose or gain that much
+        // mass per step (1e-2 over the 1e5 steps a slow chain needs).  The chain is DEFINED with normalised rows.
+        double rowsum = 0.0;
+        for (int32_t j : touched) rowsum += rowacc[j];
         for (int32_t j : touched) {
-          if (rowacc[j] != 0.0) incoming[(size_t)(so + j)].push_back({(int32_t)s, rowacc[j]});
+          if (rowacc[j] != 0.0) incoming[(size_t)(so + j)].push_back({(int32_t)s, rowacc[j] / rowsum});
           rowacc[j] = 0.0;
         }
       }
@@ -1748,6 +1896,13 @@ int cmdp_mixing_time(cmdp_t* h, const float* pi, const double* stationary, doubl
   HIP_TRY(d_crow.upload(crow.data(), crow.size(), st));
   HIP_TRY(d_cval.upload(cval.data(), cval.size(), st));
   HIP_TRY(d_stat.upload(stationary, (size_t)NS, st));
+  if (dense_path) {
+    for (int b = 0; b < B; ++b)
+      if (int rc = mixing_time_dense(h, b, d_cptr.p, d_crow.p, d_cval.p, d_stat.p, threshold, max_steps, t_mix + b,
+                                     tv_at ? tv_at + b : nullptr))
+        return rc;
+    return CMDP_OK;
+  }
   HIP_TRY(d_X.alloc((size_t)xoff[B]));
   HIP_TRY(d_Xn.alloc((size_t)xoff[B]));
   HIP_TRY(d_dl.alloc((size_t)B * CH));

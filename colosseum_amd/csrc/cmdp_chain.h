@@ -555,6 +555,66 @@ __global__ void __launch_bounds__(256) k_mix_step(MixArgs m) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// Mixing time of LARGE chains (a float64 row of X does not fit LDS, or S > 1024): X_t = P^t as a dense S x S
+// float64 matrix, advanced by repeated squaring (rocBLAS dgemm, the one plain library GEMM of this library) and, for
+// the last stretch, by sparse steps that gather from the row in global memory.  cmdp_mixing_time describes the search.
+// ---------------------------------------------------------------------------------------------------
+struct MixDense {
+  int32_t S;
+  int64_t soff;              // first flat state of the instance
+  const int64_t* csc_ptr;    // global offsets, column = flat state
+  const int32_t* csc_row;    // instance-relative predecessor
+  const double* csc_val;
+  const double* stationary;  // flat
+  unsigned long long* out;   // bit pattern of max_s TV (atomicMax)
+};
+
+// P as a dense row-major matrix from its CSC (the buffer has been zeroed); one thread per column.
+__global__ void __launch_bounds__(256) k_mixd_build(MixDense m, double* __restrict__ P) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= m.S) return;
+  for (int64_t k = m.csc_ptr[m.soff + j]; k < m.csc_ptr[m.soff + j + 1]; ++k)
+    P[(int64_t)m.csc_row[k] * m.S + j] = m.csc_val[k];
+}
+
+__device__ __forceinline__ void mixd_reduce_tv(double part, unsigned long long* out) {
+  __shared__ double red[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tv = 0.5 * (((red[0] + red[1]) + red[2]) + red[3]);
+    atomicMax(out, (unsigned long long)__double_as_longlong(tv));
+  }
+}
+
+// max_s TV(X[s, :], stationary): one workgroup per row.
+__global__ void __launch_bounds__(256) k_mixd_tv(MixDense m, const double* __restrict__ X) {
+  const double* x = X + (int64_t)blockIdx.x * m.S;
+  double part = 0.0;
+  for (int j = threadIdx.x; j < m.S; j += 256) part += fabs(x[j] - m.stationary[m.soff + j]);
+  mixd_reduce_tv(part, m.out);
+}
+
+// One step X_{t+1}[s, :] = X_t[s, :] P for every row s (one workgroup per row; the gathers hit the row in L2), same
+// index-order float64 accumulation as k_mix_step, and the TV of the new row.
+__global__ void __launch_bounds__(256) k_mixd_step(MixDense m, const double* __restrict__ X, double* __restrict__ Xn) {
+  const double* x = X + (int64_t)blockIdx.x * m.S;
+  double* xn = Xn + (int64_t)blockIdx.x * m.S;
+  double part = 0.0;
+  for (int j = threadIdx.x; j < m.S; j += 256) {
+    double acc = 0.0;
+    for (int64_t k = m.csc_ptr[m.soff + j]; k < m.csc_ptr[m.soff + j + 1]; ++k)
+      acc = __dadd_rn(acc, __dmul_rn(x[m.csc_row[k]], m.csc_val[k]));
+    xn[j] = acc;
+    part += fabs(acc - m.stationary[m.soff + j]);
+  }
+  mixd_reduce_tv(part, m.out);
+}
+
+
 // ===================================================================================================
 // k_emit: non-tabular observations of all instances (reference colosseum/emission_maps/base.py:56-141): row
 // [h][state] of the instance's float32 feature table (zeros once an episodic instance has reached its horizon),

@@ -104,35 +104,53 @@ def mixing_time(models: Sequence[TabularModel], policies=None, threshold: float 
     max_s TV(P^t(s, .), pi) <= threshold, where pi is the stationary distribution of the chain's single recurrent class
     (GTH kernel).  Returns (t_mix, tv): t_mix = -1 when the chain has several recurrent classes or does not get below
     the threshold within max_steps (periodic chains)."""
-    from ..markov_chain import gth_batch, recurrent_classes
+    from scipy.sparse import csr_matrix
+
+    from ..markov_chain import gth_batch, recurrent_classes, stationary_sparse
 
     n = len(models)
     t_out = np.full(n, -1, np.int64)
     tv_out = np.full(n, np.nan)
     groups = {}
     for i, m in enumerate(models):
-        groups.setdefault(m.n_actions, []).append(i)
-    for A, idx in groups.items():
+        groups.setdefault((m.n_actions, m.n_states > 1024), []).append(i)  # large chains one at a time (S x S matrices in HBM)
+    for (A, large), idx in groups.items():
         stats, keep, pols = [], [], []
         for i in idx:
             m = models[i]
-            T, _ = m.dense()
-            pol = np.full((m.n_states, A), 1.0 / A, np.float32) if policies is None else np.asarray(policies[i], np.float32)
-            P = np.einsum("saj,sa->sj", T.astype(np.float64), pol.astype(np.float64))
+            S = m.n_states
+            pol = np.full((S, A), 1.0 / A, np.float32) if policies is None else np.asarray(policies[i], np.float32)
+            # the chain as a sparse matrix: P[s, j] = sum_a pi[s, a] T[s, a, j] in float64 (never a dense S x A x S array)
+            ptr, col, val = m.csr()
+            rows = np.repeat(np.arange(S * A) // A, np.diff(ptr))
+            w = np.repeat(pol.astype(np.float64).ravel(), np.diff(ptr))
+            P = csr_matrix((w * val.astype(np.float64), (rows, col)), shape=(S, S))
+            P.sum_duplicates()
+            P.eliminate_zeros()
+            from scipy.sparse import diags
+
+            P = csr_matrix(diags(1.0 / np.asarray(P.sum(axis=1)).ravel()) @ P)  # rows normalised, as the library defines the chain
             classes = recurrent_classes(P)
             if len(classes) != 1:
                 continue
             cls = classes[0]
-            sd = np.zeros(m.n_states)
-            sd[cls] = np.ones(1) if len(cls) == 1 else gth_batch([P[np.ix_(cls, cls)]])[0]
+            sd = np.zeros(S)
+            if len(cls) == 1:
+                sd[cls] = 1.0
+            elif len(cls) > 2048:
+                sd[cls] = stationary_sparse(P[cls][:, cls])
+            else:
+                sd[cls] = gth_batch([P[cls][:, cls].toarray()])[0]
             stats.append(sd)
             keep.append(i)
             pols.append(pol)
         if not keep:
             continue
-        dp = BatchedMDP([models[i] for i in keep], with_env=False)
-        t, tv = dp.mixing_time(stats, None if policies is None else pols, threshold, max_steps)
-        dp.close()
-        t_out[keep] = t
-        tv_out[keep] = tv
+        for part in ([[k] for k in range(len(keep))] if large else [list(range(len(keep)))]):
+            dp = BatchedMDP([models[keep[k]] for k in part], with_env=False)
+            t, tv = dp.mixing_time([stats[k] for k in part], None if policies is None else [pols[k] for k in part],
+                                   threshold, max_steps)
+            dp.close()
+            t_out[[keep[k] for k in part]] = t
+            tv_out[[keep[k] for k in part]] = tv
     return t_out, tv_out

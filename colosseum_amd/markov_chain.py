@@ -73,7 +73,7 @@ def recurrent_classes(tps: np.ndarray) -> List[np.ndarray]:
     state order, listed in the reference's order (markov_chain.py:95): networkx emits strongly connected components as
     its depth-first search completes them, and a component without outgoing edges is completed before the search leaves
     it -- so the attracting components come in the order in which that search first touches them."""
-    n = len(tps)
+    n = tps.shape[0]  # dense array or scipy sparse matrix
     g = csr_matrix(tps > 0)
     ncomp, label = connected_components(g, directed=True, connection="strong")
     src, dst = g.nonzero()
@@ -85,6 +85,24 @@ def recurrent_classes(tps: np.ndarray) -> List[np.ndarray]:
         pre = _dfs_preorder(g.indptr, g.indices, n)
         classes.sort(key=lambda cls: pre[cls].min())
     return classes
+
+
+def stationary_sparse(P) -> np.ndarray:
+    """Stationary distribution of a single-class chain given as a scipy sparse matrix, for chains too large for a dense
+    float64 copy (config C5: 50 272 states; BUILD-DEFINED helper of `hardness.mixing_time`, no reference counterpart --
+    the reference's own routines take dense arrays): the linear system pi (P - I) = 0 with the last equation replaced
+    by sum(pi) = 1, solved by sparse LU (SuperLU through scipy), float64."""
+    from scipy.sparse import identity, lil_matrix
+    from scipy.sparse.linalg import spsolve
+
+    n = P.shape[0]
+    A = (csr_matrix(P, dtype=np.float64).T - identity(n, dtype=np.float64, format="csr")).tolil()
+    A[n - 1, :] = 1.0
+    b = np.zeros(n)
+    b[n - 1] = 1.0
+    pi = spsolve(A.tocsc(), b)
+    pi = np.maximum(pi, 0.0)
+    return pi / pi.sum()
 
 
 def _class_distribution(tps: np.ndarray, cls: np.ndarray) -> np.ndarray:

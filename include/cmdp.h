@@ -205,12 +205,14 @@ int cmdp_calibrate(int what, int64_t n_steps, double* ns_per_step);
    chains with hundreds of states.
    CMDP_OPT_DIAMETER_WORKSPACE_MB: HBM the value arrays of K5S may take per launch (default 24576; 512 bytes per
    state per group of 64 targets; more groups in flight = more of the GPU busy).
+   CMDP_OPT_MIXING_PATH (cmdp_mixing_time): 0 = automatic (matrix powers when an instance has more than 1024 states or
+   a float64 row does not fit LDS), 1 = matrix powers, 2 = one sparse step at a time with the row in LDS.
    CMDP_OPT_LDS_GROUPS_PER_CU: 1 or 2 workgroups of the fused-walker kernel K1L per CU (default: whichever needs
    fewer rounds of workgroups for the batch).  Setting it re-plans the handle onto K1L with the
    balanced number of instances per workgroup for that many groups (the pipeline kernel K1P always runs one workgroup
    per CU); CMDP_ERR_INVALID when the batch is not eligible for the LDS-resident kernels or two groups do not fit. */
 enum { CMDP_OPT_ROLLOUT_KERNEL = 1, CMDP_OPT_DP_KERNEL = 2, CMDP_OPT_LDS_GROUPS_PER_CU = 3,
-       CMDP_OPT_DIAMETER_WORKSPACE_MB = 4, CMDP_OPT_CHAIN_EXACT_ORDER = 5 };
+       CMDP_OPT_DIAMETER_WORKSPACE_MB = 4, CMDP_OPT_CHAIN_EXACT_ORDER = 5, CMDP_OPT_MIXING_PATH = 6 };
 int cmdp_set_option(cmdp_t* h, int option, int64_t value);
 
 /* What the LDS-resident random-policy rollout of this handle is (introspection for benchmarks and tests; no
@@ -333,10 +335,19 @@ int cmdp_observe(cmdp_t* h, double noise_scale, float* obs);
 
 /* ---- Markov chains ------------------------------------------------------------------------------------ */
 /* BUILD-DEFINED (the reference has no mixing time): t_mix[b] = smallest t >= 1 with
-   max_s TV(P^t(s, .), stationary) <= threshold for the chain P[s, j] = sum_a pi[s, a] T[s, a, j] of instance b
-   (pi [state_off[B]*A] float32, NULL = the uniform policy; stationary [state_off[B]] float64, e.g. from cmdp_gth),
+   max_s TV(P^t(s, .), stationary) <= threshold for the chain P[s, j] = sum_a pi[s, a] T[s, a, j] of instance b, rows
+   normalised to sum to one in float64 (float32 probabilities sum to 1 only within ~1e-7, which would leak 1e-2 of mass
+   over the 1e5 steps a slow chain needs); pi [state_off[B]*A] float32, NULL = the uniform policy; stationary
+   [state_off[B]] float64, e.g. from cmdp_gth on the same normalised chain;
    float64 on the device; -1 when max_steps is reached first (periodic chains never get there).  tv_at [B] (may be
-   NULL) receives the total variation at t_mix (or after the last step taken).  Parity unpinned by construction. */
+   NULL) receives the total variation at t_mix (or at the last t evaluated).  Parity unpinned by construction.
+   Two paths (CMDP_OPT_MIXING_PATH).  Stepping: the S rows of X_t = P^t advance one sparse step at a time, row in LDS
+   (S <= ~20 000).  Matrix powers, for large chains (config C5, S = 50 272): X is a dense S x S float64 matrix in HBM
+   (20 GB at C5); since max_s TV is non-increasing in t, A_k = P^(2^k) is squared (rocBLAS dgemm) until 2^K is mixed,
+   a binary search multiplies the stored powers back in, one dgemm per bit, and the last 2^r steps -- r = the lowest
+   power still held when HBM ran out of S x S buffers -- are sparse steps that gather from the row in global memory.
+   The two paths round differently (1e-16 relative per product) and return the same t unless the total variation
+   crosses the threshold within that distance. */
 int cmdp_mixing_time(cmdp_t* h, const float* pi, const double* stationary, double threshold, int64_t max_steps,
                      int64_t* t_mix, double* tv_at);
 /* get_average_reward (colosseum/mdp/utils/markov_chain.py:12-31) of deterministic stationary policies: actions

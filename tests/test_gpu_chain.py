@@ -1,6 +1,8 @@
 """K9 (cmdp_average_reward): average reward of deterministic policies, fully on the device, against the host
 restatement of colosseum/mdp/utils/markov_chain.py:12-136 (recurrent classes by scipy + networkx-order DFS, GTH by the
 dense kernel K7): same value, same numpy type, same number of recurrent classes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -67,26 +69,31 @@ def test_average_reward_kernel_matches_host_restatement(need_gpu, cls, kw):
 
 
 def test_mixing_time_against_dense_float64_powers(need_gpu):
-    """Build-defined measure (no reference counterpart): the device evolution X_{t+1} = X_t P with the TV test must
-    give the t and the total variation of a plain numpy float64 evaluation; a periodic chain reports -1."""
+    """Build-defined measure (no reference counterpart): both device paths -- one sparse step at a time with the row in
+    LDS, and matrix powers with the binary search on t (what config C5 runs) -- must give the t and the total variation
+    of a plain numpy float64 evaluation; a periodic chain reports -1."""
     from colosseum_amd.hardness import mixing_time
     from colosseum_amd.markov_chain import gth_batch
 
     ms = [make_model("FrozenLakeContinuous", seed=3, size=5, p_frozen=0.8),
           make_model("MiniGridEmptyContinuous", seed=4, size=5, n_starting_states=2, p_lazy=0.2),
           make_model("FrozenLakeContinuous", seed=6, size=8, p_frozen=0.9),
-          make_model("DeepSeaContinuous", seed=1, size=6)]       # period = size under any policy
-    t, tv = mixing_time(ms, threshold=0.25, max_steps=3000)
+          make_model("DeepSeaContinuous", seed=1, size=6),       # period = size under any policy
+          make_model("MiniGridRoomsContinuous", seed=0, room_size=4, n_rooms=4, p_lazy=0.1)]   # t_mix in the thousands
+    t, tv = mixing_time(ms, threshold=0.25, max_steps=20000)
+    wants = []
     for i, m in enumerate(ms):
         T, _ = m.dense()
         P = T.astype(np.float64).mean(1)
+        P /= P.sum(1, keepdims=True)
         if i == 3:
             assert t[i] == -1
+            wants.append(None)
             continue
         sd = gth_batch([P])[0]
         X = np.eye(m.n_states)
         want = None
-        for step in range(1, 3001):
+        for step in range(1, 20001):
             X = X @ P
             d = 0.5 * np.abs(X - sd).sum(1).max()
             if d <= 0.25:
@@ -94,6 +101,26 @@ def test_mixing_time_against_dense_float64_powers(need_gpu):
                 break
         assert want is not None and t[i] == want[0], (i, t[i], want)
         assert tv[i] == pytest.approx(want[1], rel=1e-10)
+        wants.append(want)
+    assert wants[4][0] > 1000
+    # the matrix-power path, forced, with as few S x S buffers as it can work with and with plenty
+    for i in (0, 2, 3, 4):
+        m = ms[i]
+        T, _ = m.dense()
+        P = T.astype(np.float64).mean(1)
+        P /= P.sum(1, keepdims=True)
+        env = BatchedMDP([m], with_env=False)
+        env.set_option(L.OPT_MIXING_PATH, 1)
+        sd = gth_batch([P])[0] if i != 3 else np.full(m.n_states, 1.0 / m.n_states)
+        for buffers in ("3", "24"):  # 3: only two powers are ever held, the search ends in a long run of sparse steps
+            os.environ["CMDP_MIX_MAX_BUFFERS"] = buffers
+            tt, tvv = env.mixing_time([sd], threshold=0.25, max_steps=20000)
+            del os.environ["CMDP_MIX_MAX_BUFFERS"]
+            if i == 3:
+                assert tt[0] == -1
+            else:
+                assert tt[0] == wants[i][0] and tvv[0] == pytest.approx(wants[i][1], rel=1e-9), (i, buffers, tt, wants[i])
+        env.close()
 
 
 def test_chain_api_argument_checks(need_gpu):

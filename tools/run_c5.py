@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--workspace-mb", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses device 0 (gloo backend)")
+    ap.add_argument("--mixing", action="store_true",
+                    help="also the build-defined mixing time of the uniform policy's chain (rank 0; matrix powers in HBM)")
+    ap.add_argument("--no-diameter", action="store_true")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -59,8 +62,17 @@ def main():
     if args.targets:
         hi = min(hi, lo + args.targets)
     t0 = time.time()
-    per = dp.diameter_range(lo, hi, args.eps)
+    per = dp.diameter_range(lo, hi, args.eps) if not args.no_diameter else np.zeros(0, np.float32)
     t_solve = time.time() - t0
+    mixing = None
+    if args.mixing and rank == 0:
+        from colosseum_amd.hardness import mixing_time
+
+        dp.close()  # the S x S float64 matrices want the HBM
+        tm = time.time()
+        tmix, tv = mixing_time([m], threshold=0.25, max_steps=1 << 22)
+        mixing = dict(t_mix=int(tmix[0]), tv_at_t_mix=float(tv[0]), threshold=0.25, policy="uniform", seconds=round(time.time() - tm, 2))
+        dp = BatchedMDP([m], with_env=False)
     local_max = float(per.max()) if len(per) else 0.0
     diameter = local_max
     if world > 1:
@@ -96,7 +108,7 @@ def main():
         print(json.dumps(dict(config="C5", mdp="MiniGridRoomsContinuous", room_size=args.room_size, n_rooms=args.n_rooms,
                               n_states=S, n_actions=A, nnz=int(len(m.csr()[1])), world=world, targets_this_rank=int(hi - lo),
                               build_s=round(t_build, 2), solve_s=round(t_solve, 3),
-                              targets_per_s=round((hi - lo) / t_solve, 1), diameter=diameter, oracle_check=ok,
+                              targets_per_s=round((hi - lo) / max(t_solve, 1e-9), 1), diameter=diameter, mixing_time=mixing, oracle_check=ok,
                               oracle_sweeps=(sweeps if args.check else None),
                               oracle_s_per_target=(round((time.time() - t_or) / args.check, 2) if args.check else None))))
     dp.close()
