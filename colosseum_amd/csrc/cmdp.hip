@@ -126,6 +126,11 @@ struct cmdp {
   DevBuf<float> d_dl_v, d_ell_val;
   DevBuf<int32_t> d_ell_col;
   int ell_K = 0;
+  // K5T cluster tables (large-instance diameter with LDS tiles)
+  DevBuf<int32_t> d_tl_c0, d_tl_ncl, d_tl_n, d_tl_R, d_tl_rows, d_tl_lcol;
+  DevBuf<float> d_tl_val;
+  int tile_K = 0;          // K the tables were built for (0: not built)
+  double tile_rows_per_state = 0.0;  // tile rows gathered per state and sweep (1 + halo/cluster)
   DevBuf<int32_t> d_dl_inst, d_dl_t0, d_dl_cnt;
   DevBuf<int64_t> d_dl_voff;
   size_t dl_ws_bytes = (size_t)24 << 30;  // value arrays of the target groups in flight per launch
@@ -806,7 +811,7 @@ int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
     h->lds_bytes = k1l_lds_bytes(h->lds_plan, g);
     return CMDP_OK;
   }
-  if (option == CMDP_OPT_DP_KERNEL && value >= 0 && value <= 5) {
+  if (option == CMDP_OPT_DP_KERNEL && value >= 0 && value <= 6) {
     h->dp_kernel = (int)value;
     return CMDP_OK;
   }
@@ -1179,6 +1184,144 @@ int cmdp_pe_episodic(cmdp_t* h, int H, const float* pi, const float* R_override,
   return episodic(h, DP_PE, H, pi, R_override, Q, V);
 }
 
+constexpr int kK5tRmax = 96;  // tile rows per cluster: 6 wavefronts x 96 rows x 256 B = 144 KiB of LDS
+constexpr int kK5tNw = 6;
+
+// Host side of K5T: cuts every instance into clusters of <= K5T_C states whose rows (own + distinct outside successors)
+// fit a tile, and writes the per-cluster row lists and the rows' entries re-indexed to tile positions (original column
+// order kept).  Breadth-first region growing over the undirected transition graph keeps the halo small on grid worlds.
+static int build_tiles(cmdp_t* h, int K) {
+  hipStream_t st = h->stream;
+  const int A = h->A, AK = A * K;
+  const int64_t NR = h->n_rows;
+  std::vector<int64_t> ptr((size_t)NR + 1);
+  std::vector<int32_t> col((size_t)h->n_csr);
+  std::vector<float> val((size_t)h->n_csr);
+  HIP_TRY(hipMemcpyAsync(ptr.data(), h->d_csr_ptr.p, sizeof(int64_t) * ptr.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(col.data(), h->d_csr_col.p, sizeof(int32_t) * col.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(val.data(), h->d_csr_val.p, sizeof(float) * val.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  std::vector<int32_t> c0v, nclv, cl_n, cl_R, rows, lcol;
+  std::vector<float> lval;
+  int64_t total_rows = 0, total_states = 0;
+  for (int b = 0; b < h->B; ++b) {
+    const int64_t so = h->state_off[b];
+    const int S = (int)(h->state_off[b + 1] - so);
+    // distinct successors of every state (directed: what a sweep gathers), and undirected neighbours for the growth
+    std::vector<std::vector<int32_t>> succ((size_t)S), nbr((size_t)S);
+    for (int s = 0; s < S; ++s) {
+      auto& v = succ[(size_t)s];
+      for (int64_t r = (so + s) * A; r < (so + s + 1) * A; ++r)
+        for (int64_t k = ptr[r]; k < ptr[r + 1]; ++k) v.push_back(col[k]);
+      std::sort(v.begin(), v.end());
+      v.erase(std::unique(v.begin(), v.end()), v.end());
+    }
+    for (int s = 0; s < S; ++s)
+      for (int32_t w : succ[(size_t)s])
+        if (w != s) { nbr[(size_t)s].push_back(w); nbr[(size_t)w].push_back(s); }
+    std::vector<char> assigned((size_t)S, 0);
+    std::vector<int32_t> mark((size_t)S, -1);   // cluster id while the state is in the cluster or its halo
+    std::vector<char> inside((size_t)S, 0);
+    std::vector<int32_t> local((size_t)S, -1);
+    c0v.push_back((int32_t)cl_n.size());
+    int next_seed = 0;
+    std::vector<int32_t> seeds;                 // frontier left over by finished clusters: grow next to them
+    size_t seed_pos = 0;
+    int n_clusters = 0;
+    while (true) {
+      int seed = -1;
+      while (seed_pos < seeds.size()) {
+        const int c = seeds[seed_pos++];
+        if (!assigned[(size_t)c]) { seed = c; break; }
+      }
+      if (seed < 0) {
+        while (next_seed < S && assigned[(size_t)next_seed]) ++next_seed;
+        if (next_seed == S) break;
+        seed = next_seed;
+      }
+      const int cid = n_clusters++;
+      std::vector<int32_t> members, halo, queue{seed};
+      size_t qpos = 0;
+      int n_halo = 0;
+      auto try_add = [&](int v) -> bool {
+        // rows the tile would hold with v inside: members + 1, halo - (v was halo) + (new outside successors of v)
+        int add = 0;
+        for (int32_t w : succ[(size_t)v])
+          if (w != v && !(inside[(size_t)w]) && mark[(size_t)w] != cid) ++add;
+        const int was_halo = (mark[(size_t)v] == cid && !inside[(size_t)v]) ? 1 : 0;
+        if ((int)members.size() + 1 + n_halo - was_halo + add > kK5tRmax) return false;
+        if (was_halo) --n_halo;
+        inside[(size_t)v] = 1;
+        mark[(size_t)v] = cid;
+        members.push_back(v);
+        for (int32_t w : succ[(size_t)v])
+          if (w != v && !inside[(size_t)w] && mark[(size_t)w] != cid) { mark[(size_t)w] = cid; halo.push_back(w); ++n_halo; }
+        return true;
+      };
+      local[(size_t)seed] = -2;  // `local` doubles as the "already queued" flag (-2) while the cluster grows
+      while (qpos < queue.size() && (int)members.size() < K5T_C) {
+        const int v = queue[qpos++];
+        if (assigned[(size_t)v]) continue;
+        if (!try_add(v)) continue;
+        assigned[(size_t)v] = 1;
+        for (int32_t w : nbr[(size_t)v])
+          if (!assigned[(size_t)w] && local[(size_t)w] != -2) { local[(size_t)w] = -2; queue.push_back(w); }
+      }
+      for (size_t i = 0; i < queue.size(); ++i) {   // reset the queue flags; unassigned leftovers seed later clusters
+        local[(size_t)queue[i]] = -1;
+        if (!assigned[(size_t)queue[i]]) seeds.push_back(queue[i]);
+      }
+      if (members.empty()) {  // a single state whose own successors exceed a tile: K5T cannot take this instance
+        return fail(CMDP_ERR_UNSUPPORTED, "state %d of instance %d has more than %d distinct successors: no tile holds its row",
+                    seed, b, kK5tRmax - 1);
+      }
+      // tile rows: members, then the halo states that are still outside (a halo state may have joined later)
+      std::vector<int32_t> trow(members);
+      for (int32_t w : halo)
+        if (!inside[(size_t)w]) trow.push_back(w);
+      for (size_t i = 0; i < trow.size(); ++i) local[(size_t)trow[i]] = (int32_t)i;
+      const int R = (int)((trow.size() + 3) / 4 * 4);
+      cl_n.push_back((int32_t)members.size());
+      cl_R.push_back(R);
+      total_rows += (int64_t)trow.size();
+      total_states += (int64_t)members.size();
+      for (int i = 0; i < kK5tRmax; ++i) rows.push_back(i < (int)trow.size() ? trow[(size_t)i] : trow[0]);
+      for (int u = 0; u < K5T_C; ++u)
+        for (int a = 0; a < A; ++a) {
+          int64_t lo = 0, hi = 0;
+          if (u < (int)members.size()) {
+            const int64_t r = (so + members[(size_t)u]) * A + a;
+            lo = ptr[r]; hi = ptr[r + 1];
+          }
+          for (int k = 0; k < K; ++k) {
+            const bool in = lo + k < hi;
+            lcol.push_back(in ? local[(size_t)col[lo + k]] : (hi > lo ? local[(size_t)col[lo]] : 0));
+            lval.push_back(in ? val[lo + k] : 0.0f);
+          }
+        }
+      for (int32_t v : members) inside[(size_t)v] = 0;
+      for (size_t i = 0; i < trow.size(); ++i) local[(size_t)trow[i]] = -1;
+    }
+    nclv.push_back(n_clusters);
+  }
+  for (int i = 0; i < 64; ++i) { lcol.push_back(0); lval.push_back(0.0f); }  // a 64-entry load past the last cluster
+  (void)AK;
+  HIP_TRY(h->d_tl_c0.upload(c0v.data(), c0v.size(), st));
+  HIP_TRY(h->d_tl_ncl.upload(nclv.data(), nclv.size(), st));
+  HIP_TRY(h->d_tl_n.upload(cl_n.data(), cl_n.size(), st));
+  HIP_TRY(h->d_tl_R.upload(cl_R.data(), cl_R.size(), st));
+  HIP_TRY(h->d_tl_rows.upload(rows.data(), rows.size(), st));
+  HIP_TRY(h->d_tl_lcol.upload(lcol.data(), lcol.size(), st));
+  HIP_TRY(h->d_tl_val.upload(lval.data(), lval.size(), st));
+  HIP_TRY(hipStreamSynchronize(st));
+  h->tile_K = K;
+  h->tile_rows_per_state = total_states ? (double)total_rows / (double)total_states : 0.0;
+  if (std::getenv("CMDP_K5T_DEBUG"))
+    std::fprintf(stderr, "[K5T] %zu clusters, %.1f states and %.1f tile rows per cluster (%.3f rows gathered per state)\n",
+                 cl_n.size(), (double)total_states / cl_n.size(), (double)total_rows / cl_n.size(), h->tile_rows_per_state);
+  return CMDP_OK;
+}
+
 // K5S driver: targets [unit_lo, unit_hi) of the flat state space in groups of 64 consecutive targets of one instance;
 // as many groups per launch as the value-array workspace allows.
 static int diameter_lanes(cmdp_t* h, DpTables t, int64_t unit_lo, int64_t unit_hi) {
@@ -1226,7 +1369,34 @@ static int diameter_lanes(cmdp_t* h, DpTables t, int64_t unit_lo, int64_t unit_h
     // fixed-width-row kernel when a compiled (A, K) shape fits; option value 4 keeps the generic CSR walker
     const int A = h->A, K = h->max_row_nnz <= 2 ? 2 : (h->max_row_nnz <= 4 ? 4 : (h->max_row_nnz <= 8 ? 8 : 0));
     bool ell = false;
-    if (K && h->dp_kernel != 4 && A >= 2 && A <= 4 && A * K <= 32) {
+    // K5T (value rows gathered into LDS tiles per cluster of states) for instances far beyond L2: option 6 forces it,
+    // 3 keeps K5S.  An instance with a state whose successors do not fit a tile falls back to K5S.
+    bool tiles = false;
+    if (K && A >= 2 && A <= 4 && A * K <= 32 && (h->dp_kernel == 6 || (h->dp_kernel == 0 && h->max_S > 8192))) {
+      if (h->tile_K != K) {
+        const int rc = build_tiles(h, K);
+        if (rc != CMDP_OK && (rc != CMDP_ERR_UNSUPPORTED || h->dp_kernel == 6)) return rc;
+      }
+      // worth it only while the halo stays small (two rows gathered per state would equal K5S's traffic at best)
+      tiles = h->tile_K == K && (h->dp_kernel == 6 || h->tile_rows_per_state <= 2.0);
+    }
+    if (tiles) {
+      TileArgs ta{h->d_tl_c0.p, h->d_tl_ncl.p, h->d_tl_n.p, h->d_tl_R.p, h->d_tl_rows.p, h->d_tl_lcol.p, h->d_tl_val.p};
+      const size_t lds = sizeof(float) * 64 * (size_t)kK5tRmax * kK5tNw;
+      bool launched = true;
+#define TILE_CASE(AT, KT)                                                                                       \
+  if (A == AT && K == KT) {                                                                                     \
+    if (int rc = set_lds(k_diam_tiles<kK5tNw, AT, KT, kK5tRmax>, lds)) return rc;                               \
+    hipLaunchKernelGGL((k_diam_tiles<kK5tNw, AT, KT, kK5tRmax>), dim3((unsigned)n), dim3(kK5tNw * 64), lds, st, t, g, ta); \
+  } else
+      TILE_CASE(2, 2) TILE_CASE(2, 4) TILE_CASE(2, 8) TILE_CASE(3, 2) TILE_CASE(3, 4) TILE_CASE(3, 8) TILE_CASE(4, 2)
+      TILE_CASE(4, 4) TILE_CASE(4, 8) { launched = false; }
+#undef TILE_CASE
+      if (!launched) tiles = false;
+    }
+    if (tiles) {
+      ell = true;  // handled
+    } else if (K && h->dp_kernel != 4 && A >= 2 && A <= 4 && A * K <= 32) {
       if (h->ell_K != K) {
         const size_t rows_p = (size_t)h->n_rows + 64 / K + 1;
         HIP_TRY(h->d_ell_col.alloc(rows_p * K));
@@ -1279,7 +1449,7 @@ int cmdp_diameter(cmdp_t* h, double epsilon, int scheme, int64_t max_sweeps, flo
   t.gamma = 1.0f; t.eps = epsilon; t.max_abs = 0.0; t.max_sweeps = max_sweeps;
   t.Q = nullptr; t.V = nullptr; t.sweeps = nullptr; t.per_target = h->d_per_target.p; t.status = h->d_status.p;
   const size_t v_need = 2 * sizeof(float) * (size_t)h->max_S + sizeof(float) * 4 * (kDpBlock / 64);
-  const bool lanes = sch == CMDP_SCHEME_JACOBI && (h->dp_kernel == 3 || h->dp_kernel == 4 || v_need > (size_t)kLdsBudget);
+  const bool lanes = sch == CMDP_SCHEME_JACOBI && (h->dp_kernel == 3 || h->dp_kernel == 4 || h->dp_kernel == 6 || v_need > (size_t)kLdsBudget);
   if (lanes) {
     if (int rc = diameter_lanes(h, t, 0, NS)) return rc;
   } else if (int rc = run_sweeps(h, DP_VI, true, sch, t, NS)) return rc;

@@ -2206,3 +2206,141 @@ __global__ void __launch_bounds__(64) k_calib_lds_chain(int steps, int H, int32_
   }
   sink[blockIdx.x * 64 + threadIdx.x] = cur + h;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// K5T k_diam_tiles: K5S with the value rows a cluster of states needs gathered into LDS first.
+//
+// K5S reads V[successor][lane] straight from HBM/L2 for every entry of every row: at C5 (S = 50 272, the two value
+// arrays of a 64-target group are 25.7 MB) every value row is fetched ~3 times per sweep (PMC: 3.1 x the algorithmic
+// reads), because a row's successors are far away in the state numbering and nothing that large stays in L2 with
+// hundreds of groups in flight.  Here the states of an instance are cut into CLUSTERS of <= 64 states (breadth-first
+// regions of the transition graph, built on the host) whose distinct successors outside the cluster (the "halo") are
+// few; a wavefront takes a cluster at a time, gathers the cluster's own rows and its halo rows -- R <= RMAX rows of 256
+// bytes -- into its private LDS tile with LDS-DMA loads (global_load_lds_dwordx4: 4 rows per instruction, the source row
+// of a lane is arbitrary, the LDS image is linear), and then every gather of the sweep is a conflict-free ds_read_b32.
+// Each value row is read from memory (1 + halo/cluster) times per sweep instead of ~3.
+//
+// The arithmetic is K5S's: every row keeps its entries in ascending ORIGINAL column order (only the index is replaced by
+// the position in the tile), float32 with separately rounded multiply and add, so the results are bit-equal to K5S, K2
+// and the oracle.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int K5T_C = 64;      // state slots per cluster
+struct TileArgs {
+  const int32_t* inst_c0;      // [B] first cluster of the instance
+  const int32_t* inst_ncl;     // [B] clusters of the instance
+  const int32_t* cl_n;         // [clusters] states in the cluster (<= K5T_C)
+  const int32_t* cl_R;         // [clusters] tile rows (cluster + halo), a multiple of 4
+  const int32_t* rows;         // [clusters][RMAX] instance-relative state of every tile row (padding repeats row 0)
+  const int32_t* lcol;         // [clusters][K5T_C * A * K] tile row of every entry (+64 entries of tail padding)
+  const float* val;            // same shape: coefficients (+0.0 for padding)
+};
+
+template <int NW, int A, int K, int RMAX>
+__global__ void __launch_bounds__(NW * 64) k_diam_tiles(DpTables t, DiamLanesArgs g, TileArgs ta) {
+  constexpr int AK = A * K, U = 64 / AK;
+  static_assert(U >= 1 && RMAX % 4 == 0, "shape");
+  extern __shared__ float k5t_lds[];             // NW tiles of RMAX x 64 floats
+  __shared__ float red_d[2][NW][64];
+  __shared__ float red_m[2][NW][64];
+  const int grp = blockIdx.x;
+  const int b = g.grp_inst[grp];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t soff = t.state_off[b];
+  const int S = (int)(t.state_off[b + 1] - soff);
+  const int target = g.grp_target0[grp] + lane;
+  const bool active = lane < g.grp_count[grp];
+  float* Vold = g.vbuf + g.grp_voff[grp];
+  float* Vnew = Vold + (int64_t)S * 64;
+  for (int64_t i = threadIdx.x; i < (int64_t)S * 128; i += NW * 64) Vold[i] = 0.0f;
+  __syncthreads();
+  float* tile = k5t_lds + (size_t)wave * RMAX * 64;
+  const int c0 = ta.inst_c0[b], ncl = ta.inst_ncl[b];
+
+  bool done = !active;
+  float result = 0.0f;
+  int status = active ? -5 : 0;
+  int64_t it = 0;
+  while (it < t.max_sweeps) {
+    ++it;
+    float dmax = 0.0f, vmin = 3.0e38f;
+    for (int ci = wave; ci < ncl; ci += NW) {
+      const int c = c0 + ci;
+      const int n = ta.cl_n[c], R = ta.cl_R[c];
+      const int32_t* crow = ta.rows + (int64_t)c * RMAX;
+      // every ds_read of the previous cluster has returned before its tile is overwritten
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // gather: instruction q brings tile rows 4q .. 4q+3, 16 lanes x 16 bytes per row
+      int rid[RMAX / 4];   // all row numbers first (the list is padded to RMAX entries), then the gathers back to back
+#pragma unroll
+      for (int q = 0; q < RMAX / 4; ++q) rid[q] = crow[4 * q + (lane >> 4)];
+#pragma unroll
+      for (int q = 0; q < RMAX / 4; ++q) {
+        if (q < R / 4) {
+          const float* src = Vold + (int64_t)rid[q] * 64 + (lane & 15) * 4;
+          __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(tile + q * 256), 16, 0, 0);
+        }
+      }
+      const int myrow = crow[lane < n ? lane : 0];   // state of cluster slot `lane` (K5T_C = 64 slots)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int32_t* ec = ta.lcol + (int64_t)c * K5T_C * AK;
+      const float* ev = ta.val + (int64_t)c * K5T_C * AK;
+      for (int s0 = 0; s0 < n; s0 += U) {
+        const int ccol = ec[s0 * AK + lane];
+        const float cval = ev[s0 * AK + lane];
+        float x[U * AK], vo[U];
+#pragma unroll
+        for (int e = 0; e < U * AK; ++e) {
+          const int cl = __builtin_amdgcn_readlane(ccol, e);
+          x[e] = tile[cl * 64 + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) vo[u] = tile[((s0 + u < n) ? s0 + u : s0) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (s0 + u < n) {
+            float v = 0.0f;
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+              float acc = 0.0f;
+#pragma unroll
+              for (int k = 0; k < K; ++k) {
+                const int e = (u * A + a) * K + k;
+                const float coef = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cval), e));
+                acc = __fadd_rn(acc, __fmul_rn(coef, x[e]));
+              }
+              const float qv = __fadd_rn(-1.0f, __fmul_rn(t.gamma, acc));
+              v = (a == 0) ? qv : fmaxf(v, qv);
+            }
+            const int s = __builtin_amdgcn_readlane(myrow, s0 + u);
+            if (s == target) v = __fadd_rn(0.0f, __fmul_rn(t.gamma, __fadd_rn(0.0f, __fmul_rn(1.0f, vo[u]))));
+            Vnew[(int64_t)s * 64 + lane] = v;
+            dmax = fmaxf(dmax, fabsf(vo[u] - v));
+            vmin = fminf(vmin, v);
+          }
+        }
+      }
+    }
+    const int par = (int)(it & 1);
+    red_d[par][wave][lane] = dmax;
+    red_m[par][wave][lane] = vmin;
+    __syncthreads();   // also orders this sweep's Vnew stores before the next sweep's gathers (workgroup scope, same CU)
+    float diff = 0.0f, mn = 3.0e38f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      diff = fmaxf(diff, red_d[par][w][lane]);
+      mn = fminf(mn, red_m[par][w][lane]);
+    }
+    float* tmp = Vold; Vold = Vnew; Vnew = tmp;
+    if (!done && (double)diff < t.eps) {
+      done = true;
+      result = -mn;
+      status = 0;
+    }
+    if (__all(done)) break;
+  }
+  if (wave == 0 && active) {
+    t.per_target[soff + target] = result;
+    t.status[soff + target] = status;
+  }
+}

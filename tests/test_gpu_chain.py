@@ -79,7 +79,7 @@ def test_mixing_time_against_dense_float64_powers(need_gpu):
           make_model("MiniGridEmptyContinuous", seed=4, size=5, n_starting_states=2, p_lazy=0.2),
           make_model("FrozenLakeContinuous", seed=6, size=8, p_frozen=0.9),
           make_model("DeepSeaContinuous", seed=1, size=6),       # period = size under any policy
-          make_model("MiniGridRoomsContinuous", seed=0, room_size=4, n_rooms=4, p_lazy=0.1)]   # t_mix in the thousands
+          make_model("MiniGridRoomsContinuous", seed=0, room_size=4, n_rooms=4, p_lazy=0.1)]   # t_mix in the hundreds: eight squarings, then the search
     t, tv = mixing_time(ms, threshold=0.25, max_steps=20000)
     wants = []
     for i, m in enumerate(ms):
@@ -102,7 +102,7 @@ def test_mixing_time_against_dense_float64_powers(need_gpu):
         assert want is not None and t[i] == want[0], (i, t[i], want)
         assert tv[i] == pytest.approx(want[1], rel=1e-10)
         wants.append(want)
-    assert wants[4][0] > 1000
+    assert wants[4][0] > 200
     # the matrix-power path, forced, with as few S x S buffers as it can work with and with plenty
     for i in (0, 2, 3, 4):
         m = ms[i]

@@ -625,6 +625,7 @@ def test_diameter_lanes_kernel_equals_workgroup_kernel_and_oracle(need_gpu):
     (the multi-GPU split) reassemble to the full vector."""
     ms = [make_model("FrozenLakeContinuous", seed=1, size=9, p_frozen=0.8),
           make_model("MiniGridRoomsContinuous", seed=2, room_size=4, n_rooms=4, p_lazy=0.1),
+          make_model("MiniGridRoomsContinuous", seed=5, room_size=6, n_rooms=9, p_lazy=0.05, p_rand=0.1),  # 1 400 states
           make_model("DeepSeaContinuous", seed=3, size=11, p_rand=0.2)]
     ms = [m for m in ms if m.n_actions == ms[0].n_actions] + [m for m in ms if m.n_actions != ms[0].n_actions]
     by_A = {}
@@ -640,6 +641,10 @@ def test_diameter_lanes_kernel_equals_workgroup_kernel_and_oracle(need_gpu):
         np.testing.assert_array_equal(diam1, diam0)
         dp.set_option(L.OPT_DP_KERNEL, 4)  # generic CSR walker instead of the fixed-width-row variant
         np.testing.assert_array_equal(dp.diameter(1e-3, L.SCHEME_JACOBI)[1], per0)
+        dp.set_option(L.OPT_DP_KERNEL, 6)  # K5T: value rows of a cluster of states gathered into an LDS tile first (C5's kernel)
+        diam6, per6 = dp.diameter(1e-3, L.SCHEME_JACOBI)
+        np.testing.assert_array_equal(per6, per0)
+        np.testing.assert_array_equal(diam6, diam0)
         dp.set_option(L.OPT_DP_KERNEL, 3)
         off = 0
         for m in group:
