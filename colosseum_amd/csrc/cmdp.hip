@@ -269,6 +269,7 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
     ~Guard() { if (h) cmdp_destroy(h); }
   } guard{h};
   HIP_TRY(hipGetDevice(&h->device));
+  if (hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || h->cus < 1) h->cus = 256;
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   hipStream_t st = h->stream;
   h->B = B; h->A = A; h->H = d->horizon; h->rng_mode = d->rng_mode; h->layout = d->layout;
@@ -1184,7 +1185,7 @@ int cmdp_pe_episodic(cmdp_t* h, int H, const float* pi, const float* R_override,
   return episodic(h, DP_PE, H, pi, R_override, Q, V);
 }
 
-constexpr int kK5tRmax = 96;  // tile rows per cluster: 6 wavefronts x 96 rows x 256 B = 144 KiB of LDS
+constexpr int kK5tRmax = 48;  // tile rows per cluster: 6 wavefronts x 48 rows x 256 B = 72 KiB of LDS, two workgroups per CU
 constexpr int kK5tNw = 6;
 
 // Host side of K5T: cuts every instance into clusters of <= K5T_C states whose rows (own + distinct outside successors)
@@ -1240,8 +1241,7 @@ static int build_tiles(cmdp_t* h, int K) {
         seed = next_seed;
       }
       const int cid = n_clusters++;
-      std::vector<int32_t> members, halo, queue{seed};
-      size_t qpos = 0;
+      std::vector<int32_t> members, halo, queue;
       int n_halo = 0;
       auto try_add = [&](int v) -> bool {
         // rows the tile would hold with v inside: members + 1, halo - (v was halo) + (new outside successors of v)
@@ -1258,16 +1258,29 @@ static int build_tiles(cmdp_t* h, int K) {
           if (w != v && !inside[(size_t)w] && mark[(size_t)w] != cid) { mark[(size_t)w] = cid; halo.push_back(w); ++n_halo; }
         return true;
       };
-      local[(size_t)seed] = -2;  // `local` doubles as the "already queued" flag (-2) while the cluster grows
-      while (qpos < queue.size() && (int)members.size() < K5T_C) {
-        const int v = queue[qpos++];
-        if (assigned[(size_t)v]) continue;
-        if (!try_add(v)) continue;
+      // Greedy growth: of the states adjacent to the cluster, take the one with the most neighbours already inside
+      // (ties: first found) -- compact blobs with a small halo that also fill the gaps between earlier clusters.
+      // `local` doubles as the score of a frontier state while the cluster grows (-1: not on the frontier).
+      std::vector<int32_t> frontier{seed};
+      local[(size_t)seed] = 0;
+      while (!frontier.empty() && (int)members.size() < K5T_C) {
+        size_t best = 0;
+        for (size_t i = 1; i < frontier.size(); ++i)
+          if (local[(size_t)frontier[i]] > local[(size_t)frontier[best]]) best = i;
+        const int v = frontier[best];
+        frontier[best] = frontier.back();
+        frontier.pop_back();
+        if (!try_add(v)) { queue.push_back(v); continue; }   // does not fit the tile: left for a later cluster
         assigned[(size_t)v] = 1;
-        for (int32_t w : nbr[(size_t)v])
-          if (!assigned[(size_t)w] && local[(size_t)w] != -2) { local[(size_t)w] = -2; queue.push_back(w); }
+        queue.push_back(v);
+        for (int32_t w : nbr[(size_t)v]) {
+          if (assigned[(size_t)w]) continue;
+          if (local[(size_t)w] < 0) { local[(size_t)w] = 0; frontier.push_back(w); }
+          if (local[(size_t)w] >= 0) ++local[(size_t)w];
+        }
       }
-      for (size_t i = 0; i < queue.size(); ++i) {   // reset the queue flags; unassigned leftovers seed later clusters
+      for (int32_t w : frontier) queue.push_back(w);
+      for (size_t i = 0; i < queue.size(); ++i) {   // reset the scores; unassigned leftovers seed later clusters
         local[(size_t)queue[i]] = -1;
         if (!assigned[(size_t)queue[i]]) seeds.push_back(queue[i]);
       }
@@ -1369,10 +1382,10 @@ static int diameter_lanes(cmdp_t* h, DpTables t, int64_t unit_lo, int64_t unit_h
     // fixed-width-row kernel when a compiled (A, K) shape fits; option value 4 keeps the generic CSR walker
     const int A = h->A, K = h->max_row_nnz <= 2 ? 2 : (h->max_row_nnz <= 4 ? 4 : (h->max_row_nnz <= 8 ? 8 : 0));
     bool ell = false;
-    // K5T (value rows gathered into LDS tiles per cluster of states) for instances far beyond L2: option 6 forces it,
-    // 3 keeps K5S.  An instance with a state whose successors do not fit a tile falls back to K5S.
+    // K5T (value rows gathered into LDS tiles per cluster of states): on request only (option 6).  At C5 it halves the
+    // HBM traffic of K5S and is bit-equal, but runs 2.3 s against 2.05 s -- see DESIGN.md.
     bool tiles = false;
-    if (K && A >= 2 && A <= 4 && A * K <= 32 && (h->dp_kernel == 6 || (h->dp_kernel == 0 && h->max_S > 8192))) {
+    if (K && A >= 2 && A <= 4 && A * K <= 32 && h->dp_kernel == 6) {
       if (h->tile_K != K) {
         const int rc = build_tiles(h, K);
         if (rc != CMDP_OK && (rc != CMDP_ERR_UNSUPPORTED || h->dp_kernel == 6)) return rc;
@@ -1407,7 +1420,10 @@ static int diameter_lanes(cmdp_t* h, DpTables t, int64_t unit_lo, int64_t unit_h
         h->ell_K = K;
       }
       ell = true;
-      static const int k5s_nw = std::getenv("CMDP_K5S_NW") ? std::atoi(std::getenv("CMDP_K5S_NW")) : 8;  // tuning aid
+      // wavefronts per group: 8 fill the chip when there are at least two groups per CU; with fewer groups than CUs (a
+      // rank's share of C5 on an 8-GPU node: 98 groups) the launch lasts as long as ONE group, so each group gets 16
+      static const int k5s_env = std::getenv("CMDP_K5S_NW") ? std::atoi(std::getenv("CMDP_K5S_NW")) : 0;  // tuning aid
+      const int k5s_nw = k5s_env ? k5s_env : ((int64_t)n <= (int64_t)h->cus ? 16 : 8);
 #define ELL_CASE(AT, KT)                                                                                          \
   if (A == AT && K == KT) {                                                                                       \
     if (k5s_nw == 16)                                                                                             \

@@ -2224,7 +2224,7 @@ __global__ void __launch_bounds__(64) k_calib_lds_chain(int steps, int H, int32_
 // the position in the tile), float32 with separately rounded multiply and add, so the results are bit-equal to K5S, K2
 // and the oracle.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int K5T_C = 64;      // state slots per cluster
+constexpr int K5T_C = 32;      // state slots per cluster (<= 64: one lane per slot holds the slot's state number)
 struct TileArgs {
   const int32_t* inst_c0;      // [B] first cluster of the instance
   const int32_t* inst_ncl;     // [B] clusters of the instance

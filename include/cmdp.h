@@ -197,7 +197,7 @@ int cmdp_calibrate(int what, int64_t n_steps, double* ns_per_step);
    non-zeros per row, <= 1024 states), 3 = (cmdp_diameter only) the 64-targets-per-workgroup kernel K5S that is
    otherwise taken when the value vector of an instance does not fit LDS (4 = the same with its generic CSR walker
    instead of the fixed-width-row variant; 6 = its tiled form K5T, which gathers the value rows of a cluster of states
-   into LDS first and is the default above 8192 states), 5 = the distinct-successor form K2U of the register-resident kernel (taken
+   into LDS first: half the HBM traffic, same bits, not faster -- on request only), 5 = the distinct-successor form K2U of the register-resident kernel (taken
    by default when the A rows of a state share their successors: <= 8 distinct columns per state, rows in ascending
    column order; 2 keeps the per-row form K2R).  All forms return identical bits.
    CMDP_OPT_CHAIN_EXACT_ORDER (cmdp_average_reward / cmdp_qlearning_average_reward): 1 = every float64 sum of the GTH
