@@ -22,6 +22,7 @@ OPT_DIAMETER_WORKSPACE_MB = 4
 OPT_CHAIN_EXACT_ORDER = 5
 OPT_MIXING_PATH = 6
 STAT_DP_KERNEL_MS, STAT_DP_KERNEL = 1, 2
+NOISE_NONE, NOISE_GAUSSIAN, NOISE_GAUSSIAN_CORRELATED, NOISE_STUDENT_T, NOISE_STUDENT_T_CORRELATED = 0, 1, 2, 3, 4
 CALIB_LDS_READ, CALIB_LDS_CHAIN = 0, 1
 DP_AUTO, DP_WORKGROUP, DP_REGISTER = 0, 1, 2
 DP_REGISTER_DISTINCT = 5  # K2U: register-resident, gathers deduplicated per state
@@ -33,7 +34,7 @@ EXPORTS = [
     "cmdp_visits", "cmdp_reset_visits", "cmdp_state", "cmdp_last_start", "cmdp_vi_discounted", "cmdp_pe_discounted",
     "cmdp_vi_episodic", "cmdp_pe_episodic", "cmdp_diameter", "cmdp_diameter_episodic", "cmdp_value_norm", "cmdp_gth", "cmdp_qlearning_create", "cmdp_qlearning_destroy", "cmdp_qlearning_run",
     "cmdp_qlearning_tables", "cmdp_qlearning_evaluate", "cmdp_greedy_policy_episodic", "cmdp_qlearning_continuous_create",
-    "cmdp_qlearning_policy", "cmdp_qlearning_average_reward", "cmdp_average_reward", "cmdp_diameter_range", "cmdp_mixing_time", "cmdp_set_observation_table", "cmdp_observe",
+    "cmdp_qlearning_policy", "cmdp_qlearning_average_reward", "cmdp_qlearning_run_logged", "cmdp_tracker_replay", "cmdp_average_reward", "cmdp_diameter_range", "cmdp_mixing_time", "cmdp_set_observation_table", "cmdp_observe", "cmdp_observe_noise",
 ]
 
 
@@ -48,6 +49,26 @@ class CmdpDesc(C.Structure):
         ("start_cum", C.c_void_p), ("start_seed", C.c_void_p), ("philox_key", C.c_void_p),
         ("csr_ptr", C.c_void_p), ("csr_col", C.c_void_p), ("csr_val", C.c_void_p), ("R", C.c_void_p),
     ]
+
+
+class CmdpLoopDesc(C.Structure):
+    _fields_ = [
+        ("n_steps", C.c_int64), ("log_every", C.c_int64),
+        ("n_check", C.c_int32), ("horizon", C.c_int32), ("kmax", C.c_int32), ("reserved", C.c_int32),
+        ("max_time", C.c_double),
+        ("base_val", C.c_void_p), ("base_kind", C.c_void_p), ("opt0", C.c_void_p), ("worst0", C.c_void_p),
+        ("start_pos", C.c_void_p), ("start_prob", C.c_void_p),
+    ]
+
+
+LOG_COLUMNS = [  # CMDP_LOG_COLUMNS: the indicator names in sorted order, without "steps"
+    "cumulative_expected_reward", "cumulative_regret", "cumulative_reward", "normalized_cumulative_expected_reward",
+    "normalized_cumulative_regret", "normalized_cumulative_reward", "optimal_cumulative_expected_reward",
+    "optimal_normalized_cumulative_expected_reward", "random_cumulative_expected_reward", "random_cumulative_regret",
+    "random_normalized_cumulative_expected_reward", "random_normalized_cumulative_regret", "steps_per_second",
+    "worst_cumulative_expected_reward", "worst_cumulative_regret", "worst_normalized_cumulative_expected_reward",
+    "worst_normalized_cumulative_regret",
+]
 
 
 class CmdpError(RuntimeError):
@@ -142,6 +163,8 @@ def load():
         L.cmdp_qlearning_destroy.argtypes = [vp]
         L.cmdp_qlearning_run.argtypes = [vp, i64, vp, vp, vp]
         L.cmdp_qlearning_evaluate.argtypes = [vp, vp]
+        L.cmdp_qlearning_run_logged.argtypes = [vp, C.POINTER(CmdpLoopDesc), i64, vp, vp, vp, vp, vp]
+        L.cmdp_tracker_replay.argtypes = [C.POINTER(CmdpLoopDesc), i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.cmdp_qlearning_continuous_create.argtypes = [C.POINTER(vp), vp, vp, i64, f64, f64, f64, f64]
         L.cmdp_qlearning_policy.argtypes = [vp, vp]
         L.cmdp_qlearning_average_reward.argtypes = [vp, vp, vp, vp]
@@ -150,6 +173,7 @@ def load():
         L.cmdp_mixing_time.argtypes = [vp, vp, vp, C.c_double, i64, vp, vp]
         L.cmdp_set_observation_table.argtypes = [vp, vp, i32, i32]
         L.cmdp_observe.argtypes = [vp, C.c_double, vp]
+        L.cmdp_observe_noise.argtypes = [vp, i32, C.c_double, C.c_double, vp, vp]
         L.cmdp_greedy_policy_episodic.argtypes = [vp, i32, i32, vp, vp]
         L.cmdp_qlearning_tables.argtypes = [vp, vp, vp]
         _lib = L

@@ -37,6 +37,20 @@ class BatchedQLearningEpisodic:
         L.check(self._lib.cmdp_qlearning_run(self._h, n_steps, L.ptr(mask), L.ptr(acts), L.ptr(rsum)))
         return dict(cumulative_reward=rsum, actions=acts)
 
+    def run_logged(self, desc, n_logs: int):
+        """`MDPLoop.run` for the whole batch in one library call (cmdp_qlearning_run_logged): interaction, policy
+        evaluation at every logging step and the reference's indicators, all without returning to Python.  `desc` from
+        `vector_tracker.loop_desc`.  Returns (steps [n_logs], values, kinds [n_logs, 17, B], last_training_step, is_training)."""
+        B = self.env.B
+        steps = np.zeros(n_logs, np.int64)
+        values = np.zeros((n_logs, len(L.LOG_COLUMNS), B), np.float64)
+        kinds = np.zeros((n_logs, len(L.LOG_COLUMNS), B), np.uint8)
+        last = np.zeros(B, np.int64)
+        training = np.zeros(B, np.uint8)
+        L.check(self._lib.cmdp_qlearning_run_logged(self._h, C.byref(desc), int(n_logs), L.ptr(steps), L.ptr(values), L.ptr(kinds),
+                                                    L.ptr(last), L.ptr(training)))
+        return steps, values, kinds, last, training.astype(bool)
+
     def evaluate(self) -> np.ndarray:
         """V[0, :] (concatenated over instances) of the current greedy policies, policy and evaluation on device."""
         V0 = np.zeros(int(self.env.state_off[-1]), np.float32)

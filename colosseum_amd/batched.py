@@ -246,6 +246,20 @@ class BatchedMDP:
         L.check(self._lib.cmdp_observe(self._h, float(noise_scale), L.ptr(out)))
         return out
 
+    def observe_noise(self, kind: str, scale: float = 0.1, df: float = 3.0, covariance=None) -> np.ndarray:
+        """Observations with one of the reference's four noise classes sampled on the device (throughput mode):
+        kind in "GaussianUncorrelated" (scale), "GaussianCorrelated" (covariance [F, F]), "StudentTUncorrelated" (df),
+        "StudentTCorrelated" (covariance = shape matrix, df)."""
+        code = {"GaussianUncorrelated": L.NOISE_GAUSSIAN, "GaussianCorrelated": L.NOISE_GAUSSIAN_CORRELATED,
+                "StudentTUncorrelated": L.NOISE_STUDENT_T, "StudentTCorrelated": L.NOISE_STUDENT_T_CORRELATED}[kind]
+        chol = None
+        if covariance is not None:
+            chol = np.ascontiguousarray(np.linalg.cholesky(np.asarray(covariance, np.float64)), np.float32)
+            assert chol.shape == (self._obs_F, self._obs_F)
+        out = np.zeros((self.B, self._obs_F), np.float32)
+        L.check(self._lib.cmdp_observe_noise(self._h, code, float(scale), float(df), L.ptr(chol), L.ptr(out)))
+        return out
+
     def average_reward(self, actions, start_states, mask=None):
         """`get_average_reward(T, R, one_hot(actions), [(start, 1.0)])` for every (continuous) instance on the device
         (kernel K9).  actions: per-instance arrays [S_b] (or one flat array); returns (values, n_recurrent_classes) with

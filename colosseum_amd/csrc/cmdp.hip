@@ -6,6 +6,7 @@
 #include <cstdlib>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
@@ -17,6 +18,7 @@
 #include <vector>
 
 #include "cmdp_kernels.h"
+#include "cmdp_tracker.h"
 #include "cmdp_agent.h"
 #include "cmdp_chain.h"
 
@@ -77,6 +79,17 @@ struct DevBuf {
   ~DevBuf() { release(); }
 };
 
+// Page-locked host memory for the per-log read-backs of the logged loop.
+template <typename T>
+struct PinnedBuf {
+  T* p = nullptr;
+  int alloc(size_t n) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p), sizeof(T) * std::max<size_t>(n, 1), 0));
+    return CMDP_OK;
+  }
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+};
+
 }  // namespace
 
 struct cmdp {
@@ -135,7 +148,7 @@ struct cmdp {
   DevBuf<int64_t> d_dl_voff;
   size_t dl_ws_bytes = (size_t)24 << 30;  // value arrays of the target groups in flight per launch
   // observation tables (k_emit)
-  DevBuf<float> d_obs_table, d_obs_out;
+  DevBuf<float> d_obs_table, d_obs_out, d_obs_chol;
   DevBuf<unsigned long long> d_n_obs;
   int obs_F = 0, obs_time_indexed = 0;
   // cmdp_average_reward workspace (K9)
@@ -1744,8 +1757,9 @@ int cmdp_qlearning_policy(cmdp_agent_t* a, float* pi) {
 
 // K9 launch shared by cmdp_average_reward / cmdp_qlearning_average_reward: policy either as device one-hot rows
 // (`d_pi`) or device actions (`d_act`); start states on the device.
+// `mask_on_device`: `mask` is already a device pointer (the logged loop keeps its need-mask there)
 static int chain_launch(cmdp_t* h, const float* d_pi, const int32_t* d_act, const int32_t* d_start, const uint8_t* mask,
-                        double* avg, int32_t* kind, int32_t* n_classes) {
+                        double* avg, int32_t* kind, int32_t* n_classes, bool mask_on_device = false, bool copy_back = true) {
   if (!h->has_dp) return fail(CMDP_ERR_INVALID, "the handle was created without the DP half (CSR transition matrices)");
   if (h->H != 0) return fail(CMDP_ERR_INVALID, "average rewards are defined for continuous instances (horizon 0)");
   const size_t lds = chain_lds_bytes(h->max_S, h->max_row_nnz);
@@ -1769,7 +1783,9 @@ static int chain_launch(cmdp_t* h, const float* d_pi, const int32_t* d_act, cons
     HIP_TRY(h->d_ch_ncls.alloc(B));
   }
   const uint8_t* dmask = nullptr;
-  if (mask) {
+  if (mask && mask_on_device) {
+    dmask = mask;
+  } else if (mask) {
     HIP_TRY(h->d_ch_mask.upload(mask, B, st));
     dmask = h->d_ch_mask.p;
   }
@@ -1806,6 +1822,7 @@ static int chain_launch(cmdp_t* h, const float* d_pi, const int32_t* d_act, cons
                  ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
   }
   HIP_TRY(hipGetLastError());
+  if (!copy_back) return CMDP_OK;  // the caller reads d_ch_avg / d_ch_kind itself
   HIP_TRY(hipMemcpyAsync(avg, h->d_ch_avg.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(kind, h->d_ch_kind.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
   if (n_classes) HIP_TRY(hipMemcpyAsync(n_classes, h->d_ch_ncls.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
@@ -1860,22 +1877,37 @@ int cmdp_set_observation_table(cmdp_t* h, const float* table, int32_t F, int tim
   return CMDP_OK;
 }
 
-int cmdp_observe(cmdp_t* h, double noise_scale, float* obs) {
+int cmdp_observe_noise(cmdp_t* h, int kind, double scale, double df, const float* chol, float* obs) {
   if (int rc = bind(h)) return rc;
   if (!obs) return fail(CMDP_ERR_INVALID, "null output");
   if (h->obs_F < 1) return fail(CMDP_ERR_INVALID, "no observation table: call cmdp_set_observation_table first");
-  if (noise_scale > 0.0 && h->rng_mode != CMDP_RNG_PHILOX)
+  if (kind < CMDP_NOISE_NONE || kind > CMDP_NOISE_STUDENT_T_CORRELATED) return fail(CMDP_ERR_INVALID, "unknown noise kind %d", kind);
+  const bool noisy = kind >= CMDP_NOISE_GAUSSIAN_CORRELATED || (kind == CMDP_NOISE_GAUSSIAN && scale > 0.0);
+  if (noisy && h->rng_mode != CMDP_RNG_PHILOX)
     return fail(CMDP_ERR_UNSUPPORTED, "device noise needs CMDP_RNG_PHILOX (the reference-exact noise stream is host side)");
+  const bool correlated = kind == CMDP_NOISE_GAUSSIAN_CORRELATED || kind == CMDP_NOISE_STUDENT_T_CORRELATED;
+  if (correlated && !chol) return fail(CMDP_ERR_INVALID, "correlated noise needs the Cholesky factor");
+  if ((kind == CMDP_NOISE_STUDENT_T || kind == CMDP_NOISE_STUDENT_T_CORRELATED) && !(df > 0.0))
+    return fail(CMDP_ERR_INVALID, "Student-t noise needs df > 0");
+  const size_t lds = correlated ? sizeof(double) * (size_t)h->obs_F : 0;
+  if (lds > (size_t)kLdsBudget - 1024) return fail(CMDP_ERR_UNSUPPORTED, "observations of %d elements: the normals do not fit LDS", h->obs_F);
   hipStream_t st = h->stream;
+  if (correlated) HIP_TRY(h->d_obs_chol.upload(chol, (size_t)h->obs_F * h->obs_F, st));
   EmitArgs e{};
   e.B = h->B; e.F = h->obs_F; e.H = h->H; e.time_indexed = h->obs_time_indexed;
   e.state_off = h->d_state_off.p; e.table = h->d_obs_table.p; e.cur = h->d_cur.p; e.hstep = h->d_h.p;
-  e.key = h->d_key.p; e.n_obs = h->d_n_obs.p; e.scale = noise_scale; e.out = h->d_obs_out.p;
-  hipLaunchKernelGGL(k_emit, dim3(h->B), dim3(256), 0, st, e);
+  e.key = h->d_key.p; e.n_obs = h->d_n_obs.p; e.scale = scale; e.kind = kind; e.df = df;
+  e.chol = correlated ? h->d_obs_chol.p : nullptr; e.out = h->d_obs_out.p;
+  if (int rc = set_lds(k_emit, lds)) return rc;
+  hipLaunchKernelGGL(k_emit, dim3(h->B), dim3(256), lds, st, e);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(obs, h->d_obs_out.p, sizeof(float) * (size_t)h->B * h->obs_F, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   return CMDP_OK;
+}
+
+int cmdp_observe(cmdp_t* h, double noise_scale, float* obs) {
+  return cmdp_observe_noise(h, noise_scale > 0.0 ? CMDP_NOISE_GAUSSIAN : CMDP_NOISE_NONE, noise_scale, 0.0, nullptr, obs);
 }
 
 }  // extern "C"
@@ -2140,6 +2172,21 @@ int cmdp_qlearning_destroy(cmdp_agent_t* a) {
   return CMDP_OK;
 }
 
+// the interaction kernel of `n_steps` steps on the handle's stream (no synchronisation, no copies)
+static int ql_enqueue_run(cmdp_agent_t* a, int64_t n_steps, const uint8_t* dmask, int8_t* d_actions) {
+  cmdp_t* h = a->env;
+  hipStream_t st = h->stream;
+  const dim3 grid(grid_for(h->B, 256)), block(256);
+  if (a->continuous)
+    hipLaunchKernelGGL(k_qlearn_continuous, grid, block, 0, st, h->env(), a->cargs, n_steps, dmask, d_actions, a->d_rsum.p);
+  else if (a->args.ucb == 0)
+    hipLaunchKernelGGL((k_qlearn_episodic<0>), grid, block, 0, st, h->env(), a->args, n_steps, dmask, d_actions, a->d_rsum.p);
+  else
+    hipLaunchKernelGGL((k_qlearn_episodic<1>), grid, block, 0, st, h->env(), a->args, n_steps, dmask, d_actions, a->d_rsum.p);
+  HIP_TRY(hipGetLastError());
+  return CMDP_OK;
+}
+
 int cmdp_qlearning_run(cmdp_agent_t* a, int64_t n_steps, const uint8_t* train_mask, int8_t* actions_trace,
                        double* reward_sum) {
   if (!a) return fail(CMDP_ERR_INVALID, "null agent");
@@ -2157,27 +2204,16 @@ int cmdp_qlearning_run(cmdp_agent_t* a, int64_t n_steps, const uint8_t* train_ma
     HIP_TRY(a->d_mask.upload(train_mask, h->B, st));
     dmask = a->d_mask.p;
   }
-  const dim3 grid(grid_for(h->B, 256)), block(256);
-  if (a->continuous)
-    hipLaunchKernelGGL(k_qlearn_continuous, grid, block, 0, st, h->env(), a->cargs, n_steps, dmask,
-                       actions_trace ? a->d_act.p : nullptr, a->d_rsum.p);
-  else if (a->args.ucb == 0)
-    hipLaunchKernelGGL((k_qlearn_episodic<0>), grid, block, 0, st, h->env(), a->args, n_steps, dmask,
-                       actions_trace ? a->d_act.p : nullptr, a->d_rsum.p);
-  else
-    hipLaunchKernelGGL((k_qlearn_episodic<1>), grid, block, 0, st, h->env(), a->args, n_steps, dmask,
-                       actions_trace ? a->d_act.p : nullptr, a->d_rsum.p);
-  HIP_TRY(hipGetLastError());
+  if (int rc = ql_enqueue_run(a, n_steps, dmask, actions_trace ? a->d_act.p : nullptr)) return rc;
   if (actions_trace) HIP_TRY(hipMemcpyAsync(actions_trace, a->d_act.p, NB, hipMemcpyDeviceToHost, st));
   if (reward_sum) HIP_TRY(hipMemcpyAsync(reward_sum, a->d_rsum.p, sizeof(double) * h->B, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   return CMDP_OK;
 }
 
-int cmdp_qlearning_evaluate(cmdp_agent_t* a, float* V0) {
-  if (!a || !V0) return fail(CMDP_ERR_INVALID, "null argument");
+// greedy policy of the agents' Q tables -> episodic policy evaluation -> V[0, :] packed into a->d_v0 (no synchronisation)
+static int ql_enqueue_evaluate(cmdp_agent_t* a) {
   cmdp_t* h = a->env;
-  if (int rc = bind(h)) return rc;
   if (a->continuous) return fail(CMDP_ERR_INVALID, "cmdp_qlearning_evaluate is for the episodic agent; use cmdp_qlearning_policy");
   if (!h->has_dp) return fail(CMDP_ERR_INVALID, "the environment handle was created without the DP half");
   hipStream_t st = h->stream;
@@ -2197,12 +2233,185 @@ int cmdp_qlearning_evaluate(cmdp_agent_t* a, float* V0) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_episodic<DP_PE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((k_episodic<DP_PE>), dim3(h->B), dim3(kDpBlock), lds, st, t, H, h->d_Q.p, h->d_V.p);
   HIP_TRY(hipGetLastError());
-  // V[0, :] of instance b sits at (H+1)*state_off[b]: pack, then one copy
+  // V[0, :] of instance b sits at (H+1)*state_off[b]: pack
   if (a->d_v0.n < (size_t)h->n_states) HIP_TRY(a->d_v0.alloc(h->n_states));
   hipLaunchKernelGGL(k_gather_v0, dim3(h->B), dim3(256), 0, st, h->B, H, h->d_state_off.p, h->d_V.p, a->d_v0.p);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(V0, a->d_v0.p, sizeof(float) * (size_t)h->n_states, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  return CMDP_OK;
+}
+
+int cmdp_qlearning_evaluate(cmdp_agent_t* a, float* V0) {
+  if (!a || !V0) return fail(CMDP_ERR_INVALID, "null argument");
+  cmdp_t* h = a->env;
+  if (int rc = bind(h)) return rc;
+  if (int rc = ql_enqueue_evaluate(a)) return rc;
+  HIP_TRY(hipMemcpyAsync(V0, a->d_v0.p, sizeof(float) * (size_t)h->n_states, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CMDP_OK;
+}
+
+int cmdp_qlearning_run_logged(cmdp_agent_t* a, const cmdp_loop_desc* d, int64_t n_logs, int64_t* steps, double* values,
+                              uint8_t* kinds, int64_t* last_training_step, uint8_t* is_training) {
+  using namespace cmdp_tracker;
+  if (!a || !d || !steps || !values || !kinds) return fail(CMDP_ERR_INVALID, "null argument");
+  cmdp_t* h = a->env;
+  if (int rc = bind(h)) return rc;
+  const int B = h->B;
+  const int64_t T = d->n_steps, log_every = d->log_every;
+  if (T < 1) return fail(CMDP_ERR_INVALID, "n_steps < 1");
+  std::vector<int64_t> log_ts;
+  if (log_every > 0)
+    for (int64_t t = log_every; t < T; t += log_every) log_ts.push_back(t);
+  if (n_logs != (int64_t)log_ts.size() + 1)
+    return fail(CMDP_ERR_INVALID, "n_logs must be %lld for %lld steps logged every %lld", (long long)log_ts.size() + 1, (long long)T,
+                (long long)log_every);
+  if (!d->base_val || !d->base_kind) return fail(CMDP_ERR_INVALID, "baseline average rewards missing");
+  const bool episodic = !a->continuous;
+  if (episodic && (!d->opt0 || !d->worst0 || !d->start_pos || !d->start_prob || d->kmax < 1))
+    return fail(CMDP_ERR_INVALID, "episodic baselines missing");
+  if (!episodic)
+    for (int b = 0; b < B; ++b)
+      if (!(d->base_val[3 * b] - d->base_val[3 * b + 1] > 0.0002))   // agent_mdp_interaction.py:379-382
+        return fail(CMDP_ERR_INVALID, "instance %d: optimal and worst average reward are closer than 0.0002", b);
+  hipStream_t st = h->stream;
+  const int64_t NS = h->n_states;
+  Tracker tr;
+  tr.init(B, d->n_check, d->base_val, d->base_kind);
+  EpisodicInputs ein{h->H, d->opt0, d->worst0, d->start_pos, d->start_prob, d->kmax};
+  PinnedBuf<double> cum, avg;
+  PinnedBuf<float> v0;
+  PinnedBuf<int32_t> last, prev, hstep, akind;
+  PinnedBuf<uint8_t> mask, need;
+  if (int rc = cum.alloc(B)) return rc;
+  if (int rc = avg.alloc(B)) return rc;
+  if (int rc = v0.alloc((size_t)NS)) return rc;
+  if (int rc = last.alloc(B)) return rc;
+  if (int rc = prev.alloc(B)) return rc;
+  if (int rc = hstep.alloc(B)) return rc;
+  if (int rc = akind.alloc(B)) return rc;
+  if (int rc = mask.alloc(B)) return rc;
+  if (int rc = need.alloc(B)) return rc;
+  if (a->d_mask.n < (size_t)B) HIP_TRY(a->d_mask.alloc(B));
+  if (h->d_ch_mask.n < (size_t)B) HIP_TRY(h->d_ch_mask.alloc(B));
+  std::vector<int64_t> start_abs((size_t)B);
+  for (int b = 0; b < B; ++b) { mask.p[b] = 1; cum.p[b] = 0.0; if (last_training_step) last_training_step[b] = -1; }
+  HIP_TRY(hipMemcpyAsync(a->d_mask.p, mask.p, B, hipMemcpyHostToDevice, st));
+  // MDPLoop.run: visitation counts cleared, environment reset (agent_mdp_interaction.py:219-224)
+  if (int rc = cmdp_reset_visits(h)) return rc;
+  if (int rc = cmdp_reset(h, nullptr, nullptr)) return rc;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+
+  auto log_row = [&](int64_t i, int64_t t, int64_t n_since, bool in_loop) -> int {
+    // evaluation of the agents' current greedy policies, then one synchronisation for everything this row reads
+    if (episodic) {
+      if (int rc = ql_enqueue_evaluate(a)) return rc;
+      HIP_TRY(hipMemcpyAsync(v0.p, a->d_v0.p, sizeof(float) * (size_t)NS, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(last.p, h->d_last_start.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(prev.p, h->d_prev_start.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(hstep.p, h->d_h.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+    } else {
+      continuous_need(tr, need.p);
+      bool any = false;
+      for (int b = 0; b < B; ++b) any = any || need.p[b];
+      if (any) {
+        HIP_TRY(hipMemcpyAsync(h->d_ch_mask.p, need.p, B, hipMemcpyHostToDevice, st));
+        if (a->d_pi.n < (size_t)a->n_q) HIP_TRY(a->d_pi.alloc(a->n_q));
+        hipLaunchKernelGGL(k_greedy_policy_episodic<double>, dim3(B), dim3(64), 0, st, B, h->A, 1, 1, h->d_state_off.p,
+                           a->d_Qc.p, a->d_pi.p);
+        HIP_TRY(hipGetLastError());
+        if (int rc = chain_launch(h, a->d_pi.p, nullptr, h->d_cur.p, h->d_ch_mask.p, nullptr, nullptr, nullptr, true, false))
+          return rc;
+        HIP_TRY(hipMemcpyAsync(avg.p, h->d_ch_avg.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(akind.p, h->d_ch_kind.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+      }
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    const double sps = (double)t / std::max(elapsed(), 1e-9);
+    double* val = values + (size_t)i * N_COLUMNS * B;
+    uint8_t* knd = kinds + (size_t)i * N_COLUMNS * B;
+    steps[i] = t;
+    if (episodic) {
+      // the reference logs step t before the reset that follows a termination: if step t ended an episode (in-episode
+      // time back at 0), its `last_starting_node` is still the start of the episode that ended
+      for (int b = 0; b < B; ++b)
+        start_abs[(size_t)b] = h->state_off[b] + ((hstep.p[b] == 0 && in_loop) ? prev.p[b] : last.p[b]);
+      episodic_update(tr, ein, t, T, v0.p, start_abs.data(), cum.p, n_since, in_loop, sps, val, knd);
+    } else {
+      continuous_update(tr, t, T, need.p, avg.p, akind.p, cum.p, n_since, in_loop, sps, val, knd);
+    }
+    return CMDP_OK;
+  };
+
+  int64_t done = 0, n_since = 0;
+  for (size_t i = 0; i < log_ts.size(); ++i) {
+    const int64_t tl = log_ts[i];
+    // the reference reads `_cumulative_reward` at step tl BEFORE adding that step's reward: the sum is copied after step
+    // tl-1, then step tl runs (whose update the logged policy already contains)
+    if (tl - done > 0) {
+      if (int rc = ql_enqueue_run(a, tl - done, a->d_mask.p, nullptr)) return rc;
+      HIP_TRY(hipMemcpyAsync(cum.p, a->d_rsum.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+      n_since += tl - done;
+    }
+    if (int rc = ql_enqueue_run(a, 1, a->d_mask.p, nullptr)) return rc;
+    done = tl + 1;
+    if (int rc = log_row((int64_t)i, tl, n_since, true)) return rc;
+    bool changed = false;
+    const bool out_of_time = d->max_time - elapsed() < 0.5;  // `_limit_exceeded` (agent_mdp_interaction.py:172-177) for the batch
+    for (int b = 0; b < B; ++b) {
+      if (out_of_time && tr.inst[(size_t)b].training) {
+        tr.inst[(size_t)b].training = false;
+        if (last_training_step) last_training_step[b] = tl;
+      }
+      const uint8_t m = tr.inst[(size_t)b].training ? 1 : 0;
+      changed = changed || m != mask.p[b];
+      mask.p[b] = m;
+    }
+    if (changed) HIP_TRY(hipMemcpyAsync(a->d_mask.p, mask.p, B, hipMemcpyHostToDevice, st));
+    n_since = 1;
+  }
+  if (T - done > 0) {
+    n_since += T - done;
+    if (int rc = ql_enqueue_run(a, T - done, a->d_mask.p, nullptr)) return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(cum.p, a->d_rsum.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+  if (int rc = log_row((int64_t)log_ts.size(), T - 1, n_since, false)) return rc;
+  if (is_training)
+    for (int b = 0; b < B; ++b) is_training[b] = tr.inst[(size_t)b].training ? 1 : 0;
+  h->known_reset = true;
+  return CMDP_OK;
+}
+
+// The indicator code alone, on inputs given by the caller (no device involved): what cmdp_qlearning_run_logged does with
+// the values it reads back at every logging step.  Exists so that the CPU test suite can hold the C++ tracker against the
+// reference's own indicator code (golden G15).
+int cmdp_tracker_replay(const cmdp_loop_desc* d, int32_t B, int32_t episodic, const int64_t* state_off, int64_t n_logs,
+                        const int64_t* log_steps, const uint8_t* in_loop, const int64_t* n_since, const double* cum_reward,
+                        const float* V0, const int64_t* start_state, const double* avg, const int32_t* avg_kind,
+                        double* values, uint8_t* kinds, uint8_t* is_training) {
+  using namespace cmdp_tracker;
+  if (!d || !log_steps || !in_loop || !n_since || !cum_reward || !values || !kinds) return fail(CMDP_ERR_INVALID, "null argument");
+  Tracker tr;
+  tr.init(B, d->n_check, d->base_val, d->base_kind);
+  std::vector<uint8_t> need((size_t)B);
+  std::vector<int64_t> start_abs((size_t)B);
+  const int64_t NS = episodic ? state_off[B] : 0;
+  EpisodicInputs ein{d->horizon, d->opt0, d->worst0, d->start_pos, d->start_prob, d->kmax};
+  for (int64_t i = 0; i < n_logs; ++i) {
+    double* val = values + (size_t)i * N_COLUMNS * B;
+    uint8_t* knd = kinds + (size_t)i * N_COLUMNS * B;
+    if (episodic) {
+      for (int b = 0; b < B; ++b) start_abs[(size_t)b] = state_off[b] + start_state[(size_t)i * B + b];
+      episodic_update(tr, ein, log_steps[i], d->n_steps, V0 + (size_t)i * NS, start_abs.data(), cum_reward + (size_t)i * B,
+                      n_since[i], in_loop[i] != 0, 0.0, val, knd);
+    } else {
+      continuous_need(tr, need.data());
+      continuous_update(tr, log_steps[i], d->n_steps, need.data(), avg + (size_t)i * B, avg_kind + (size_t)i * B,
+                        cum_reward + (size_t)i * B, n_since[i], in_loop[i] != 0, 0.0, val, knd);
+    }
+    if (is_training)
+      for (int b = 0; b < B; ++b) is_training[(size_t)i * B + b] = tr.inst[(size_t)b].training ? 1 : 0;
+  }
   return CMDP_OK;
 }
 

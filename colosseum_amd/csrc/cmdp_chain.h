@@ -629,11 +629,20 @@ struct EmitArgs {
   const int32_t* hstep;
   const uint2* key;
   unsigned long long* n_obs;   // [B] observations emitted so far (noise counter)
-  double scale;                // <= 0: no noise
+  double scale;                // Gaussian uncorrelated: standard deviation; <= 0 with kind 1: no noise
+  int32_t kind;                // 0 none, 1 Gaussian uncorrelated, 2 Gaussian correlated, 3 Student-t uncorrelated, 4 Student-t correlated
+  double df;                   // Student-t degrees of freedom
+  const float* chol;           // [F][F] lower Cholesky factor of the covariance / shape matrix (kinds 2, 4)
   float* out;                  // [B][F]
 };
 
+// Noise kinds of the throughput mode (the reference-exact streams are numpy's and stay on the host): standard normals z_j
+// from Philox domain 4 (Box-Muller, counter = (observation number, element pair)); Student-t: z / sqrt(chi2(df) / df) with
+// chi2(df) = 2 Gamma(df / 2) (Marsaglia-Tsang on Philox domain 5: one per element when uncorrelated, one per observation
+// when correlated -- the multivariate t); correlated kinds multiply by the lower Cholesky factor L of the covariance /
+// shape matrix, y = L z (float64 accumulation in index order), with z staged in LDS.
 __global__ void __launch_bounds__(256) k_emit(EmitArgs e) {
+  extern __shared__ double emit_z[];
   const int b = blockIdx.x;
   const int64_t so = e.state_off[b];
   const int S = (int)(e.state_off[b + 1] - so);
@@ -643,18 +652,43 @@ __global__ void __launch_bounds__(256) k_emit(EmitArgs e) {
   const float* row = e.table + ((int64_t)(e.time_indexed ? e.H : 1) * so + (int64_t)layer * S + e.cur[b]) * e.F;
   const unsigned long long n = e.n_obs[b];
   const uint2 key = e.key ? e.key[b] : make_uint2(0, 0);
+  const bool noisy = !ended && (e.kind >= 2 || (e.kind == 1 && e.scale > 0.0));
+  const bool correlated = e.kind == 2 || e.kind == 4;
+  auto normal = [&](int j) -> double {
+    uint32_t w[4];
+    philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 4u, (uint32_t)(j >> 1), key.x, key.y, w);
+    const uint32_t a = (j & 1) ? w[2] : w[0], c = (j & 1) ? w[3] : w[1];
+    const double u1 = ((double)a + 1.0) * (1.0 / 4294967296.0), u2 = (double)c * (1.0 / 4294967296.0);
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+  };
+  if (noisy && correlated) {
+    for (int j = threadIdx.x; j < e.F; j += blockDim.x) emit_z[j] = normal(j);
+    __syncthreads();
+  }
+  double t_scale = 1.0;
+  if (noisy && e.kind == 4) {  // one chi-square per observation, the same for every element
+    uint32_t draw = 0;
+    t_scale = 1.0 / sqrt(2.0 * philox_gamma(0.5 * e.df, n, key, draw, 5u) / e.df);
+  }
   for (int j = threadIdx.x; j < e.F; j += blockDim.x) {
     float v = ended ? 0.0f : row[j];
-    if (e.scale > 0.0 && !ended) {
-      uint32_t w[4];
-      philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 4u, (uint32_t)(j >> 1), key.x, key.y, w);
-      const uint32_t a = (j & 1) ? w[2] : w[0], c = (j & 1) ? w[3] : w[1];
-      const double u1 = ((double)a + 1.0) * (1.0 / 4294967296.0), u2 = (double)c * (1.0 / 4294967296.0);
-      const double z = sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
-      v = v + (float)(e.scale * z);
+    if (noisy) {
+      double y;
+      if (correlated) {
+        y = 0.0;
+        const float* lrow = e.chol + (int64_t)j * e.F;
+        for (int k = 0; k <= j; ++k) y += (double)lrow[k] * emit_z[k];
+        y *= t_scale;
+      } else if (e.kind == 3) {
+        uint32_t draw = (uint32_t)j << 8;
+        y = normal(j) / sqrt(2.0 * philox_gamma(0.5 * e.df, n, key, draw, 5u) / e.df);
+      } else {
+        y = e.scale * normal(j);
+      }
+      v = v + (float)y;
     }
     e.out[(int64_t)b * e.F + j] = v;
   }
   __syncthreads();
-  if (threadIdx.x == 0 && e.scale > 0.0 && !ended) e.n_obs[b] = n + 1;
+  if (threadIdx.x == 0 && noisy) e.n_obs[b] = n + 1;
 }

@@ -152,23 +152,24 @@ __device__ __forceinline__ float wave_min(float v) {
 // half, the acceptance uniform; shapes below one use Gamma(shape + 1) * U^(1/shape).  The CPU oracle runs the
 // same recipe with libm, so the two agree to rounding of log/sqrt/cos/pow (tests compare with rtol 1e-12).
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double philox_gamma(double shape, unsigned long long n, uint2 key, uint32_t& draw) {
+__device__ __forceinline__ double philox_gamma(double shape, unsigned long long n, uint2 key, uint32_t& draw,
+                                               uint32_t domain = 3u) {
   double boost = 1.0;
   uint32_t w[4];
   if (shape < 1.0) {
-    philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 3u, draw++, key.x, key.y, w);
+    philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), domain, draw++, key.x, key.y, w);
     boost = pow(1.0 - u53(w[0], w[1]), 1.0 / shape);
     shape += 1.0;
   }
   const double d = shape - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
   for (int attempt = 0; attempt < 64; ++attempt) {
-    philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 3u, draw++, key.x, key.y, w);
+    philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), domain, draw++, key.x, key.y, w);
     const double u1 = u53(w[0], w[1]), u2 = u53(w[2], w[3]);
     const double z = sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586476925286766559 * u2);
     double v = 1.0 + c * z;
     if (v <= 0.0) continue;
     v = v * v * v;
-    philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 3u, draw++, key.x, key.y, w);
+    philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), domain, draw++, key.x, key.y, w);
     const double u3 = u53(w[0], w[1]);
     if (log(u3) < 0.5 * z * z + d - d * v + d * log(v)) return boost * d * v;
   }

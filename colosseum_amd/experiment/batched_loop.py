@@ -33,7 +33,32 @@ class _BatchedLoop:
     def _log(self, t: int, cum: np.ndarray, n_since: int, T: int, in_loop: bool):
         raise NotImplementedError
 
+    native = True  # the whole run in one library call (cmdp_qlearning_run_logged); False: the Python-driven loop below
+
+    def _desc(self, T: int, log_every: int, max_time: float):
+        raise NotImplementedError
+
     def run(self, T: int, log_every: int = -1, max_time: float = np.inf) -> List[List[Dict[str, float]]]:
+        if self.native:
+            try:
+                return self._run_native(T, log_every, max_time)
+            except L.CmdpError as e:  # e.g. a continuous instance beyond the LDS budget of the chain kernel K9
+                if e.code != L.ERR_UNSUPPORTED:
+                    raise
+        return self._run_python(T, log_every, max_time)
+
+    def _run_native(self, T: int, log_every: int, max_time: float):
+        from .vector_tracker import n_log_rows, native_log
+
+        self.vt.reset()
+        desc, keep = self._desc(T, log_every, max_time)
+        steps, values, kinds, last, training = self.agent.run_logged(desc, n_log_rows(T, log_every))
+        self.vt.log = native_log(self.env.B, steps, values, kinds)
+        self.vt.is_training = training
+        self.last_training_step = last
+        return self.vt.tables()
+
+    def _run_python(self, T: int, log_every: int = -1, max_time: float = np.inf) -> List[List[Dict[str, float]]]:
         from time import time
 
         env, agent = self.env, self.agent
@@ -85,6 +110,13 @@ class BatchedEpisodicLoop(_BatchedLoop):
         self.vt = EpisodicVectorTracker(H, env.state_off, *flat0, [(m.start_states, m.start_probs) for m in env.models],
                                         n_log_intervals_to_check_for_agent_optimality)
 
+    def _desc(self, T, log_every, max_time):
+        from .vector_tracker import loop_desc
+
+        vt = self.vt
+        return loop_desc(T, log_every, vt.n_check, (vt.opt, vt.worst, vt.rand), max_time, H=vt.H, opt0=vt.opt0, worst0=vt.worst0,
+                         start_pos=vt._ss, start_prob=vt._sp)
+
     def _log(self, t: int, cum: np.ndarray, n_since: int, T: int, in_loop: bool):
         V0 = self.agent.evaluate()
         last_start = self.env.last_start()
@@ -126,6 +158,12 @@ class BatchedContinuousLoop(_BatchedLoop):
         self.cache = AverageRewardCache(self._TR)
         self.vt = ContinuousVectorTracker(*(MP.from_scalars(vals[j::3]) for j in range(3)),
                                           n_log_intervals_to_check_for_agent_optimality)
+
+    def _desc(self, T, log_every, max_time):
+        from .vector_tracker import loop_desc
+
+        vt = self.vt
+        return loop_desc(T, log_every, vt.n_check, (vt.opt, vt.worst, vt.rand), max_time)
 
     def _log(self, t, cum, n_since, T, in_loop):
         def averages(need):

@@ -440,3 +440,48 @@ def csv_texts_parallel(logs: Sequence["BatchLog"], workers: int, chunk: int = 16
     for (key, b0), texts in zip(where, parts):
         out.setdefault(key, {})[b0] = texts
     return {key: [t for b0 in sorted(d) for t in d[b0]] for key, d in out.items()}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The same indicators computed by the library in C++ (csrc/cmdp_tracker.h): what `cmdp_qlearning_run_logged` runs between
+# kernels.  `native_log` wraps its output as a `BatchLog`; `loop_desc` builds the description both entry points take.
+def loop_desc(T: int, log_every: int, n_check: int, baselines: Sequence[MP], max_time: float = np.inf, H: int = 0,
+              opt0=None, worst0=None, start_pos=None, start_prob=None):
+    """(CmdpLoopDesc, keep-alive list) -- `baselines` = (optimal, worst, random) average rewards as MP."""
+    from .. import _lib as L
+
+    B = len(baselines[0].v)
+    val = np.ascontiguousarray(np.stack([m.values64() for m in baselines], 1), np.float64)
+    kind = np.ascontiguousarray(np.stack([m.kinds() for m in baselines], 1), np.int32)  # 0 Python float, 1 float32, 2 float64
+    d = L.CmdpLoopDesc()
+    d.n_steps, d.log_every, d.n_check, d.horizon = int(T), int(log_every if log_every and log_every > 0 else 0), int(n_check), int(H)
+    d.max_time = float(max_time) if np.isfinite(max_time) else 1e300
+    keep = [val, kind]
+    d.base_val, d.base_kind = L.ptr(val), L.ptr(kind)
+    if H:
+        o = np.ascontiguousarray(opt0, np.float32)
+        w = np.ascontiguousarray(worst0, np.float32)
+        sp = np.ascontiguousarray(start_pos, np.int64)
+        pp = np.ascontiguousarray(start_prob, np.float64)
+        d.kmax = int(sp.shape[1])
+        d.opt0, d.worst0, d.start_pos, d.start_prob = L.ptr(o), L.ptr(w), L.ptr(sp), L.ptr(pp)
+        keep += [o, w, sp, pp]
+    assert B == len(val)
+    return d, keep
+
+
+def n_log_rows(T: int, log_every: int) -> int:
+    return (len(range(log_every, T, log_every)) if log_every and log_every > 0 else 0) + 1
+
+
+def native_log(B: int, steps: np.ndarray, values: np.ndarray, kinds: np.ndarray) -> BatchLog:
+    """BatchLog over the arrays cmdp_qlearning_run_logged / cmdp_tracker_replay fill: values, kinds
+    [n_logs][CMDP_LOG_COLUMNS][B]."""
+    from .._lib import LOG_COLUMNS
+
+    log = BatchLog(B)
+    log.steps = [int(s) for s in steps]
+    log._final = {name: (np.ascontiguousarray(values[:, c, :]), np.ascontiguousarray(kinds[:, c, :]).astype(np.int8))
+                  for c, name in enumerate(LOG_COLUMNS)}
+    log._cols = {name: None for name in LOG_COLUMNS}  # names() reads the keys
+    return log

@@ -34,7 +34,6 @@ class GpuMDP:
         noise_kwargs = dict(kwargs.pop("noise_kwargs", {}) or {})
         em_name = em if isinstance(em, str) or em is None else em.__name__
         noise_name = noise if isinstance(noise, str) or noise is None else noise.__name__
-        assert not em_kwargs, "the built emission maps take no keyword arguments"
         self._model = make_model(cls_name, **kwargs)
         self._family_name, self._episodic = split_class_name(cls_name)
         m = self._model
@@ -48,16 +47,25 @@ class GpuMDP:
         self.r_min, self.r_max = self.rewards_range
         self.emission_map = None
         self.is_tabular = True
-        self._obs_table = observation_table(m, em_name)
+        # the observation table is built when the first observation is asked for, as in the reference
+        # (`all_observations` is lazy, emission_maps/base.py:56-83): the StateLinear maps draw their features from the
+        # global numpy stream at that moment, and the MiniGrid drawings show the state the MDP is in at that moment
+        self._em_name = None if em_name in (None, "Tabular") else em_name
+        self._em_kwargs = dict(em_kwargs)
+        self._obs_table_cache = None
         self._noise = None
-        if self._obs_table is not None:
+        self._noise_spec = None
+        if self._em_name is not None:
+            if self._em_name not in ("StateInfo", "OneHotEncoding", "TensorEncoding", "ImageEncoding", "StateLinearOptimal",
+                                     "StateLinearRandom"):
+                raise NotImplementedError(f"emission map {em_name!r} is not one of the reference's")
             self.emission_map = em_name
             self.is_tabular = False
             if noise_name is not None:
-                if noise_name != "GaussianUncorrelated":
-                    raise NotImplementedError(f"noise {noise_name!r} is not built (GaussianUncorrelated is)")
+                if noise_name not in CompatNoise.KINDS:
+                    raise NotImplementedError(f"noise {noise_name!r} is not one of the reference's")
                 noise_kwargs.pop("seed", None)
-                self._noise = CompatNoise(kwargs.get("seed"), self._obs_table.shape[-1:], **noise_kwargs)
+                self._noise_spec = (noise_name, noise_kwargs)
         self._seed = kwargs.get("seed")
         self.parameters = dict(kwargs)
         nodes = [tuple(int(x) for x in n) for n in m.nodes]
@@ -88,6 +96,26 @@ class GpuMDP:
             raise AttributeError("H is defined for episodic MDPs only")
         return self._model.H
 
+    @property
+    def _obs_table(self):
+        """`EmissionMap.all_observations`, built at the first observation (None for the tabular map)."""
+        if self._em_name is None:
+            return None
+        if self._obs_table_cache is None:
+            values = None
+            if self._em_name == "StateLinearOptimal":
+                values = self.optimal_value_functions[1]
+            elif self._em_name == "StateLinearRandom":
+                values = self.random_value_functions[1]
+            cur = None if self.cur_node is None else self.node_to_index[self.cur_node]
+            self._obs_table_cache = observation_table(self._model, self._em_name, cur_state=cur, h_now=self.h, values=values,
+                                                      **self._em_kwargs)
+            if self._noise_spec is not None:
+                kind, kw = self._noise_spec
+                shape = self._obs_table_cache.shape[2:] if self._episodic else self._obs_table_cache.shape[1:]
+                self._noise = CompatNoise(self._seed, shape, kind=kind, **kw)
+        return self._obs_table_cache
+
     def action_spec(self):
         return ts_.DiscreteArray(self.n_actions, name="action")
 
@@ -101,11 +129,12 @@ class GpuMDP:
 
     def _observation(self, state: int, h: int):
         """EmissionMap.get_observation (emission_maps/base.py:110-141)."""
+        table = self._obs_table
         if self._episodic and h >= self._model.H:
-            return np.zeros(self._obs_table.shape[-1:], np.float32)
+            return np.zeros(table.shape[2:], np.float32)
         # continuous setting: the reference indexes `all_observations[None, state]` (in_episode_time = None is numpy's
         # newaxis, emission_maps/base.py:135-137), so its observations carry a leading axis of length 1
-        obs = self._obs_table[h, state] if self._episodic else self._obs_table[None, state]
+        obs = table[h, state] if self._episodic else table[None, state]
         return obs + next(self._noise) if self._noise is not None else obs
 
     def reward_spec(self):
@@ -150,7 +179,7 @@ class GpuMDP:
     def _spec_value(self):
         # `np.zeros_like(self.observation_spec().generate_value())`: building the spec draws a noise sample
         self.observation_spec()
-        return np.zeros(self._obs_table.shape[-1:], np.float32)
+        return np.zeros(self._obs_table.shape[2:] if self._episodic else (1,) + self._obs_table.shape[1:], np.float32)
 
     def random_step(self, auto_reset=False):
         """mdp/base.py:1341-1355: the action comes from the MDP's own numpy stream (shared with the reward caches),

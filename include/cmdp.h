@@ -302,6 +302,47 @@ int cmdp_qlearning_continuous_create(cmdp_agent_t** out, cmdp_t* env, const int3
    was created (the additions continue across calls in transition order).  actions_trace [n_steps][B] may be NULL. */
 int cmdp_qlearning_run(cmdp_agent_t* a, int64_t n_steps, const uint8_t* train_mask, int8_t* actions_trace,
                        double* cumulative_reward);
+/* MDPLoop.run as ONE call (colosseum/experiment/agent_mdp_interaction.py:179-302 with its indicator code :304-578 and
+   colosseum/experiment/indicators.py:29-45): the interaction of cmdp_qlearning_run, and at every logging step the
+   evaluation of the agents' greedy policies on the device (episodic: V[0] by policy evaluation; continuous: average reward
+   of the policy's chain from the current state) followed by the reference's 18 performance indicators, computed on the
+   host in C++ with the reference's numpy scalar types (csrc/cmdp_tracker.h), the `_is_policy_optimal` freeze of training
+   and the wall-clock limit -- one stream synchronisation per logging step, no Python in between.
+
+   desc: n_steps = T, log_every (<= 0: only the final row), n_check = n_log_intervals_to_check_for_agent_optimality,
+   max_time (seconds of training for the batch; the reference gives every instance its own process and clock: here all
+   instances still training are frozen at the first logging step after max_time - 0.5 s); base_val / base_kind [B][3]: the
+   optimal, worst and random average reward of every instance as Python / numpy scalars (kind 0 = Python float, 1 =
+   np.float32, 2 = np.float64); episodic
+   handles also need horizon, opt0 / worst0 (V*[0] and V_worst[0], flat [state_off[B]]) and the start distribution as
+   start_pos / start_prob [B][kmax] (flat state positions in state-index order, probability 0 for padding).
+   Outputs for the n_logs = len(range(log_every, T, log_every)) + 1 rows: steps [n_logs]; values / kinds
+   [n_logs][CMDP_LOG_COLUMNS][B] -- the columns are the indicator names in sorted order without "steps" (kind 1 =
+   np.float32, 2 = np.float64; the values are rounded to 5 decimals in their type, as the logger receives them);
+   last_training_step [B] (-1: the time limit was not hit); is_training [B] after the run (these two may be NULL). */
+#define CMDP_LOG_COLUMNS 17
+typedef struct cmdp_loop_desc {
+  int64_t n_steps, log_every;
+  int32_t n_check, horizon, kmax, reserved;
+  double max_time;
+  const double* base_val;
+  const int32_t* base_kind;
+  const float* opt0;
+  const float* worst0;
+  const int64_t* start_pos;
+  const double* start_prob;
+} cmdp_loop_desc;
+int cmdp_qlearning_run_logged(cmdp_agent_t* a, const cmdp_loop_desc* desc, int64_t n_logs, int64_t* steps, double* values,
+                              uint8_t* kinds, int64_t* last_training_step, uint8_t* is_training);
+/* The indicator code of cmdp_qlearning_run_logged alone, on caller-supplied inputs (host only, no device): per row the
+   step, whether it lies inside the loop (the final row does not run the freeze check), the steps since the previous row,
+   cumulative rewards [n_logs][B], and -- episodic: V0 [n_logs][state_off[B]] of the policies and the logged episode's
+   start state [n_logs][B] (instance-relative); continuous: avg / avg_kind [n_logs][B] (kind != 0: np.float32).
+   is_training [n_logs][B] receives the flags after every row.  For tests against the reference's indicator code. */
+int cmdp_tracker_replay(const cmdp_loop_desc* desc, int32_t B, int32_t episodic, const int64_t* state_off, int64_t n_logs,
+                        const int64_t* log_steps, const uint8_t* in_loop, const int64_t* n_since, const double* cum_reward,
+                        const float* V0, const int64_t* start_state, const double* avg, const int32_t* avg_kind,
+                        double* values, uint8_t* kinds, uint8_t* is_training);
 /* V[0, :] of episodic_policy_evaluation for the agents' current greedy policies
    (BaseAgent.current_optimal_stochastic_policy = argmax_3d(Q), ties by RandomState(42)): what
    MDPLoop._compute_episodic_regret needs.  The environment handle must carry the DP half.  V0 [state_off[B]]. */
@@ -333,6 +374,14 @@ int cmdp_set_observation_table(cmdp_t* h, const float* table, int32_t F, int tim
    from the instance's Philox stream (throughput mode, CMDP_RNG_PHILOX only; the reference-exact GaussianUncorrelated
    stream is numpy's and stays on the host, colosseum_amd/emission_maps.py). */
 int cmdp_observe(cmdp_t* h, double noise_scale, float* obs);
+/* The same with any of the reference's four noise classes (the files of colosseum/noises/) in throughput mode: Gaussian
+   (scale), Gaussian correlated (y = L z, chol = the lower Cholesky factor L [F][F] of the covariance -- the reference
+   draws it from a Wishart distribution once per MDP), Student-t (df) and the multivariate Student-t (chol = factor of
+   the shape matrix, df).  Philox mode only; distribution-exact, not stream-exact (the reference-exact streams are
+   numpy's / scipy's and stay on the host, colosseum_amd/emission_maps.py: CompatNoise). */
+enum { CMDP_NOISE_NONE = 0, CMDP_NOISE_GAUSSIAN = 1, CMDP_NOISE_GAUSSIAN_CORRELATED = 2, CMDP_NOISE_STUDENT_T = 3,
+       CMDP_NOISE_STUDENT_T_CORRELATED = 4 };
+int cmdp_observe_noise(cmdp_t* h, int kind, double scale, double df, const float* chol, float* obs);
 
 /* ---- Markov chains ------------------------------------------------------------------------------------ */
 /* BUILD-DEFINED (the reference has no mixing time): t_mix[b] = smallest t >= 1 with

@@ -852,42 +852,78 @@ def g13():
 
 
 def g14():
-    """Emission maps + GaussianUncorrelated noise: all_observations tables and the observation
-    stream of reset()/step() with noise, incl. the samples observation_spec() consumes at episode ends."""
-    from colosseum.emission_maps import OneHotEncoding, StateInfo
-    from colosseum.noises import GaussianUncorrelated
+    """Emission maps and noises: `all_observations` of every non-tabular map on a family of each
+    drawing style, and observation streams of reset()/step() under each of the four noise classes, incl. the samples
+    observation_spec() consumes at episode ends.  The StateLinear maps draw from the global numpy stream: it is seeded
+    (recorded in the case) right before the MDP is stepped."""
+    from colosseum.emission_maps import (ImageEncoding, OneHotEncoding, StateInfo, StateLinearOptimal, StateLinearRandom,
+                                         TensorEncoding)
+    from colosseum.noises import GaussianCorrelated, GaussianUncorrelated, StudentTCorrelated, StudentTUncorrelated
 
     specs = [
-        ("DeepSeaEpisodic", dict(seed=2, size=5), StateInfo, 0.3),
-        ("FrozenLakeContinuous", dict(seed=1, size=4, p_frozen=0.9, p_rand=0.1), StateInfo, 0.1),
-        ("MiniGridEmptyEpisodic", dict(seed=3, size=4, n_starting_states=2), OneHotEncoding, 0.2),
-        ("RiverSwimContinuous", dict(seed=4, size=7, p_rand=0.2), OneHotEncoding, None),
+        ("DeepSeaEpisodic", dict(seed=2, size=5), StateInfo, GaussianUncorrelated, dict(scale=0.3)),
+        ("FrozenLakeContinuous", dict(seed=1, size=4, p_frozen=0.9, p_rand=0.1), StateInfo, GaussianUncorrelated, dict(scale=0.1)),
+        ("MiniGridEmptyEpisodic", dict(seed=3, size=4, n_starting_states=2), OneHotEncoding, GaussianUncorrelated, dict(scale=0.2)),
+        ("RiverSwimContinuous", dict(seed=4, size=7, p_rand=0.2), OneHotEncoding, None, {}),
+        # the other noise classes
+        ("DeepSeaContinuous", dict(seed=5, size=4, p_rand=0.1), StateInfo, StudentTUncorrelated, dict(df=4)),
+        ("FrozenLakeEpisodic", dict(seed=6, size=4, p_frozen=0.9), StateInfo, GaussianCorrelated, dict(scale=0.2)),
+        ("RiverSwimContinuous", dict(seed=7, size=5), OneHotEncoding, StudentTCorrelated, dict(scale=0.3)),
+        # the drawings
+        ("DeepSeaEpisodic", dict(seed=1, size=4), TensorEncoding, None, {}),
+        ("DeepSeaContinuous", dict(seed=1, size=4), ImageEncoding, GaussianUncorrelated, dict(scale=0.05)),
+        ("FrozenLakeContinuous", dict(seed=2, size=5, p_frozen=0.8), TensorEncoding, None, {}),
+        ("FrozenLakeEpisodic", dict(seed=2, size=4, p_frozen=0.9), ImageEncoding, None, {}),
+        ("MiniGridEmptyContinuous", dict(seed=0, size=4), ImageEncoding, None, {}),
+        ("MiniGridRoomsEpisodic", dict(seed=1, room_size=3, n_rooms=4), TensorEncoding, None, {}),
+        ("RiverSwimContinuous", dict(seed=0, size=6), ImageEncoding, None, {}),
+        ("SimpleGridContinuous", dict(seed=3, size=4), TensorEncoding, None, {}),
+        ("SimpleGridEpisodic", dict(seed=3, size=4, reward_type=1), ImageEncoding, None, {}),
+        ("TaxiContinuous", dict(seed=0, size=5, length=1), ImageEncoding, None, {}),
+        # features linear in a value function
+        ("DeepSeaEpisodic", dict(seed=0, size=5), StateLinearOptimal, None, {}),
+        ("FrozenLakeContinuous", dict(seed=0, size=5, p_frozen=0.9), StateLinearRandom, GaussianUncorrelated, dict(scale=0.1)),
     ]
     cases, arrays = [], {}
-    for cls, kw, em, scale in specs:
+    for cls, kw, em, noise, nkw in specs:
         extra = dict(emission_map=em)
-        if scale is not None:
-            extra.update(noise=GaussianUncorrelated, noise_kwargs=dict(scale=scale))
-        mdp = CLASSES[cls](**kw, **extra)
+        if noise is not None:
+            extra.update(noise=noise, noise_kwargs=dict(nkw))
+        ckw = dict(kw)
+        if "reward_type" in ckw:
+            from colosseum.mdp.simple_grid.base import SimpleGridReward
+
+            ckw["reward_type"] = SimpleGridReward(ckw["reward_type"])
         key = f"c{len(cases)}_"
-        arrays[key + "all_observations"] = np.asarray(mdp.emission_map.all_observations, np.float32)
-        acts = np.random.RandomState(40 + len(cases)).randint(0, mdp.n_actions, 400)
-        obs, stype, first = [], [], []
-        ts = mdp.reset()
-        first.append(np.asarray(ts.observation, np.float32))
-        for a in acts:
-            ts = mdp.step(int(a))
-            obs.append(np.asarray(ts.observation, np.float32))
-            stype.append(int(ts.step_type))
-            if mdp.is_episodic() and ts.last():
-                ts = mdp.reset()
-                first.append(np.asarray(ts.observation, np.float32))
-        arrays[key + "actions"] = acts.astype(np.int8)
-        arrays[key + "obs"] = np.stack(obs)
-        arrays[key + "stype"] = np.array(stype, np.uint8)
-        arrays[key + "reset_obs"] = np.stack(first)
-        cases.append(dict(cls=cls, kwargs=kw, emission_map=em.__name__, noise_scale=scale))
-        print("   ", cls, em.__name__, scale, arrays[key + "all_observations"].shape)
+        case = dict(cls=cls, kwargs=kw, emission_map=em.__name__, noise=None if noise is None else noise.__name__,
+                    noise_kwargs=nkw, noise_scale=nkw.get("scale") if noise is GaussianUncorrelated else None)
+        try:
+            mdp = CLASSES[cls](**ckw, **extra)
+            np_seed = 1000 + len(cases)
+            np.random.seed(np_seed)  # StateLinear features come from the global stream at the first observation
+            acts = np.random.RandomState(40 + len(cases)).randint(0, mdp.n_actions, 300)
+            obs, stype, first = [], [], []
+            ts = mdp.reset()
+            case["first_state"] = int(mdp.node_to_index[mdp.cur_node])  # the table is built now: the MiniGrid drawings show it
+            first.append(np.asarray(ts.observation, np.float32))
+            for a in acts:
+                ts = mdp.step(int(a))
+                obs.append(np.asarray(ts.observation, np.float32))
+                stype.append(int(ts.step_type))
+                if mdp.is_episodic() and ts.last():
+                    ts = mdp.reset()
+                    first.append(np.asarray(ts.observation, np.float32))
+            arrays[key + "all_observations"] = np.asarray(mdp.emission_map.all_observations, np.float32)
+            arrays[key + "actions"] = acts.astype(np.int8)
+            arrays[key + "obs"] = np.stack(obs)
+            arrays[key + "stype"] = np.array(stype, np.uint8)
+            arrays[key + "reset_obs"] = np.stack(first)
+            case["np_seed"] = np_seed
+            print("   ", cls, em.__name__, None if noise is None else noise.__name__, "table", arrays[key + "all_observations"].shape)
+        except Exception as e:  # what the reference does with this combination IS the known answer
+            case["raises"] = type(e).__name__
+            print("   ", cls, em.__name__, "raises", repr(e)[:120])
+        cases.append(case)
     arrays["cases"] = np.array(json.dumps(cases))
     save("G14_emission_maps", **arrays)
 

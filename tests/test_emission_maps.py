@@ -1,6 +1,7 @@
-"""Emission maps and observation noise (golden G14, generated from the reference): feature tables, the reference-exact
-observation stream through GpuMDP (noise = numpy's RandomState stream, incl. the samples `observation_spec()` draws at
-episode ends), and the device gather / Philox noise of BatchedMDP.observe."""
+"""Emission maps and observation noise (golden G14, generated from the reference): the observation tables of all seven
+non-tabular maps (incl. the family drawings behind TensorEncoding / ImageEncoding and the StateLinear features), the four
+noise classes, the reference-exact observation stream through GpuMDP (noise = numpy's RandomState stream, incl. the
+samples `observation_spec()` draws at episode ends), and the device gather / Philox noise of BatchedMDP.observe."""
 import numpy as np
 import pytest
 
@@ -9,15 +10,61 @@ from colosseum_amd.emission_maps import CompatNoise, observation_table
 from colosseum_amd.mdp import make_model
 
 
+def _values(m, which):
+    """V of the optimal / uniform policy from the CPU oracle (the GPU tests take it from the HIP kernels)."""
+    from oracle import oracle as O
+
+    S, A = m.n_states, m.n_actions
+    if m.H:
+        if which == "StateLinearOptimal":
+            return O.episodic(S, A, m.H, m.csr(), m.reward_matrix())[1]
+        pi = np.full((m.H, S, A), 1.0 / A, np.float32)
+        return O.episodic(S, A, m.H, m.csr(), m.reward_matrix(), pi=pi)[1]
+    if which == "StateLinearOptimal":
+        return O.vi_discounted(S, A, m.csr(), m.reward_matrix(), 0.99, 1e-3, 0)[1]
+    return O.pe_discounted(S, A, m.csr(), m.reward_matrix(), np.full((S, A), 1.0 / A, np.float32), 0.99, 1e-7, 0)[1]
+
+
 def test_observation_tables_match_reference():
     z, cases = load_golden("G14_emission_maps")
+    seen = set()
     for i, c in enumerate(cases):
+        assert "raises" not in c
         m = make_model(c["cls"], **c["kwargs"])
-        tab = observation_table(m, c["emission_map"])
-        np.testing.assert_array_equal(tab, z[f"c{i}_all_observations"], err_msg=str(c))
+        name = c["emission_map"]
+        seen.add(name)
+        want = z[f"c{i}_all_observations"]
+        if name.startswith("StateLinear"):
+            continue  # needs value functions: tests/test_gpu_mdploop-style GPU test below, and the CPU check after this loop
+        # the table is built at the first observation = the first reset(): the MDP sits in its start state, time 0
+        tab = observation_table(m, name, cur_state=c["first_state"], h_now=0)
+        np.testing.assert_array_equal(tab, want, err_msg=str(c))
+    assert seen == {"StateInfo", "OneHotEncoding", "TensorEncoding", "ImageEncoding", "StateLinearOptimal", "StateLinearRandom"}
     assert observation_table(m, "Tabular") is None
     with pytest.raises(NotImplementedError):
-        observation_table(m, "ImageEncoding")
+        observation_table(m, "NoSuchEncoding")
+    mg = make_model("MiniGridEmptyContinuous", seed=0, size=4)
+    with pytest.raises(AttributeError):  # the reference draws self.cur_node, which is None before the first reset()
+        observation_table(mg, "ImageEncoding")
+
+
+def test_state_linear_features_match_reference():
+    """Features drawn from the global numpy stream (seeded like the generator did), V from the CPU oracle: the value
+    function is float32 DP output on both sides, the projection is float64 linear algebra -> 1e-5 on unit-norm columns."""
+    z, cases = load_golden("G14_emission_maps")
+    n = 0
+    for i, c in enumerate(cases):
+        if not c["emission_map"].startswith("StateLinear"):
+            continue
+        m = make_model(c["cls"], **c["kwargs"])
+        V = _values(m, c["emission_map"])
+        np.random.seed(c["np_seed"])
+        tab = observation_table(m, c["emission_map"], values=V)
+        want = z[f"c{i}_all_observations"]
+        assert tab.shape == want.shape and tab.dtype == np.float32
+        np.testing.assert_allclose(tab, want, atol=2e-5, err_msg=str(c))
+        n += 1
+    assert n == 2
 
 
 def test_compat_noise_is_numpys_stream():
@@ -25,30 +72,55 @@ def test_compat_noise_is_numpys_stream():
     ref = np.random.RandomState(5).normal(0, 0.25, (5000, 3)).astype(np.float32)
     got = np.stack([next(n) for _ in range(40)])
     np.testing.assert_array_equal(got, ref[:40])
+    # StudentTUncorrelated: the cache is ONE array of the observation's shape, handed out slice by slice
+    t = CompatNoise(7, (4,), kind="StudentTUncorrelated", df=3)
+    ref = np.random.RandomState(7)
+    first = ref.standard_t(3, 4).astype(np.float32)
+    got = [next(t) for _ in range(6)]
+    assert all(np.ndim(g) == 0 for g in got) and [float(g) for g in got[:4]] == [float(x) for x in first]
+    second = ref.standard_t(3, 4).astype(np.float32)
+    assert [float(g) for g in got[4:]] == [float(x) for x in second[:2]]
+
+
+def _stream_cases():
+    z, cases = load_golden("G14_emission_maps")
+    return z, [(i, c) for i, c in enumerate(cases)]
 
 
 @pytest.mark.gpu
 def test_gpu_mdp_observation_stream_matches_reference(need_gpu):
     from colosseum_amd.mdp import gpu_mdp
 
-    z, cases = load_golden("G14_emission_maps")
-    for i, c in enumerate(cases):
+    z, cases = _stream_cases()
+    kinds = set()
+    for i, c in cases:
         k = f"c{i}_"
         extra = dict(emission_map=c["emission_map"])
-        if c["noise_scale"] is not None:
-            extra.update(noise="GaussianUncorrelated", noise_kwargs=dict(scale=c["noise_scale"]))
+        if c["noise"] is not None:
+            extra.update(noise=c["noise"], noise_kwargs=dict(c["noise_kwargs"]))
+            kinds.add(c["noise"])
         mdp = getattr(gpu_mdp, c["cls"])(**c["kwargs"], **extra)
+        np.random.seed(c["np_seed"])
+        linear = c["emission_map"].startswith("StateLinear")  # float32 DP behind a float64 projection: see the CPU test
+
+        def cmp(a, b, msg="", linear=linear):
+            if linear:
+                np.testing.assert_allclose(a, b, atol=2e-5, err_msg=msg)
+            else:
+                np.testing.assert_array_equal(a, b, err_msg=msg)
+
         ts = mdp.reset()
-        np.testing.assert_array_equal(ts.observation, z[k + "reset_obs"][0])
+        cmp(ts.observation, z[k + "reset_obs"][0])
         ri = 1
         for t, a in enumerate(z[k + "actions"]):
             ts = mdp.step(int(a))
-            np.testing.assert_array_equal(ts.observation, z[k + "obs"][t], err_msg=f"{c} step {t}")
+            cmp(ts.observation, z[k + "obs"][t], f"{c} step {t}")
             assert int(ts.step_type) == z[k + "stype"][t]
             if ts.last():
-                np.testing.assert_array_equal(mdp.reset().observation, z[k + "reset_obs"][ri])
+                cmp(mdp.reset().observation, z[k + "reset_obs"][ri])
                 ri += 1
         mdp.close()
+    assert kinds == set(CompatNoise.KINDS)
 
 
 @pytest.mark.gpu
@@ -83,4 +155,38 @@ def test_device_observe_gathers_rows_and_adds_philox_noise(need_gpu):
             np.testing.assert_allclose(noisy[b], want, rtol=1e-6, atol=1e-6)
     big = np.stack([env.observe(1.0) - clean for _ in range(300)])   # 300 x 3 x F samples of N(0, 1)
     assert abs(big.mean()) < 0.06 and abs(big.std() - 1.0) < 0.06
+    env.close()
+
+
+@pytest.mark.gpu
+def test_device_noise_kinds_have_the_right_distributions(need_gpu):
+    """Throughput-mode noise of the three other classes (distribution-exact, not stream-exact): second moments of 4 000
+    observations per instance against the closed forms."""
+    from colosseum_amd import _lib as L
+    from colosseum_amd.batched import BatchedMDP
+
+    ms = [make_model("DeepSeaContinuous", seed=s, size=4) for s in range(2)]
+    tabs = [observation_table(m, "OneHotEncoding") for m in ms]
+    F = tabs[0].shape[-1]
+    env = BatchedMDP(ms, rng_mode=L.RNG_PHILOX, philox_keys=np.array([3, 4], np.uint64), with_dp=False)
+    env.set_observation_table(tabs)
+    env.reset()
+    clean = env.observe()
+    rng = np.random.default_rng(0)
+    Aw = rng.normal(size=(F, F))
+    cov = Aw @ Aw.T / F + 0.5 * np.eye(F)
+    n = 4000
+    x = np.stack([env.observe_noise("GaussianCorrelated", covariance=cov) - clean for _ in range(n)]).reshape(-1, F)
+    emp = x.T @ x / len(x)
+    assert np.abs(emp - cov).max() < 0.12 * np.abs(cov).max()
+    df = 6.0
+    x = np.stack([env.observe_noise("StudentTUncorrelated", df=df) - clean for _ in range(n)]).reshape(-1, F)
+    assert abs(x.var() - df / (df - 2)) < 0.12 and abs(x.mean()) < 0.03
+    # heavier tails than a Gaussian of the same variance: excess kurtosis 6 / (df - 4) = 3
+    assert ((x / x.std()) ** 4).mean() > 4.0
+    x = np.stack([env.observe_noise("StudentTCorrelated", df=df, covariance=cov) - clean for _ in range(n)]).reshape(-1, F)
+    emp = x.T @ x / len(x)
+    assert np.abs(emp - cov * df / (df - 2)).max() < 0.2 * np.abs(cov).max() * df / (df - 2)
+    with pytest.raises(L.CmdpError):
+        env.observe_noise("GaussianCorrelated")  # no covariance
     env.close()

@@ -99,6 +99,18 @@ def test_device_qlearning_batch_vs_numpy_agent(need_gpu):
             env.close()
 
 
+def _assert_same_rows(a, b):
+    """Two runs of a batched loop: every logged value identical in value AND numpy type (steps_per_second is wall clock)."""
+    assert len(a) == len(b)
+    for ta, tb in zip(a, b):
+        assert len(ta) == len(tb)
+        for ra, rb in zip(ta, tb):
+            assert set(ra) == set(rb)
+            for k in ra:
+                if k != "steps_per_second":
+                    assert ra[k] == rb[k] and type(ra[k]) is type(rb[k]), (k, ra["steps"], ra[k], rb[k])
+
+
 def test_batched_episodic_loop_matches_reference_logger_rows(need_gpu):
     """The whole MDPLoop.run on the device for a batch: golden G7 rows (17 deterministic indicators per logging step)
     for each reference run, here executed with the instance replicated three times in one batch."""
@@ -123,6 +135,15 @@ def test_batched_episodic_loop_matches_reference_logger_rows(need_gpu):
                     assert float(got[k]) == pytest.approx(v, rel=2e-6, abs=2e-5), (c["mdp_kwargs"], k, got["steps"])
         Q, N = ag.tables()
         np.testing.assert_array_equal(Q[2].astype(np.float64), np.asarray(c["Q_final"]))
+        ag.close()
+        env.close()
+        # the default above is ONE library call for the whole run; with Python in the loop the rows must be identical
+        env = BatchedMDP([m, m, m], rng_mode=L.RNG_MT_COMPAT)
+        ag = BatchedQLearningEpisodic(env, [seed, seed, seed], **kw)
+        loop2 = BatchedEpisodicLoop(env, ag)
+        loop2.native = False
+        _assert_same_rows(rows, loop2.run(T=c["T"], log_every=c["log_every"]))
+        np.testing.assert_array_equal(loop2.vt.is_training, loop.vt.is_training)
         ag.close()
         env.close()
 
@@ -169,5 +190,13 @@ def test_device_continuous_qlearning_and_batched_loop(need_gpu):
             for got, ref in zip(inst, ref_rows):
                 for k, v in ref.items():
                     assert float(got[k]) == pytest.approx(v, rel=2e-6, abs=2e-5), (c["mdp_kwargs"], k, got["steps"])
+        ag.close()
+        env.close()
+        # (iii) the same run with Python in the loop (one call per step of the schedule): identical rows, value and type
+        env = BatchedMDP([m, m], rng_mode=L.RNG_MT_COMPAT)
+        ag = BatchedQLearningContinuous(env, [seed, seed], **kw)
+        loop = BatchedContinuousLoop(env, ag)
+        loop.native = False
+        _assert_same_rows(rows, loop.run(T=c["T"], log_every=c["log_every"]))
         ag.close()
         env.close()

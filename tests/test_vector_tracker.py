@@ -145,3 +145,87 @@ def test_csv_text_matches_dictwriter():
         for r in rows:
             w.writerow(r)
         assert vt.log.csv_text(b) == buf.getvalue()
+
+
+# ---- the C++ tracker of the library (csrc/cmdp_tracker.h, what cmdp_qlearning_run_logged runs between kernels) ---------
+def _native_rows(B, log, i_rows):
+    return [[log.value(name, i, b) for name in log.names()] for b in range(B) for i in i_rows]
+
+
+def _check_native(z, members, log, flags):
+    from colosseum_amd._lib import LOG_COLUMNS
+
+    for b, (key, c) in enumerate(members):
+        want, kinds = z[key + "rows"], z[key + "kinds"]
+        for i in range(len(want)):
+            for j, name in enumerate(c["keys"]):
+                if name == "steps":
+                    assert log.steps[i] == int(want[i, j])
+                    continue
+                got = log.value(name, i, b)
+                assert float(got) == want[i, j] or (np.isnan(got) and np.isnan(want[i, j])), (key, i, name, got, want[i, j])
+                assert (1 if isinstance(got, np.float32) else 2) == kinds[i, j], (key, i, name, type(got), kinds[i, j])
+        np.testing.assert_array_equal(flags[:, b].astype(bool), z[key + "is_training"], err_msg=key)
+    assert set(LOG_COLUMNS) | {"steps"} == set(members[0][1]["keys"]) | {"steps_per_second"}
+
+
+def test_native_tracker_equals_reference_indicator_code():
+    """cmdp_tracker_replay (host-only entry point of libcmdp.so) on the inputs of golden G15: the rows, numpy types and
+    training flags the reference's own indicator code produced."""
+    import ctypes as C
+
+    from colosseum_amd import _lib as L
+    from colosseum_amd.experiment.vector_tracker import loop_desc, native_log
+
+    lib = L.load()
+    n_frozen = 0
+    z, by = _groups("episodic")
+    for g, members in by.items():
+        c0 = members[0][1]
+        B = len(members)
+        sizes = [len(z[k + "opt0"]) for k, _ in members]
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        flat = [np.concatenate([z[k + n] for k, _ in members]) for n in ("opt0", "worst0", "rand0")]
+        starts = [(z[k + "start_states"], z[k + "start_probs"]) for k, _ in members]
+        vt = EpisodicVectorTracker(c0["H"], off, *flat, starts, c0["n_check"])  # prepares baselines and start tables
+        d, keep = loop_desc(c0["T"], 100, c0["n_check"], (vt.opt, vt.worst, vt.rand), H=c0["H"], opt0=flat[0], worst0=flat[1],
+                            start_pos=vt._ss, start_prob=vt._sp)
+        ts = z[members[0][0] + "t"].astype(np.int64)
+        n = len(ts)
+        V0 = np.ascontiguousarray(np.stack([np.concatenate([z[k + "V0"][i] for k, _ in members]) for i in range(n)]), np.float32)
+        start = np.ascontiguousarray(np.stack([[z[k + "last_start"][i] for k, _ in members] for i in range(n)]), np.int64)
+        cum = np.ascontiguousarray(np.stack([[z[k + "cum"][i] for k, _ in members] for i in range(n)]), np.float64)
+        in_loop = np.ascontiguousarray(z[members[0][0] + "in_loop"], np.uint8)
+        n_since = np.ascontiguousarray(z[members[0][0] + "n_since"], np.int64)
+        values = np.zeros((n, len(L.LOG_COLUMNS), B))
+        kinds = np.zeros((n, len(L.LOG_COLUMNS), B), np.uint8)
+        flags = np.zeros((n, B), np.uint8)
+        L.check(lib.cmdp_tracker_replay(C.byref(d), B, 1, L.ptr(off), n, L.ptr(ts), L.ptr(in_loop), L.ptr(n_since), L.ptr(cum),
+                                        L.ptr(V0), L.ptr(start), None, None, L.ptr(values), L.ptr(kinds), L.ptr(flags)))
+        _check_native(z, members, native_log(B, ts, values, kinds), flags)
+        n_frozen += int((flags[-1] == 0).sum())
+    z, by = _groups("continuous")
+    for g, members in by.items():
+        c0 = members[0][1]
+        B = len(members)
+
+        def mp(j):
+            return MP.from_scalars([np.float32(z[k + "baselines"][j]) if z[k + "baseline_kinds"][j] == 1
+                                    else np.float64(z[k + "baselines"][j]) for k, _ in members])
+
+        d, keep = loop_desc(c0["T"], 100, c0["n_check"], (mp(0), mp(1), mp(2)))
+        ts = z[members[0][0] + "t"].astype(np.int64)
+        n = len(ts)
+        avg = np.ascontiguousarray(np.stack([[z[k + "avg"][i] for k, _ in members] for i in range(n)]), np.float64)
+        akind = np.ascontiguousarray(np.stack([[1 if z[k + "avg_kinds"][i] == 1 else 0 for k, _ in members] for i in range(n)]), np.int32)
+        cum = np.ascontiguousarray(np.stack([[z[k + "cum"][i] for k, _ in members] for i in range(n)]), np.float64)
+        in_loop = np.ascontiguousarray(z[members[0][0] + "in_loop"], np.uint8)
+        n_since = np.ascontiguousarray(z[members[0][0] + "n_since"], np.int64)
+        values = np.zeros((n, len(L.LOG_COLUMNS), B))
+        kinds = np.zeros((n, len(L.LOG_COLUMNS), B), np.uint8)
+        flags = np.zeros((n, B), np.uint8)
+        L.check(lib.cmdp_tracker_replay(C.byref(d), B, 0, None, n, L.ptr(ts), L.ptr(in_loop), L.ptr(n_since), L.ptr(cum),
+                                        None, None, L.ptr(avg), L.ptr(akind), L.ptr(values), L.ptr(kinds), L.ptr(flags)))
+        _check_native(z, members, native_log(B, ts, values, kinds), flags)
+        n_frozen += int((flags[-1] == 0).sum())
+    assert n_frozen >= 8
