@@ -34,7 +34,7 @@ EXPORTS = [
     "cmdp_visits", "cmdp_reset_visits", "cmdp_state", "cmdp_last_start", "cmdp_vi_discounted", "cmdp_pe_discounted",
     "cmdp_vi_episodic", "cmdp_pe_episodic", "cmdp_diameter", "cmdp_diameter_episodic", "cmdp_value_norm", "cmdp_gth", "cmdp_qlearning_create", "cmdp_qlearning_destroy", "cmdp_qlearning_run",
     "cmdp_qlearning_tables", "cmdp_qlearning_evaluate", "cmdp_greedy_policy_episodic", "cmdp_qlearning_continuous_create",
-    "cmdp_qlearning_policy", "cmdp_qlearning_average_reward", "cmdp_qlearning_run_logged", "cmdp_tracker_replay", "cmdp_average_reward", "cmdp_diameter_range", "cmdp_mixing_time", "cmdp_set_observation_table", "cmdp_observe", "cmdp_observe_noise",
+    "cmdp_qlearning_policy", "cmdp_qlearning_average_reward", "cmdp_qlearning_run_logged", "cmdp_tracker_replay", "cmdp_average_reward", "cmdp_diameter_range", "cmdp_diameter_sparse_f64", "cmdp_mixing_time", "cmdp_set_observation_table", "cmdp_observe", "cmdp_observe_noise",
 ]
 
 
@@ -170,6 +170,7 @@ def load():
         L.cmdp_qlearning_average_reward.argtypes = [vp, vp, vp, vp]
         L.cmdp_average_reward.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.cmdp_diameter_range.argtypes = [vp, C.c_double, i64, i64, i64, vp]
+        L.cmdp_diameter_sparse_f64.argtypes = [vp, C.c_double, i64, vp, vp]
         L.cmdp_mixing_time.argtypes = [vp, vp, vp, C.c_double, i64, vp, vp]
         L.cmdp_set_observation_table.argtypes = [vp, vp, i32, i32]
         L.cmdp_observe.argtypes = [vp, C.c_double, vp]

@@ -372,6 +372,14 @@ class BatchedMDP:
         L.check(self._lib.cmdp_mixing_time(self._h, L.ptr(pi), L.ptr(st), float(threshold), int(max_steps), L.ptr(t), L.ptr(tv)))
         return t, tv
 
+    def diameter_sparse_f64(self, epsilon=1e-3, max_sweeps=1_000_000):
+        """`_get_sparse_diameter` (the single-core reference's path above 1000 states): float64, sequential targets with
+        the running-maximum early exit.  Returns (diameter float64 [B], running maximum after every target, flat)."""
+        run = np.zeros(int(self.state_off[-1]), np.float64)
+        diam = np.zeros(self.B, np.float64)
+        L.check(self._lib.cmdp_diameter_sparse_f64(self._h, float(epsilon), int(max_sweeps), L.ptr(run), L.ptr(diam)))
+        return diam, run
+
     def diameter_range(self, target_lo: int, target_hi: int, epsilon=1e-3, max_sweeps=1_000_000) -> np.ndarray:
         """Optimal expected hitting times (max over start states) of the targets [target_lo, target_hi) of the flat
         state space, Jacobi scheme, 64 targets per workgroup (kernel K5S): the shard of `diameter()` one GPU takes

@@ -164,7 +164,11 @@ def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, r
         # continuous baselines use discounted VI under the reference's own scheme rule, which depends on the instance's
         # size and density: one scheme per device batch
         scheme = 0 if m.is_episodic else _vi_rule(m.n_states, m.n_actions, len(m.csr()[1]))
-        groups.setdefault((instances[i].mdp_cls, m.H, m.n_actions, tuple(m.rewards_range), scheme), []).append(i)
+        # deterministic-reward instances run the reference's own random streams (MT_COMPAT: rows equal to the reference's
+        # for that seed), Beta-reward instances sample their rewards on the device from Philox streams: never in one
+        # batch, so that what an instance produces does not depend on which other instances the benchmark holds
+        groups.setdefault((instances[i].mdp_cls, m.H, m.n_actions, tuple(m.rewards_range), scheme, m.deterministic_rewards),
+                          []).append(i)
     results: Dict[int, list] = {}
 
     def work(idx):

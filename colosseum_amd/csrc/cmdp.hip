@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdarg>
+#include <limits>
 #include <cstdio>
 #include <cmath>
 #include <cstring>
@@ -1491,6 +1492,94 @@ int cmdp_diameter(cmdp_t* h, double epsilon, int scheme, int64_t max_sweeps, flo
     diameter[b] = dmax;
   }
   if (per_target) std::memcpy(per_target, per.data(), sizeof(float) * NS);
+  return CMDP_OK;
+}
+
+int cmdp_diameter_sparse_f64(cmdp_t* h, double epsilon, int64_t max_sweeps, double* running_max, double* diameter) {
+  if (int rc = bind(h)) return rc;
+  if (!h->has_dp) return fail(CMDP_ERR_INVALID, "handle was created without the DP half");
+  if (!diameter) return fail(CMDP_ERR_INVALID, "null output");
+  if (max_sweeps < 1) return fail(CMDP_ERR_INVALID, "max_sweeps < 1");
+  if (h->H != 0) return fail(CMDP_ERR_INVALID, "the sparse float64 diameter is the continuous setting's (horizon 0)");
+  hipStream_t st = h->stream;
+  const int64_t NS = h->n_states;
+  if (h->d_status.n < (size_t)NS) HIP_TRY(h->d_status.alloc(NS));
+  DpTables t{};
+  t.B = h->B; t.A = h->A; t.state_off = h->d_state_off.p; t.csr_ptr = h->d_csr_ptr.p; t.csr_col = h->d_csr_col.p;
+  t.csr_val = h->d_csr_val.p; t.eps = epsilon; t.max_sweeps = max_sweeps; t.status = h->d_status.p;
+  constexpr int kLogCap = 2048;  // sweeps between diff < 0.05 and diff < eps that can be logged per target
+  std::vector<int32_t> inst, t0, cnt;
+  std::vector<int64_t> vdoubles;
+  for (int b = 0; b < h->B; ++b) {
+    const int64_t S = h->state_off[b + 1] - h->state_off[b];
+    for (int64_t x = 0; x < S; x += 64) {
+      inst.push_back(b);
+      t0.push_back((int32_t)x);
+      cnt.push_back((int32_t)std::min<int64_t>(64, S - x));
+      vdoubles.push_back(2 * S * 64);
+    }
+  }
+  const size_t G = inst.size();
+  size_t ws_cap = h->dl_ws_bytes;
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ws_cap = std::min(ws_cap, free_b / 5 * 3);
+  }
+  std::vector<double> log_host;
+  std::vector<int32_t> logn_host;
+  std::vector<double> run((size_t)NS, 0.0);
+  std::vector<double> D((size_t)h->B, -std::numeric_limits<double>::infinity());
+  DevBuf<double> d_v, d_log;
+  DevBuf<int32_t> d_logn, d_inst, d_t0, d_cnt;
+  DevBuf<int64_t> d_voff;
+  size_t g0 = 0;
+  while (g0 < G) {
+    size_t g1 = g0, doubles = 0;
+    std::vector<int64_t> voff;
+    while (g1 < G && (g1 == g0 || (doubles + (size_t)vdoubles[g1]) * sizeof(double) + (g1 - g0 + 1) * 64 * kLogCap * 16 <= ws_cap)) {
+      voff.push_back((int64_t)doubles);
+      doubles += (size_t)vdoubles[g1];
+      ++g1;
+    }
+    const size_t n = g1 - g0;
+    if (d_v.n < doubles) HIP_TRY(d_v.alloc(doubles));
+    if (d_log.n < n * 64 * kLogCap * 2) HIP_TRY(d_log.alloc(n * 64 * kLogCap * 2));
+    if (d_logn.n < n * 64) HIP_TRY(d_logn.alloc(n * 64));
+    HIP_TRY(d_inst.upload(inst.data() + g0, n, st));
+    HIP_TRY(d_t0.upload(t0.data() + g0, n, st));
+    HIP_TRY(d_cnt.upload(cnt.data() + g0, n, st));
+    HIP_TRY(d_voff.upload(voff.data(), n, st));
+    DiamF64Args g{d_inst.p, d_t0.p, d_cnt.p, d_voff.p, d_v.p, d_log.p, d_logn.p, kLogCap};
+    hipLaunchKernelGGL(k_diam_lanes_f64<8>, dim3((unsigned)n), dim3(512), 0, st, t, g);
+    HIP_TRY(hipGetLastError());
+    log_host.resize(n * 64 * kLogCap * 2);
+    logn_host.resize(n * 64);
+    HIP_TRY(hipMemcpyAsync(logn_host.data(), d_logn.p, sizeof(int32_t) * n * 64, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(log_host.data(), d_log.p, sizeof(double) * log_host.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // the reference's loop over the targets, in its order: the first logged sweep at which it would have stopped
+    for (size_t gi = 0; gi < n; ++gi) {
+      const int b = inst[g0 + gi];
+      for (int l = 0; l < cnt[g0 + gi]; ++l) {
+        const int32_t nl = logn_host[gi * 64 + l];
+        if (nl < 0) return fail(CMDP_ERR_MAX_ITER, "target %d of instance %d did not converge within max_sweeps", t0[g0 + gi] + l, b);
+        if (nl > kLogCap)
+          return fail(CMDP_ERR_UNSUPPORTED, "target %d of instance %d needs more than %d sweeps between diff < 0.05 and diff < eps",
+                      t0[g0 + gi] + l, b, kLogCap);
+        const double* lg = log_host.data() + (gi * 64 + l) * (size_t)kLogCap * 2;
+        double mx = lg[2 * (nl - 1) + 1];
+        for (int32_t j = 0; j < nl; ++j) {
+          const double diff = lg[2 * j], m = lg[2 * j + 1];
+          if (diff < epsilon || (diff < 0.05 && m - 1 < D[(size_t)b])) { mx = m; break; }
+        }
+        D[(size_t)b] = std::max(D[(size_t)b], mx);
+        run[(size_t)(h->state_off[b] + t0[g0 + gi] + l)] = D[(size_t)b];
+      }
+    }
+    g0 = g1;
+  }
+  for (int b = 0; b < h->B; ++b) diameter[b] = D[(size_t)b];
+  if (running_max) std::memcpy(running_max, run.data(), sizeof(double) * (size_t)NS);
   return CMDP_OK;
 }
 

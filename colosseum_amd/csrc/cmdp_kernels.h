@@ -2344,3 +2344,99 @@ __global__ void __launch_bounds__(NW * 64) k_diam_tiles(DpTables t, DiamLanesArg
     t.status[soff + target] = status;
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// K5D k_diam_lanes_f64: the reference's SPARSE float64 diameter (`_get_sparse_diameter`,
+// colosseum/hardness/measures/diameter.py:382-420 -- what a single-core reference runs for continuous MDPs above 1000
+// states).  Per target i: float64 expected hitting times over the other states, Jacobi sweeps
+//     ET'[s] = min_a ( T[s,a,i] + sum_{j != i, ascending} float64(T[s,a,j]) * (1 + ET[j]) ),
+// diff = max_{s != i} |ET' - ET|.  The reference stops a target at diff < eps OR (diff < 0.05 and max ET' - 1 < the
+// running maximum over the targets before it): the second clause makes the result depend on the target ORDER.  The
+// sweeps themselves do not depend on it, so the kernel runs every target to diff < eps (lane = target, 64 targets per
+// workgroup, value vectors interleaved in HBM as in K5S) and LOGS (diff, max ET') of every sweep from the first one with
+// diff < max(eps, 0.05) on; the host then walks the targets in the reference's order and takes, for each, the sweep at
+// which the reference would have stopped (cmdp_diameter_sparse_f64).
+// ---------------------------------------------------------------------------------------------------------------
+struct DiamF64Args {
+  const int32_t* grp_inst;
+  const int32_t* grp_target0;
+  const int32_t* grp_count;
+  const int64_t* grp_voff;     // offset of the group's two value arrays in `vbuf` (doubles)
+  double* vbuf;
+  double* log;                 // [groups][64][log_cap][2]: (diff, max) per logged sweep
+  int32_t* log_n;              // [groups][64] logged sweeps (log_cap + 1: the log overflowed)
+  int32_t log_cap;
+};
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) k_diam_lanes_f64(DpTables t, DiamF64Args g) {
+  __shared__ double red_d[2][NW][64];
+  __shared__ double red_m[2][NW][64];
+  const int grp = blockIdx.x;
+  const int b = g.grp_inst[grp];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int A = t.A;
+  const int64_t soff = t.state_off[b];
+  const int S = (int)(t.state_off[b + 1] - soff);
+  const int64_t* ptr = t.csr_ptr + soff * A;
+  const int target = g.grp_target0[grp] + lane;
+  const bool active = lane < g.grp_count[grp];
+  double* Eold = g.vbuf + g.grp_voff[grp];
+  double* Enew = Eold + (int64_t)S * 64;
+  for (int64_t i = threadIdx.x; i < (int64_t)S * 128; i += NW * 64) Eold[i] = 0.0;
+  __syncthreads();
+  double* mylog = g.log + ((int64_t)grp * 64 + lane) * g.log_cap * 2;
+  const double log_thr = t.eps > 0.05 ? t.eps : 0.05;
+  bool done = !active;
+  int n_logged = 0;
+  int64_t it = 0;
+  while (it < t.max_sweeps) {
+    ++it;
+    double dmax = 0.0, emax = -1.0e300;
+    for (int s = wave; s < S; s += NW) {
+      double v = 0.0;
+      for (int a = 0; a < A; ++a) {
+        const int64_t lo = ptr[(int64_t)s * A + a], hi = ptr[(int64_t)s * A + a + 1];
+        double acc = 0.0, te = 0.0;
+        for (int64_t k = lo; k < hi; ++k) {
+          const int c = t.csr_col[k];
+          const double p = (double)t.csr_val[k];
+          const double term = __dmul_rn(p, __dadd_rn(1.0, Eold[(int64_t)c * 64 + lane]));
+          if (c == target) te = p;                  // the hit: its column is not part of the sum
+          else acc = __dadd_rn(acc, term);
+        }
+        const double q = __dadd_rn(te, acc);
+        v = (a == 0) ? q : fmin(v, q);
+      }
+      Enew[(int64_t)s * 64 + lane] = v;
+      if (s != target) {
+        dmax = fmax(dmax, fabs(Eold[(int64_t)s * 64 + lane] - v));
+        emax = fmax(emax, v);
+      }
+    }
+    const int par = (int)(it & 1);
+    red_d[par][wave][lane] = dmax;
+    red_m[par][wave][lane] = emax;
+    __syncthreads();
+    double diff = 0.0, mx = -1.0e300;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      diff = fmax(diff, red_d[par][w][lane]);
+      mx = fmax(mx, red_m[par][w][lane]);
+    }
+    double* tmp = Eold; Eold = Enew; Enew = tmp;
+    if (!done && diff < log_thr) {
+      if (wave == 0) {
+        if (n_logged < g.log_cap) { mylog[2 * n_logged] = diff; mylog[2 * n_logged + 1] = mx; }
+      }
+      ++n_logged;
+      if (diff < t.eps || n_logged > g.log_cap) done = true;
+    }
+    if (__all(done)) break;
+  }
+  if (wave == 0 && active) {
+    g.log_n[(int64_t)grp * 64 + lane] = done ? n_logged : -1;   // -1: max_sweeps reached
+    t.status[soff + target] = done ? 0 : -5;
+  }
+}

@@ -20,9 +20,29 @@ def _vi_rule(S, A, nnz):
     return L.SCHEME_JACOBI if (size > 300 * 3 * 300 and nnz / size < 0.2) else L.SCHEME_GAUSS_SEIDEL
 
 
-def diameter(models: Sequence[TabularModel], epsilon: float = 1e-3) -> np.ndarray:
-    """`get_diameter` per model.  Models are grouped by (episodic?, H, A, scheme) into batches."""
+def diameter(models: Sequence[TabularModel], epsilon: float = 1e-3, variant: str = "per_target") -> np.ndarray:
+    """`get_diameter` per model.  Models are grouped by (episodic?, H, A, scheme) into batches.
+
+    variant "per_target" (default): every target solved to the stopping rule, the maximum taken -- what the reference
+    computes on a machine with >= 3 cores (diameter.py:35-36,108-124) and, below 1000 states, on any machine.
+    variant "reference_single_core": the reference's dispatch with one core (its default, config.py:19): continuous MDPs
+    above 1000 states take `_get_sparse_diameter` (float64, order-dependent early exit; `BatchedMDP.diameter_sparse_f64`),
+    everything else as above."""
+    assert variant in ("per_target", "reference_single_core")
     out = np.zeros(len(models), np.float64)
+    if variant == "reference_single_core":
+        big = [i for i, m in enumerate(models) if not m.is_episodic and m.n_states > 1000]
+        small = [i for i in range(len(models)) if i not in set(big)]
+        if small:
+            out[small] = diameter([models[i] for i in small], epsilon)
+        by_A = {}
+        for i in big:
+            by_A.setdefault(models[i].n_actions, []).append(i)
+        for A, idx in by_A.items():
+            dp = BatchedMDP([models[i] for i in idx], with_env=False)
+            out[idx] = dp.diameter_sparse_f64(epsilon)[0]
+            dp.close()
+        return out
     groups = {}
     for i, m in enumerate(models):
         key = (m.H, m.n_actions, 0 if m.is_episodic else _vi_rule(m.n_states, m.n_actions, len(m.csr()[1])))

@@ -261,6 +261,13 @@ int cmdp_pe_episodic(cmdp_t* h, int H, const float* pi, const float* R_override,
    NULL.  scheme as in cmdp_vi_discounted (AUTO = the rule applied to the instance's T). */
 int cmdp_diameter(cmdp_t* h, double epsilon, int scheme, int64_t max_sweeps,
                   float* per_target, float* diameter);
+/* `_get_sparse_diameter` (colosseum/hardness/measures/diameter.py:382-420): the variant a single-core reference runs
+   for continuous MDPs above 1000 states (dispatch :35-39) -- float64 hitting times, targets in index order, and the
+   running-maximum early exit `diff < 0.05 and max - 1 < diameter so far`, which makes the value depend on that order.
+   The device solves every target to diff < epsilon and logs (diff, max) per sweep; the host replays the reference's
+   sequential loop on the logs, so the committed values are the reference's.  diameter [B] float64; running_max
+   [state_off[B]] (may be NULL) = the running maximum after each target.  Continuous handles only. */
+int cmdp_diameter_sparse_f64(cmdp_t* h, double epsilon, int64_t max_sweeps, double* running_max, double* diameter);
 /* The per-target hitting-time solves of cmdp_diameter for the targets [target_lo, target_hi) of the flat state
    space [0, state_off[B]) only (Jacobi scheme, kernel K5S; any instance size): per_target[i] belongs to target
    target_lo + i.  This is how config C5 (one MDP with ~50 000 states) is split over GPUs: every rank takes a

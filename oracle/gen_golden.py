@@ -22,6 +22,7 @@ Fixture groups:
   G6  episodic/continuous diameter + value-norm recomputed by the reference here (small cases)
   G7  MDPLoop + QLearningEpisodic logger rows and action stream (config C1, plumbing)
   G14 emission maps (StateInfo, OneHotEncoding) and GaussianUncorrelated noise
+  G16 the reference's sparse float64 diameter (single-core path above 1000 states) on small MDPs
   G15 the reference's MDPLoop indicator code on synthetic inputs (value / type of every logged scalar, training freeze)
   G13 CustomMDP (user-given T_0, T, R)
   G12 RiverSwim / SimpleGrid / Taxi: structure, DP values, trajectories
@@ -1127,7 +1128,48 @@ def g15():
     save("G15_indicators", **arrays)
 
 
-GROUPS = dict(G15=g15, G14=g14, G13=g13, G12=g12, G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11)
+def g16():
+    """The reference's sparse float64 diameter (`_get_sparse_diameter`, hardness/measures/diameter.py:382-420: what a
+    default single-core reference runs for continuous MDPs above 1000 states -- sequential targets, float64 hitting
+    times, the running-maximum early exit), called directly on the dense T of small MDPs: the diameter it returns and,
+    per target, the running maximum after that target (so that the order-dependent exit is pinned too)."""
+    from colosseum.hardness.measures import diameter as ref_d
+
+    specs = [
+        ("FrozenLakeContinuous", dict(seed=0, size=6, p_frozen=0.9, p_rand=0.1)),
+        ("MiniGridEmptyContinuous", dict(seed=1, size=5, p_rand=0.05, p_lazy=0.1)),
+        ("DeepSeaContinuous", dict(seed=2, size=9, p_rand=0.2)),
+        ("MiniGridRoomsContinuous", dict(seed=0, room_size=3, n_rooms=4, p_lazy=0.1)),
+        ("RiverSwimContinuous", dict(seed=0, size=15, p_rand=0.1)),
+    ]
+    rows = []
+    for cls, kw in specs:
+        mdp = CLASSES[cls](**kw)
+        T = np.asarray(mdp.T)
+        t0 = time.time()
+        running = []
+        real_max = max
+
+        # the function keeps its running maximum in a local; record it through the builtin it calls once per target
+        def spy_max(*a, **k):
+            r = real_max(*a, **k)
+            if len(a) == 2 and not k and isinstance(a[0], (float, np.floating)):
+                running.append(float(r))
+            return r
+
+        ref_d.max = spy_max
+        try:
+            d = ref_d._get_sparse_diameter(T)
+        finally:
+            del ref_d.max
+        rows.append(dict(cls=cls, kwargs=kw, n_states=mdp.n_states, diameter=float(d), running_max=running))
+        assert len(running) == mdp.n_states and running[-1] == float(d)
+        print("   ", cls, kw, "S", mdp.n_states, "sparse float64 diameter", float(d), f"{time.time() - t0:.1f}s")
+    with open(os.path.join(OUT, "G16_sparse_diameter.json"), "w") as f:
+        json.dump(rows, f, indent=0)
+
+
+GROUPS = dict(G16=g16, G15=g15, G14=g14, G13=g13, G12=g12, G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

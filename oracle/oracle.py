@@ -297,3 +297,46 @@ def gth(tps):
     x = np.zeros(n, np.float64)
     lib().oracle_gth(n, a, x)
     return x
+
+
+def sparse_diameter_f64(S, A, csr, eps=1e-3, return_log=False):
+    """Restatement of the reference's `_get_sparse_diameter` (colosseum/hardness/measures/diameter.py:382-420), the path a
+    single-core reference takes for continuous MDPs above 1000 states: targets in index order, float64 expected hitting
+    times ET over the states other than the target, Jacobi sweeps
+        ET'[s] = min_a ( T[s,a,target] + sum_{j != target, ascending} float64(T[s,a,j]) * (1 + ET[j]) ),
+    stop at diff < eps OR (diff < 0.05 and max(ET') - 1 < running maximum) -- order dependent --, running maximum updated
+    with max(ET').  Returns (diameter, running maximum after every target)."""
+    ptr, col, val = csr
+    ptr = np.asarray(ptr, np.int64)
+    col = np.asarray(col, np.int64)
+    val64 = np.asarray(val, np.float32).astype(np.float64)
+    rows = np.repeat(np.arange(S * A), np.diff(ptr))
+    diameter = -np.inf
+    running = []
+    for i in range(S):
+        hit = col == i
+        Te = np.zeros(S * A)
+        Te[rows[hit]] = val64[hit]          # at most one entry per row
+        keep = ~hit
+        r_k, c_k, v_k = rows[keep], col[keep], val64[keep]
+        starts = np.searchsorted(r_k, np.arange(S * A))
+        others = np.arange(S) != i
+        ET = np.zeros(S)                     # entry i is never read (its column is excluded)
+        for _ in range(1_000_000):
+            old = ET
+            prod = v_k * (1.0 + old[c_k])
+            acc = np.zeros(S * A)
+            # ascending-j sequential float64 accumulation per row
+            pos = np.arange(len(r_k)) - starts[r_k]
+            for k in range(int(pos.max()) + 1 if len(pos) else 0):
+                sel = pos == k
+                acc[r_k[sel]] = acc[r_k[sel]] + prod[sel]
+            Q = (Te + acc).reshape(S, A)
+            ET = Q.min(1)
+            diff = np.abs(old[others] - ET[others]).max()
+            mx = ET[others].max()
+            if diff < eps or (diff < 0.05 and mx - 1 < diameter):
+                break
+        diameter = max(diameter, mx)
+        running.append(float(diameter))
+    return float(diameter), running

@@ -60,7 +60,15 @@ class COO:
         return self._with_data(self.data * other.reshape(()).astype(other.dtype)[()])
 
     def __mul__(self, other):
+        if np.asarray(other).size != 1:  # broadcasting product with a dense array: non-zeros times the matching entries
+            return self._elemwise(other, np.multiply)
         return self._scale(other)
+
+    def __add__(self, other):
+        other = other.todense() if hasattr(other, "todense") else np.asarray(other)
+        return _Dense(self.todense() + other)
+
+    __radd__ = __add__
 
     __rmul__ = __mul__
 
@@ -70,14 +78,30 @@ class COO:
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
         if ufunc is np.multiply and method == "__call__" and len(inputs) == 2:
             other = inputs[0] if inputs[1] is self else inputs[1]
-            return self._scale(other)
+            return self.__mul__(other)
+        if ufunc is np.add and method == "__call__" and len(inputs) == 2:
+            other = inputs[0] if inputs[1] is self else inputs[1]
+            return self.__add__(other)
         if ufunc is np.matmul and method == "__call__":
             return NotImplemented
         return NotImplemented
 
     def sum(self, axis=None):
+        # the package reduces with np.add.reduceat over the coordinates sorted by the kept axes: the terms of one output
+        # element are added one by one in ascending order of the reduced index, in the data's dtype -- what numpy does
+        # for a dense reduction over a leading axis too (the zeros in between leave every partial sum unchanged)
         d = self.todense().sum(axis)
         return _Dense(d)
+
+    # -- what the sparse diameter uses (hardness/measures/diameter.py:382-420) -------------------------------------
+    def __getitem__(self, idx):
+        return COO(self.todense()[idx])
+
+    def reshape(self, shape):
+        return COO(self.todense().reshape(shape))
+
+    def _elemwise(self, other, op):
+        return COO(op(self.todense(), np.asarray(other)))
 
     # -- matmul -----------------------------------------------------------------------
     def __matmul__(self, other):
@@ -114,3 +138,15 @@ class _Dense:
 
     def todense(self):
         return self._a
+
+    def min(self, axis=None):
+        return self._a.min(axis)
+
+    def max(self, axis=None):
+        return self._a.max(axis)
+
+    def __getitem__(self, idx):
+        return self._a[idx]
+
+    def __array__(self, dtype=None, copy=None):
+        return self._a if dtype is None else self._a.astype(dtype)

@@ -658,6 +658,43 @@ def test_diameter_lanes_kernel_equals_workgroup_kernel_and_oracle(need_gpu):
         dp.close()
 
 
+def test_sparse_float64_diameter_equals_reference(need_gpu):
+    """K5D + the host replay of the reference's sequential loop (`cmdp_diameter_sparse_f64`) against the reference's own
+    `_get_sparse_diameter` (golden G16) and, on further MDPs incl. a mixed batch, the numpy restatement: float64
+    diameters and the running maximum after every target, bit for bit."""
+    import json
+    import os
+
+    from conftest import GOLDEN
+    from colosseum_amd import hardness
+
+    rows = json.load(open(os.path.join(GOLDEN, "G16_sparse_diameter.json")))
+    for r in rows:
+        m = make_model(r["cls"], **r["kwargs"])
+        dp = BatchedMDP([m], with_env=False)
+        d, run = dp.diameter_sparse_f64()
+        assert d[0] == r["diameter"], (r["cls"], d[0], r["diameter"])
+        assert run.tolist() == r["running_max"]
+        dp.close()
+    ms = [make_model("MiniGridEmptyContinuous", seed=s, size=4 + s, p_rand=0.1) for s in range(3)]  # 64, 100, 144 states
+    dp = BatchedMDP(ms, with_env=False)
+    dp.set_option(L.OPT_DIAMETER_WORKSPACE_MB, 1)  # several launches
+    d, run = dp.diameter_sparse_f64()
+    off = 0
+    for i, m in enumerate(ms):
+        od, orun = O.sparse_diameter_f64(m.n_states, m.n_actions, m.csr())
+        assert d[i] == od and run[off:off + m.n_states].tolist() == orun
+        off += m.n_states
+    dp.close()
+    # the dispatch of a single-core reference: above 1000 states the sparse float64 path, below it the per-target one
+    big = make_model("MiniGridEmptyContinuous", seed=0, size=16, p_rand=0.1)  # 1024 states
+    assert big.n_states > 1000
+    got = hardness.diameter([ms[0], big], variant="reference_single_core")
+    assert got[0] == hardness.diameter([ms[0]])[0]
+    per_target = hardness.diameter([big])[0]
+    assert got[1] != per_target and got[1] == pytest.approx(per_target, abs=0.06)  # float64 + early exit vs float32 to eps
+
+
 def test_greedy_q_policy_rollout(need_gpu):
     """CMDP_POLICY_GREEDY_Q: the device picks the first maximiser of the current Q row.  Feeding the actions it must
     have taken (recomputed on the host from the traced observations) through CMDP_POLICY_HOST_ACTIONS on a fresh handle

@@ -243,3 +243,15 @@ def test_gth_stationary_distribution_vs_reference(monkeypatch):
                                    z[k + "sd_random"], atol=1e-12)
         ar = mc.get_average_reward(T, R, z[k + "pi_rand"], [(int(m.start_states[0]), 1.0)])
         assert ar == pytest.approx(c["avg_reward_pi_rand"], rel=1e-9)
+
+
+def test_sparse_float64_diameter_restatement_vs_reference():
+    """`_get_sparse_diameter` (the single-core reference's path above 1000 states), run by the reference on small MDPs
+    (golden G16): the numpy restatement gives the same float64 diameter and the same running maximum after every
+    target -- the order-dependent early exit included -- bit for bit."""
+    rows = json.load(open(os.path.join(GOLDEN, "G16_sparse_diameter.json")))
+    assert len(rows) >= 5
+    for r in rows:
+        m = make_model(r["cls"], **r["kwargs"])
+        d, running = O.sparse_diameter_f64(m.n_states, m.n_actions, m.csr())
+        assert d == r["diameter"] and running == r["running_max"], r["cls"]
