@@ -26,7 +26,7 @@ NOISE_NONE, NOISE_GAUSSIAN, NOISE_GAUSSIAN_CORRELATED, NOISE_STUDENT_T, NOISE_ST
 CALIB_LDS_READ, CALIB_LDS_CHAIN = 0, 1
 DP_AUTO, DP_WORKGROUP, DP_REGISTER = 0, 1, 2
 DP_REGISTER_DISTINCT = 5  # K2U: register-resident, gathers deduplicated per state
-ROLLOUT_AUTO, ROLLOUT_GLOBAL, ROLLOUT_LDS = 0, 1, 2
+ROLLOUT_AUTO, ROLLOUT_GLOBAL, ROLLOUT_LDS, ROLLOUT_LDS_STOCHASTIC = 0, 1, 2, 3
 
 EXPORTS = [
     "cmdp_version", "cmdp_build_id", "cmdp_last_error", "cmdp_device_count", "cmdp_set_device", "cmdp_create", "cmdp_destroy",

@@ -20,6 +20,7 @@
 
 #include "cmdp_kernels.h"
 #include "cmdp_tracker.h"
+#include "cmdp_k1s.h"
 #include "cmdp_agent.h"
 #include "cmdp_chain.h"
 
@@ -128,6 +129,14 @@ struct cmdp {
   DevBuf<int32_t> d_tr_obs, d_last_obs;
   DevBuf<double> d_tr_rew, d_rsum;
   DevBuf<uint8_t> d_tr_type, d_mask;
+  // LDS-resident rollout of stochastic-dynamics batches (K1S)
+  bool k1s_ok = false;
+  K1sPlan k1s{};
+  size_t k1s_bytes = 0;
+  DevBuf<unsigned long long> d_k1s_codes;
+  DevBuf<uint8_t> d_k1s_pat, d_k1s_rc;
+  DevBuf<uint16_t> d_k1s_sets;
+  DevBuf<double> d_k1s_patterns, d_k1s_rvals;
   // LDS-resident rollout (K1L)
   bool lds_ok = false;
   int lds_G1 = 0, lds_G2 = 0;  // LDS capacity in instances per workgroup at one / two workgroups per CU
@@ -205,6 +214,126 @@ int set_lds(K kernel, size_t bytes) {
 
 
 }  // namespace
+
+// Host side of K1S (cmdp_k1s.h): compresses the sampler tables of a batch with stochastic dynamics into shared
+// cumulative-probability patterns, per-state successor sets and 4-bit entry codes, and sizes the LDS plan.  Leaves
+// h->k1s_ok false (the batch then takes K1) whenever a limit of the format is exceeded.
+static int build_k1s(cmdp_t* h, const cmdp_desc* d) {
+  const int B = h->B, A = h->A;
+  if (h->rng_mode != CMDP_RNG_PHILOX || h->sample_beta || h->layout != CMDP_LAYOUT_CSR) return CMDP_OK;
+  const int64_t S0 = h->max_S;   // slots are sized for the largest instance
+  if (S0 * A >= 65536 || S0 < 1) return CMDP_OK;
+  if (d->sp_rkind)
+    for (int64_t e = 0; e < h->n_entries; ++e)
+      if (d->sp_rkind[e] != 0) return CMDP_OK;   // reward means of Beta entries: K1 reports them
+  const int64_t R = h->n_rows, NS = h->n_states;
+  std::vector<unsigned long long> codes((size_t)R, 0);
+  std::vector<uint8_t> pat((size_t)R, 0);
+  std::vector<double> patterns;
+  std::map<std::vector<uint64_t>, int> pat_of;
+  std::map<uint64_t, int> code_of;
+  std::vector<double> rvals;
+  std::vector<std::vector<int32_t>> sets((size_t)NS);
+  // reward value of every entry -> code
+  std::vector<int> ecode((size_t)h->n_entries);
+  for (int64_t e = 0; e < h->n_entries; ++e) {
+    uint64_t bits;
+    std::memcpy(&bits, &d->sp_reward[e], sizeof bits);
+    auto it = code_of.find(bits);
+    if (it == code_of.end()) {
+      if (rvals.size() == 256) return CMDP_OK;
+      it = code_of.emplace(bits, (int)rvals.size()).first;
+      rvals.push_back(d->sp_reward[e]);
+    }
+    ecode[(size_t)e] = it->second;
+  }
+  int U = 1;
+  bool by_state = true, by_row = true;      // is the reward a function of the successor state alone / of the row alone?
+  std::vector<int> rc_state((size_t)NS, -1), rc_row((size_t)R, -1);
+  for (int b = 0; b < B; ++b) {
+    const int64_t so = h->state_off[b], Sb = h->state_off[b + 1] - so;
+    for (int64_t s = 0; s < Sb; ++s) {
+      auto& set = sets[(size_t)(so + s)];
+      for (int a = 0; a < A; ++a) {
+        const int64_t r = (so + s) * A + a;
+        const int64_t lo = d->sp_ptr[r], hi = d->sp_ptr[r + 1];
+        const int n = (int)(hi - lo);
+        if (n < 1 || n > K1S_MAXE) return CMDP_OK;
+        std::vector<uint64_t> key((size_t)n);
+        std::memcpy(key.data(), d->sp_cum + lo, sizeof(double) * (size_t)n);
+        auto it = pat_of.find(key);
+        if (it == pat_of.end()) {
+          if (pat_of.size() == 64) return CMDP_OK;
+          it = pat_of.emplace(key, (int)pat_of.size()).first;
+          for (int k = 0; k < K1S_MAXE; ++k)
+            patterns.push_back(k < n - 1 ? d->sp_cum[lo + k] : std::numeric_limits<double>::infinity());
+          patterns.push_back(d->sp_cum[hi - 1]);
+        }
+        pat[(size_t)r] = (uint8_t)it->second;
+        unsigned long long word = 0;
+        for (int k = 0; k < n; ++k) {
+          const int32_t nx = d->sp_next[lo + k];
+          int idx = -1;
+          for (size_t j = 0; j < set.size(); ++j)
+            if (set[j] == nx) { idx = (int)j; break; }
+          if (idx < 0) {
+            if (set.size() == 16) return CMDP_OK;
+            idx = (int)set.size();
+            set.push_back(nx);
+          }
+          word |= (unsigned long long)idx << (4 * k);
+          const int c = ecode[(size_t)(lo + k)];
+          if (rc_state[(size_t)(so + nx)] < 0) rc_state[(size_t)(so + nx)] = c;
+          else if (rc_state[(size_t)(so + nx)] != c) by_state = false;
+          if (rc_row[(size_t)r] < 0) rc_row[(size_t)r] = c;
+          else if (rc_row[(size_t)r] != c) by_row = false;
+        }
+        codes[(size_t)r] = word;
+      }
+      U = std::max(U, (int)set.size());
+    }
+    if (d->start_off[b + 1] - d->start_off[b] > K1S_MAXSTART) return CMDP_OK;
+  }
+  if (!by_state && !by_row) return CMDP_OK;
+  K1sPlan p{};
+  p.S = (int)S0; p.rows = (int)S0 * A; p.U = U; p.n_pat = (int)pat_of.size(); p.n_codes = (int)rvals.size();
+  p.reward_mode = by_state ? 0 : 1;
+  p.ch = 32;
+  auto up8 = [](int x) { return (x + 7) & ~7; };
+  p.off_pat = p.rows * 8;
+  p.off_cnt = up8(p.off_pat + p.rows);
+  p.off_ovf = up8(p.off_cnt + p.rows);
+  p.off_sets = up8(p.off_ovf + 2 * (K1S_OVF + 2));
+  p.off_rc = up8(p.off_sets + 2 * p.S * U);
+  p.off_start = up8(p.off_rc + (by_state ? p.S : p.rows));
+  p.slot_bytes = up8(p.off_start + 48 + 8 * K1S_MAXSTART + 4 * K1S_MAXSTART);
+  const size_t fixed = k1s_fixed_bytes(p.n_pat) + 64;
+  const size_t per = (size_t)p.slot_bytes + k1s_ring_bytes(p.ch);
+  if (fixed + 4 * per > (size_t)kLdsBudget) return CMDP_OK;   // fewer than four instances per CU: not worth it
+  const int cap = (int)std::min<size_t>(64, ((size_t)kLdsBudget - fixed) / per);
+  // the fewest instances per workgroup that keep the number of rounds (as for K1L)
+  const int64_t wgs = (B + cap - 1) / cap, rounds = (wgs + h->cus - 1) / h->cus;
+  p.G = (int)std::min<int64_t>(cap, std::max<int64_t>(1, (B + rounds * h->cus - 1) / (rounds * h->cus)));
+  hipStream_t st = h->stream;
+  std::vector<uint16_t> sets_flat((size_t)NS * U, 0);
+  for (int64_t s = 0; s < NS; ++s)
+    for (size_t j = 0; j < sets[(size_t)s].size(); ++j) sets_flat[(size_t)s * U + j] = (uint16_t)sets[(size_t)s][j];
+  std::vector<uint8_t> rc(by_state ? (size_t)NS : (size_t)R, 0);
+  for (size_t i = 0; i < rc.size(); ++i) rc[i] = (uint8_t)std::max(0, by_state ? rc_state[i] : rc_row[i]);
+  HIP_TRY(h->d_k1s_codes.upload(codes.data(), codes.size(), st));
+  HIP_TRY(h->d_k1s_pat.upload(pat.data(), pat.size(), st));
+  HIP_TRY(h->d_k1s_sets.upload(sets_flat.data(), sets_flat.size(), st));
+  HIP_TRY(h->d_k1s_rc.upload(rc.data(), rc.size(), st));
+  HIP_TRY(h->d_k1s_patterns.upload(patterns.data(), patterns.size(), st));
+  HIP_TRY(h->d_k1s_rvals.upload(rvals.data(), rvals.size(), st));
+  HIP_TRY(hipStreamSynchronize(st));
+  p.codes = h->d_k1s_codes.p; p.pat = h->d_k1s_pat.p; p.sets = h->d_k1s_sets.p; p.rcode = h->d_k1s_rc.p;
+  p.patterns = h->d_k1s_patterns.p; p.rvals = h->d_k1s_rvals.p;
+  h->k1s = p;
+  h->k1s_bytes = fixed + (size_t)p.G * per + 16;
+  h->k1s_ok = true;
+  return CMDP_OK;
+}
 
 extern "C" {
 
@@ -522,6 +651,8 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
         }
       }
     }
+    if (!h->lds_ok)
+      if (int rc = build_k1s(h, d)) return rc;
     if (h->n_slots) {
       DevBuf<int32_t> d_seeds;
       HIP_TRY(d_seeds.upload(seeds.data(), seeds.size(), st));
@@ -730,6 +861,19 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
     HIP_TRY(hipGetLastError());
     return CMDP_OK;
   }
+  const bool k1s_eligible = h->k1s_ok && policy == CMDP_POLICY_RANDOM && !trace;
+  if (h->rollout_kernel == 3 && !k1s_eligible)
+    return fail(CMDP_ERR_UNSUPPORTED, "the LDS-resident stochastic rollout K1S needs Philox mode, the random policy, no trace, equal "
+                                      "state counts, <= 16 entries per row and <= 16 distinct successors per state, <= 64 "
+                                      "cumulative-probability patterns, deterministic rewards that depend on the successor or on "
+                                      "the row alone, and room for four instances in LDS");
+  if (k1s_eligible && (h->rollout_kernel == 3 || (h->rollout_kernel == 0 && n_steps >= 64))) {
+    if (int rc = set_lds(k_rollout_stoch, h->k1s_bytes)) return rc;
+    hipLaunchKernelGGL(k_rollout_stoch, dim3(grid_for(h->B, h->k1s.G)), dim3(K1S_THREADS), h->k1s_bytes, st, t, h->k1s, n_steps,
+                       d_rsum, d_last);
+    HIP_TRY(hipGetLastError());
+    return CMDP_OK;
+  }
 #define ROLL(P, TR, BT) \
   hipLaunchKernelGGL((k_rollout<P, TR, BT>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype)
   const bool bt = h->sample_beta;
@@ -808,7 +952,7 @@ int cmdp_rollout_async(cmdp_t* h, int policy, int64_t n_steps) {
 
 int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
   if (!h) return fail(CMDP_ERR_INVALID, "null handle");
-  if (option == CMDP_OPT_ROLLOUT_KERNEL && value >= 0 && value <= 2) {
+  if (option == CMDP_OPT_ROLLOUT_KERNEL && value >= 0 && value <= 3) {
     h->rollout_kernel = (int)value;
     return CMDP_OK;
   }
@@ -847,10 +991,10 @@ int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
 
 int cmdp_lds_plan(cmdp_t* h, int32_t plan[4]) {
   if (!h || !plan) return fail(CMDP_ERR_INVALID, "bad argument");
-  plan[0] = h->lds_ok ? 1 : 0;
-  plan[1] = h->lds_ok ? h->lds_plan.pipe : 0;
-  plan[2] = h->lds_ok ? h->lds_plan.G : 0;
-  plan[3] = h->lds_ok ? h->lds_plan.ch : 0;
+  plan[0] = (h->lds_ok || h->k1s_ok) ? 1 : 0;
+  plan[1] = h->lds_ok ? h->lds_plan.pipe : (h->k1s_ok ? 2 : 0);
+  plan[2] = h->lds_ok ? h->lds_plan.G : (h->k1s_ok ? h->k1s.G : 0);
+  plan[3] = h->lds_ok ? h->lds_plan.ch : (h->k1s_ok ? h->k1s.ch : 0);
   return CMDP_OK;
 }
 

@@ -191,7 +191,10 @@ int cmdp_calibrate(int what, int64_t n_steps, double* ns_per_step);
 /* Tuning knobs (never change results).  CMDP_OPT_ROLLOUT_KERNEL: 0 = automatic, 1 = lane-per-instance
    kernel with the tables in HBM, 2 = LDS-resident kernel (fails with CMDP_ERR_UNSUPPORTED when the batch is
    not eligible: deterministic dynamics, one start state, equal state counts <= 65535, <= 256 distinct reward
-   values, at least 8 instances per 160 KiB of LDS).
+   values, at least 8 instances per 160 KiB of LDS), 3 = LDS-resident kernel for STOCHASTIC dynamics K1S (Philox mode;
+   the sampler tables compressed into shared cumulative-probability patterns and per-state successor sets: <= 16
+   entries per row, <= 16 distinct successors per state, <= 64 patterns, rewards a function of the successor or of
+   the row, at least 4 instances per 160 KiB of LDS).
    CMDP_OPT_DP_KERNEL (Jacobi sweeps): 0 = automatic, 1 = workgroup kernel with the CSR in LDS or HBM,
    2 = register-resident CSR kernel (CMDP_ERR_UNSUPPORTED when no compiled shape fits: A in 2..4, <= 8
    non-zeros per row, <= 1024 states), 3 = (cmdp_diameter only) the 64-targets-per-workgroup kernel K5S that is
@@ -218,7 +221,8 @@ int cmdp_set_option(cmdp_t* h, int option, int64_t value);
 
 /* What the LDS-resident random-policy rollout of this handle is (introspection for benchmarks and tests; no
    reference counterpart): plan[0] = 1 if the batch is eligible for it, plan[1] = 1 for the wavefront-pipeline kernel
-   K1P (k_rollout_pipe), 0 for the fused walker K1L (k_rollout_lds), plan[2] = instances per workgroup,
+   K1P (k_rollout_pipe), 0 for the fused walker K1L (k_rollout_lds), 2 for the stochastic-dynamics kernel K1S
+   (k_rollout_stoch), plan[2] = instances per workgroup,
    plan[3] = transitions per chunk.  The kernel flavour and chunk length are chosen when the handle is created (fewest
    rounds of workgroups x measured time per transition). */
 int cmdp_lds_plan(cmdp_t* h, int32_t plan[4]);

@@ -658,6 +658,58 @@ def test_diameter_lanes_kernel_equals_workgroup_kernel_and_oracle(need_gpu):
         dp.close()
 
 
+def test_lds_resident_stochastic_rollout_equals_hbm_kernel_and_oracle(need_gpu):
+    """K1S (sampler tables compressed into patterns / successor sets / 4-bit codes, resident in LDS) on batches with
+    stochastic dynamics: final states, float64 reward sums, state and state-action visit counts, in-episode times and
+    the Philox counters bit-equal to the lane-per-instance kernel K1 and to the CPU oracle, over several launches of odd
+    lengths, multiple start states, episodic and continuous."""
+    cases = [
+        ("FrozenLakeContinuous", dict(size=8, p_frozen=0.9, p_rand=0.1), 9),
+        ("FrozenLakeEpisodic", dict(size=5, p_frozen=0.9, p_rand=0.2, p_lazy=0.1), 20),
+        ("MiniGridEmptyEpisodic", dict(size=6, p_rand=0.1, n_starting_states=3), 12),
+        ("MiniGridEmptyContinuous", dict(size=8, p_rand=0.05, p_lazy=0.05), 70),   # more instances than fit one workgroup
+        ("DeepSeaEpisodic", dict(size=9, p_rand=0.3), 7),                          # rewards depend on the row
+        ("MiniGridRoomsContinuous", dict(room_size=3, n_rooms=4, p_lazy=0.1, n_starting_states=2), 5),
+    ]
+    ran = 0
+    for cls, kw, n in cases:
+        ms = [make_model(cls, seed=s, **kw) for s in range(n)]
+        ms = [m for m in ms if m.n_states == ms[0].n_states and m.H == ms[0].H]
+        keys = np.arange(1000, 1000 + len(ms), dtype=np.uint64)
+        outs = []
+        for kernel in (L.ROLLOUT_LDS_STOCHASTIC, L.ROLLOUT_GLOBAL):
+            env = BatchedMDP(ms, rng_mode=L.RNG_PHILOX, philox_keys=keys, with_dp=False)
+            if kernel == L.ROLLOUT_LDS_STOCHASTIC:
+                assert env.lds_plan()["kernel"] == "k_rollout_stoch", (cls, env.lds_plan())
+            env.set_rollout_kernel(kernel)
+            env.reset()
+            rs = []
+            for steps in (1, 63, 700, 9001):   # 9001: several flushes of the 8-bit counters
+                r = env.rollout(steps)
+                rs.append((r["last_obs"].copy(), r["reward_sum"].copy()))
+            vs, vsa = env.visits()
+            cur, h, _ = env.state()
+            last = env.last_start()
+            outs.append((rs, vs, vsa, cur, h, last, env.previous_start))
+            env.close()
+        (rs1, vs1, vsa1, cur1, h1, l1, p1), (rs0, vs0, vsa0, cur0, h0, l0, p0) = outs
+        for (a, b), (c, d) in zip(rs1, rs0):
+            np.testing.assert_array_equal(a, c, err_msg=cls)
+            np.testing.assert_array_equal(b, d, err_msg=cls)
+        for x, y in ((vs1, vs0), (vsa1, vsa0), (cur1, cur0), (h1, h0), (l1, l0), (p1, p0)):
+            np.testing.assert_array_equal(x, y, err_msg=cls)
+        # and the oracle, instance 0 and the last one
+        for i in (0, len(ms) - 1):
+            e = O.OracleEnv(ms[i], rng_mode=1, philox_key=int(keys[i]))
+            e.reset()
+            for steps in (1, 63, 700, 9001):
+                e.rollout(steps, trace=False)
+            off = int(sum(m.n_states for m in ms[:i]))
+            np.testing.assert_array_equal(vs1[off:off + ms[i].n_states], e.visits()[0])
+        ran += 1
+    assert ran == len(cases)
+
+
 def test_sparse_float64_diameter_equals_reference(need_gpu):
     """K5D + the host replay of the reference's sequential loop (`cmdp_diameter_sparse_f64`) against the reference's own
     `_get_sparse_diameter` (golden G16) and, on further MDPs incl. a mixed batch, the numpy restatement: float64

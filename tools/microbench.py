@@ -39,8 +39,15 @@ for name, cls, kws, B in (
     env = BatchedMDP(tables=replicate(None, models, B), rng_mode=L.RNG_PHILOX, philox_keys=np.arange(B, dtype=np.uint64))
     env.reset()
     n = 2000
-    dt = timed(lambda: (env.rollout_async(n), env.synchronize()))
-    out[name] = dict(instances=B, states=int(models[0].n_states), steps_per_s=B * n / dt)
+    out[name] = dict(instances=B, states=int(models[0].n_states), lds_plan=env.lds_plan())
+    for label, kernel in (("hbm_tables_k1", L.ROLLOUT_GLOBAL), ("lds_resident_k1s", L.ROLLOUT_LDS_STOCHASTIC)):
+        try:
+            env.set_rollout_kernel(kernel)
+            dt = timed(lambda: (env.rollout_async(n), env.synchronize()))
+            out[name][label + "_steps_per_s"] = B * n / dt
+        except L.CmdpError as e:
+            out[name][label + "_steps_per_s"] = None
+            out[name][label + "_error"] = str(e)[:120]
     env.close()
 
 # per-call step API: H2D actions + kernel + D2H obs/reward/type every call
