@@ -314,6 +314,10 @@ static int build_k1s(cmdp_t* h, const cmdp_desc* d) {
   // the fewest instances per workgroup that keep the number of rounds (as for K1L)
   const int64_t wgs = (B + cap - 1) / cap, rounds = (wgs + h->cus - 1) / h->cus;
   p.G = (int)std::min<int64_t>(cap, std::max<int64_t>(1, (B + rounds * h->cus - 1) / (rounds * h->cus)));
+  // lanes per instance in the walker wavefront.  Measured (FrozenLake-20 / MiniGrid-8 / DeepSea-20 with p_rand, G = 8 /
+  // 11 / 22): teams of 8 (two entries per lane, two ballots) +19 %; teams of 4 (four ballots) -3 %; of 2 -31 % against
+  // a lane per instance counting its 16 entries itself -- so teams only where a lane gets at most two entries
+  p.team = p.G <= 4 ? 16 : (p.G <= 8 ? 8 : 1);
   hipStream_t st = h->stream;
   std::vector<uint16_t> sets_flat((size_t)NS * U, 0);
   for (int64_t s = 0; s < NS; ++s)

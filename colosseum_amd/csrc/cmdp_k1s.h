@@ -9,8 +9,8 @@
 //   * the rows of a state draw their successors from the same few states (a cell's neighbours and itself): a per-state
 //     SUCCESSOR SET of U <= 16 states, and every row entry is a 4-bit index into it -- one 64-bit word per row.
 // With that, an instance is ~10 bytes per row + 2 U bytes per state (FrozenLake 20x20: 18 KB instead of 67 KB of
-// float64 / int32 tables) and G instances fit a CU's LDS.  One workgroup runs G instances: lane i of wavefront 0 walks
-// instance i entirely on chip, wavefronts 1-3 produce the random-policy action bytes and the 53-bit transition uniforms
+// float64 / int32 tables) and G instances fit a CU's LDS.  One workgroup runs G instances: a TEAM of lanes of wavefront 0
+// walks each instance entirely on chip, wavefronts 1-3 produce the random-policy action bytes and the 53-bit transition uniforms
 // of the NEXT chunk (Philox domains 2 and 0, the same streams as K1 and the CPU oracle) into double-buffered LDS rings.
 //
 // Per transition the walker does: action + uniform from the ring; row word + pattern id (two independent ds_reads);
@@ -34,6 +34,7 @@ struct K1sPlan {
   int32_t n_codes;       // distinct reward values
   int32_t reward_mode;   // 0: code per successor state, 1: code per row
   int32_t ch;            // transitions per ring chunk
+  int32_t team;          // lanes of wavefront 0 per instance: 16 or 8 when G <= 4 / 8 (one or two entries per lane), else 1
   int32_t slot_bytes;    // LDS bytes per instance
   int32_t off_pat, off_cnt, off_ovf, off_sets, off_rc, off_start;   // byte offsets inside a slot
   const unsigned long long* codes;  // [R] 4-bit successor-set indices of the row's entries
@@ -101,13 +102,22 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
     }
     for (int k = 0; k < K1S_MAXSTART; ++k) reinterpret_cast<int32_t*>(sb + 48 + 8 * K1S_MAXSTART)[k] = 0;  // resets per start state
   }
-  const bool walker = tid < nb;
-  const int b = g0 + (walker ? tid : 0);
+  // Wavefront 0 walks the instances in TEAMS of T lanes: the lanes of a team hold the same state and split the one part
+  // of a transition that is wide -- the comparison of u * total with the row's (padded) 16 cumulative probabilities:
+  // every lane compares 16 / T of them, one wave-wide ballot per entry collects the results and the popcount of the
+  // team's bits is bisect_right's index (the north star's "wavefront CDF lookup").  Lane 0 of a team owns its instance's
+  // counters; teams beyond the group's instances shadow instance 0 without writing.
+  const int T = p.team, E = K1S_MAXE / T;
+  const int team = (tid & 63) / T, sub = (tid & 63) - team * T;
+  const bool walker = tid < 64 && team < nb;
+  const bool writer = walker && sub == 0;
+  const int wslot = walker ? team : 0;
+  const int b = g0 + wslot;
   int32_t cur = t.cur[b], h = t.hstep[b];
   int32_t last_s = t.last_start[b], prev_s = t.prev_start[b];
   unsigned long long nr = t.n_reset[b];
   double sum = 0.0;
-  unsigned char* base = slots + (size_t)(walker ? tid : 0) * p.slot_bytes;
+  unsigned char* base = slots + (size_t)wslot * p.slot_bytes;
   const unsigned long long* codes = reinterpret_cast<const unsigned long long*>(base);
   const uint8_t* pat = base + p.off_pat;
   uint8_t* c8 = base + p.off_cnt;
@@ -161,9 +171,10 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
     if (tid >= 64) {
       const int64_t nfirst = done + len;
       if (nfirst < n_steps) produce(buf ^ 1, nfirst, (int)min((int64_t)CH, n_steps - nfirst));
-    } else if (walker) {
-      const double* us = reinterpret_cast<const double*>(ring_u) + ((size_t)buf * p.G + tid) * CH;
-      const unsigned char* as = ring_a + ((size_t)buf * p.G + tid) * CH;
+    } else {   // wavefront 0, every lane (the ballots need the whole wave in step)
+      const double* us = reinterpret_cast<const double*>(ring_u) + ((size_t)buf * p.G + wslot) * CH;
+      const unsigned char* as = ring_a + ((size_t)buf * p.G + wslot) * CH;
+      const unsigned long long tmask = (T == 64) ? ~0ull : ((1ull << T) - 1ull);
       for (int s = 0; s < len; ++s) {
         const int a = as[s];
         const double u = us[s];
@@ -172,15 +183,24 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
         const double* pc = pats + (size_t)pat[row] * K1S_PAT_STRIDE;
         const double x = u * (pc[16] + 0.0);
         int idx = 0;
+        if (T == 1) {
 #pragma unroll
-        for (int k = 0; k < K1S_MAXE; ++k) idx += (pc[k] <= x) ? 1 : 0;   // padded with +inf beyond n - 1
+          for (int k = 0; k < K1S_MAXE; ++k) idx += (pc[k] <= x) ? 1 : 0;   // padded with +inf beyond n - 1: those never count
+        } else {
+          for (int e = 0; e < E; ++e) {
+            const unsigned long long bal = __ballot(pc[sub * E + e] <= x);
+            idx += __popcll((bal >> (team * T)) & tmask);
+          }
+        }
         const int code = (int)((w >> (4 * idx)) & 15ull);
         const int nxt = sets[cur * U + code];
         const int arow = nxt * A + a;                       // arrival node under the action taken (base.py:1302-1303)
-        const int c1 = (int)c8[arow] + 1;
-        ovf[n_ovf] = (uint16_t)arow;                        // kept only on a wrap
-        n_ovf += c1 >> 8;
-        c8[arow] = (uint8_t)c1;
+        if (writer) {
+          const int c1 = (int)c8[arow] + 1;
+          ovf[n_ovf] = (uint16_t)arow;                      // kept only on a wrap
+          n_ovf += c1 >> 8;
+          c8[arow] = (uint8_t)c1;
+        }
         sum += rv2[p.reward_mode == 0 ? rc[nxt] : rc[row]];
         ++h;
         cur = nxt;
@@ -190,14 +210,14 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
           const int ns = st_n[0];
           if (ns > 1) {
             uint32_t ww[4];
-            const uint2 key = keys[tid];
+            const uint2 key = keys[wslot];
             philox4x32_10((uint32_t)nr, (uint32_t)(nr >> 32), 1u, 0u, key.x, key.y, ww);
             const double xs = u53(ww[0], ww[1]) * (st_cum[ns - 1] + 0.0);
             for (int i = 0; i < ns - 1; ++i) k += (st_cum[i] <= xs) ? 1 : 0;
           }
           ++nr;
           cur = st_n[1 + k];
-          st_res[k] += 1;
+          if (writer) st_res[k] += 1;
           prev_s = last_s;
           last_s = cur;
         }
@@ -209,7 +229,7 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
     const bool flush_now = (since_flush + CH > 256 * K1S_OVF) || done >= n_steps;   // an 8-bit counter wraps at most once per 256 transitions
     __syncthreads();
     if (flush_now) {
-      if (walker) {  // wraps first: each is worth 256 visits
+      if (writer) {  // wraps first: each is worth 256 visits
         const int64_t so = t.state_off[b];
         for (int i = 0; i < n_ovf; ++i) {
           atomicAdd(t.visits_sa + so * A + ovf[i], 256);
@@ -222,7 +242,7 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
       __syncthreads();
     }
   }
-  if (walker) {
+  if (writer) {
     const int64_t so = t.state_off[b];
     const int ns = st_n[0];
     for (int k = 0; k < ns; ++k)                            // resets bump the start state's visit count (env_reset)
@@ -231,7 +251,7 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
     t.prev_start[b] = prev_s;
     t.cur[b] = cur;
     t.hstep[b] = h;
-    t.n_trans[b] = ntr[tid] + (unsigned long long)n_steps;
+    t.n_trans[b] = ntr[wslot] + (unsigned long long)n_steps;
     t.n_reset[b] = nr;
     if (reward_sum) reward_sum[b] = sum;
     if (last_obs) last_obs[b] = cur;
