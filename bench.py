@@ -387,7 +387,7 @@ def main():
         kms, kid = C.c_double(), C.c_double()
         L.check(lib.cmdp_stat(dp.handle, L.STAT_DP_KERNEL_MS, C.byref(kms)))
         L.check(lib.cmdp_stat(dp.handle, L.STAT_DP_KERNEL, C.byref(kid)))
-        kname = {1: "k_dp_block", 2: "k_dp_reg", 5: "k_dp_regu", 6: "k_dp_wave_gs"}.get(int(kid.value), "?")
+        kname = {1: "k_dp_block", 2: "k_dp_reg", 5: "k_dp_regu", 6: "k_dp_wave_gs", 7: "k_dp_regw"}.get(int(kid.value), "?")
         nS = int(np.max(np.diff(fl["state_off"])))
         nnz = int(len(fl["csr_col"])) / args.vi_instances
         line["vi"] = {

@@ -21,11 +21,13 @@ OPT_LDS_GROUPS_PER_CU = 3
 OPT_DIAMETER_WORKSPACE_MB = 4
 OPT_CHAIN_EXACT_ORDER = 5
 OPT_MIXING_PATH = 6
+OPT_DIAMETER_RELABEL_MIN_STATES = 7
 STAT_DP_KERNEL_MS, STAT_DP_KERNEL = 1, 2
 NOISE_NONE, NOISE_GAUSSIAN, NOISE_GAUSSIAN_CORRELATED, NOISE_STUDENT_T, NOISE_STUDENT_T_CORRELATED = 0, 1, 2, 3, 4
 CALIB_LDS_READ, CALIB_LDS_CHAIN = 0, 1
 DP_AUTO, DP_WORKGROUP, DP_REGISTER = 0, 1, 2
 DP_REGISTER_DISTINCT = 5  # K2U: register-resident, gathers deduplicated per state
+DP_REGISTER_WAVEFRONT = 7  # K2W: K2U's tables with one wavefront per instance (<= 448 states, <= 5 distinct successors)
 ROLLOUT_AUTO, ROLLOUT_GLOBAL, ROLLOUT_LDS, ROLLOUT_LDS_STOCHASTIC = 0, 1, 2, 3
 
 EXPORTS = [

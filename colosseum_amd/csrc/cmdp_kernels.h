@@ -1006,131 +1006,198 @@ __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
 // partial-sum pass and the search pass.  The Philox work of a wavefront is spread over its lanes: every 64
 // transitions lane j computes the transition uniform of transition base+j and the action block base/4+j, and
 // the per-transition values are then broadcast with one shuffle each (values are wave-uniform anyway).
-template <int POLICY, int NV, bool BETA>
+// NI = instances per wavefront.  A transition is one dependent chain -- row address -> 2 KB row from HBM -> scan ->
+// successor -- so a wavefront with one instance has ONE row in flight and idles for the HBM latency (16 wavefronts per CU
+// x 2 KB = 32 KB in flight per CU, half of what covers the latency at 8 TB/s).  With NI = 2 the wavefront walks two
+// instances in one instruction stream, software-pipelined half a transition apart: the row of one is in flight while the
+// other's is scanned (`issue` = everything up to the loads, `consume` = everything after).  Per-instance state is
+// indexed by compile-time constants only (registers, no scratch).
+template <int NV>
+struct DenseWalk {
+  // persistent
+  int b;
+  int64_t soff, ebase;
+  int S_b;
+  uint2 key;
+  int32_t cur, h;
+  unsigned long long nt, nr, base;
+  double sum, u_lane;
+  uint32_t acts_lane;
+  // in flight between issue and consume
+  float4 v[NV];
+  RowDesc d;
+  double u;
+  int a;
+};
+
+template <int POLICY, int NV, bool BETA, int NI>
 __global__ void __launch_bounds__(256) k_rollout_dense(EnvTables t, DenseArgs dn, const int8_t* __restrict__ actions,
                                                        int64_t n_steps, double* __restrict__ reward_sum,
                                                        int32_t* __restrict__ last_obs) {
   const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= t.B) return;  // whole wavefronts leave together
-  const int64_t soff = t.state_off[b], ebase = t.entry_base[b];
-  const int S_b = (int)(t.state_off[b + 1] - soff);
-  const uint2 key = t.philox_key[b];
-  int32_t cur = t.cur[b], h = t.hstep[b];
-  unsigned long long nt = t.n_trans[b], nr = t.n_reset[b];
-  double sum = 0.0;
-  unsigned long long base = nt;
-  double u_lane = 0.0;
-  uint32_t acts_lane = 0;
-  for (int64_t step = 0; step < n_steps; ++step) {
-    const int i = (int)(nt - base);
-    if (i == 0 || i == 64) {  // refill: 64 transitions' worth of random numbers, one Philox block per lane
-      base = nt;
-      uint32_t w[4];
-      const unsigned long long n = base + (unsigned long long)lane;
-      philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 0u, 0u, key.x, key.y, w);
-      u_lane = u53(w[0], w[1]);
-      if (POLICY == 0) {
-        const unsigned long long q = (base >> 2) + (unsigned long long)lane;
-        philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), 2u, 0u, key.x, key.y, w);
-        acts_lane = 0;
+  // the instance index and everything derived from it is wave-uniform: readfirstlane tells the compiler, and the walkers'
+  // state (current state, counters, keys, offsets, the row descriptor) lives in scalar registers -- VGPRs, which set the
+  // occupancy, are left to the row itself and the scan
+  const int b0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))) * NI;
+  if (b0 >= t.B) return;  // whole wavefronts leave together
+  DenseWalk<NV> w[NI];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acts_lane |= (uint32_t)(((uint64_t)w[j] * (uint64_t)t.A) >> 32) << (8 * j);
+  for (int i = 0; i < NI; ++i) {
+    const int b = (b0 + i < t.B) ? b0 + i : b0;  // an odd batch: the last wavefront's second walker stays idle
+    w[i].b = b;
+    w[i].soff = t.state_off[b];
+    w[i].ebase = t.entry_base[b];
+    w[i].S_b = (int)(t.state_off[b + 1] - w[i].soff);
+    w[i].key = t.philox_key[b];
+    w[i].cur = t.cur[b];
+    w[i].h = t.hstep[b];
+    w[i].nt = t.n_trans[b];
+    w[i].nr = t.n_reset[b];
+    w[i].base = w[i].nt;
+    w[i].sum = 0.0;
+    w[i].u_lane = 0.0;
+    w[i].acts_lane = 0;
+  }
+  const bool second_is_real = NI == 1 || b0 + 1 < t.B;
+
+  // everything of a transition up to and including its loads
+  auto issue = [&](DenseWalk<NV>& x, int64_t step) {
+    const int i = (int)(x.nt - x.base);
+    if (i == 0 || i == 64) {  // refill: 64 transitions' worth of random numbers, one Philox block per lane
+      x.base = x.nt;
+      uint32_t r4[4];
+      const unsigned long long n = x.base + (unsigned long long)lane;
+      philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 0u, 0u, x.key.x, x.key.y, r4);
+      x.u_lane = u53(r4[0], r4[1]);
+      if (POLICY == 0) {
+        const unsigned long long q = (x.base >> 2) + (unsigned long long)lane;
+        philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), 2u, 0u, x.key.x, x.key.y, r4);
+        x.acts_lane = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x.acts_lane |= (uint32_t)(((uint64_t)r4[j] * (uint64_t)t.A) >> 32) << (8 * j);
       }
     }
     // wave-uniform lane indices: v_readlane (scalar result, no LDS round trip) instead of a shuffle
-    const int idx = __builtin_amdgcn_readfirstlane((int)(nt - base));
-    const double u = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(u_lane), idx),
-                                      __builtin_amdgcn_readlane(__double2loint(u_lane), idx));
-    int a;
+    const int idx = __builtin_amdgcn_readfirstlane((int)(x.nt - x.base));
+    x.u = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x.u_lane), idx),
+                           __builtin_amdgcn_readlane(__double2loint(x.u_lane), idx));
     if (POLICY == 1) {
-      a = (int)actions[step * t.B + b];
+      x.a = (int)actions[step * t.B + x.b];
     } else {
-      const int widx = __builtin_amdgcn_readfirstlane((int)((nt >> 2) - (base >> 2)));
-      const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)acts_lane, widx);
-      a = (int)((word >> (8 * (int)(nt & 3))) & 0xffu);
+      const int widx = __builtin_amdgcn_readfirstlane((int)((x.nt >> 2) - (x.base >> 2)));
+      const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)x.acts_lane, widx);
+      x.a = (int)((word >> (8 * (int)(x.nt & 3))) & 0xffu);
     }
-    ++nt;
-    ++h;
-    const int64_t r = (soff + cur) * t.A + a;
+    ++x.nt;
+    ++x.h;
+    const int64_t r = (x.soff + x.cur) * t.A + x.a;
     const float4* row = reinterpret_cast<const float4*>(dn.P + r * dn.spad + (int64_t)lane * (4 * NV));
-    float4 v[NV];
 #pragma unroll
     for (int q = 0; q < NV; ++q)  // the padding behind the last state is all zeros: not fetched
-      v[q] = (lane * (4 * NV) + 4 * q < S_b) ? row[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const RowDesc d = t.row[r];  // independent of the row data: in flight together with it
+      x.v[q] = (lane * (4 * NV) + 4 * q < x.S_b) ? row[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    x.d = t.row[r];  // independent of the row data: in flight together with it
+  };
+
+  // everything after the loads: the successor, the reward, the counters, the episode end
+  auto consume = [&](DenseWalk<NV>& x) {
     // exact float64 prefix sums inside the lane (kept in registers), then across the wave
     double cl[4 * NV];
     double part = 0.0;
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
-      part += (double)v[q].x; cl[4 * q + 0] = part;
-      part += (double)v[q].y; cl[4 * q + 1] = part;
-      part += (double)v[q].z; cl[4 * q + 2] = part;
-      part += (double)v[q].w; cl[4 * q + 3] = part;
+      part += (double)x.v[q].x; cl[4 * q + 0] = part;
+      part += (double)x.v[q].y; cl[4 * q + 1] = part;
+      part += (double)x.v[q].z; cl[4 * q + 2] = part;
+      part += (double)x.v[q].w; cl[4 * q + 3] = part;
     }
     const double incl = wave_incl_scan(part, lane);
     const double total = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(incl), 63),
                                           __builtin_amdgcn_readlane(__double2loint(incl), 63));
-    const double x = u * total;
+    const double xx = x.u * total;
     const double excl = incl - part;
     // next = min{ j : cum_j > x }.  The cumulative sums are non-decreasing and only grow at non-zero columns, so the
     // first lane whose inclusive total exceeds x holds the column, and inside it the column is the number of its
     // prefix sums that are still <= x (all sums are exact, so excl + cl[i] is the sequential scan's value).
-    const unsigned long long m = __ballot(incl > x);
+    const unsigned long long m = __ballot(incl > xx);
     int nxt;
     if (m) {
       int cnt = 0;
 #pragma unroll
-      for (int i = 0; i < 4 * NV; ++i) cnt += (excl + cl[i] <= x) ? 1 : 0;
+      for (int i = 0; i < 4 * NV; ++i) cnt += (excl + cl[i] <= xx) ? 1 : 0;
       nxt = __builtin_amdgcn_readlane(lane * (4 * NV) + cnt, __ffsll((long long)m) - 1);
     } else {  // u * total rounded up to total: the last non-zero column of the row
       int last_nz = -1;
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
-        const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+        const float e[4] = {x.v[q].x, x.v[q].y, x.v[q].z, x.v[q].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (e[k] != 0.0f) last_nz = lane * (4 * NV) + q * 4 + k;
       }
       const unsigned long long mz = __ballot(last_nz >= 0);
-      nxt = __shfl(last_nz, 63 - __clzll((long long)mz), 64);
+      nxt = __builtin_amdgcn_readfirstlane(__shfl(last_nz, 63 - __clzll((long long)mz), 64));
     }
     // reward of the sampler entry (s, a, nxt)
+    const RowDesc d = x.d;
     double rraw = d.reward_if_det;
-    int64_t ent = ebase + d.first;
+    int64_t ent = x.ebase + d.first;
     if (d.n > 1) {
       int found = -1;
       for (int k0 = 0; k0 < d.n && found < 0; k0 += 64) {
         const int k = k0 + lane;
-        const bool eq = k < d.n && t.sp_next[ebase + d.first + k] == nxt;
+        const bool eq = k < d.n && t.sp_next[x.ebase + d.first + k] == nxt;
         const unsigned long long me = __ballot(eq);
         if (me) found = k0 + __ffsll((long long)me) - 1;
       }
       ent += found;
       rraw = t.sp_reward[ent];
     }
-    if (BETA && t.sp_rkind && t.sp_rkind[ent] == 1) rraw = philox_beta(t.sp_rp0[ent], t.sp_rp1[ent], nt - 1, key);
-    sum += rraw * t.rscale - t.rmin;
+    if (BETA && t.sp_rkind && t.sp_rkind[ent] == 1) rraw = philox_beta(t.sp_rp0[ent], t.sp_rp1[ent], x.nt - 1, x.key);
+    x.sum += rraw * t.rscale - t.rmin;
     if (lane == 0) {
-      bump(t.visits_s + soff + nxt);
-      bump(t.visits_sa + (soff + nxt) * t.A + a);
+      bump(t.visits_s + x.soff + nxt);
+      bump(t.visits_sa + (x.soff + nxt) * t.A + x.a);
     }
-    cur = nxt;
-    if (t.H > 0 && h >= t.H) {
+    x.cur = nxt;
+    if (t.H > 0 && x.h >= t.H) {
       int32_t s0 = 0;
-      if (lane == 0) s0 = env_reset(t, b, soff, key, nr);
-      cur = __shfl(s0, 0, 64);
-      h = 0;
+      unsigned long long nr_lane0 = x.nr;
+      if (lane == 0) s0 = env_reset(t, x.b, x.soff, x.key, nr_lane0);
+      x.nr += 1;  // what env_reset did to lane 0's copy: the counter itself stays wave-uniform
+      x.cur = __builtin_amdgcn_readfirstlane(s0);
+      x.h = 0;
+    }
+  };
+
+  if (n_steps > 0) {
+    if constexpr (NI == 1) {
+      for (int64_t step = 0; step < n_steps; ++step) {
+        issue(w[0], step);
+        consume(w[0]);
+      }
+    } else {
+      issue(w[0], 0);
+      for (int64_t step = 0; step < n_steps; ++step) {
+        if (second_is_real) issue(w[1], step);
+        consume(w[0]);
+        if (step + 1 < n_steps) issue(w[0], step + 1);
+        if (second_is_real) consume(w[1]);
+      }
     }
   }
   if (lane == 0) {
-    t.cur[b] = cur;
-    t.hstep[b] = h;
-    t.n_trans[b] = nt;
-    t.n_reset[b] = nr;
-    if (reward_sum) reward_sum[b] = sum;
-    if (last_obs) last_obs[b] = cur;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (i == 0 || second_is_real) {
+        const int b = w[i].b;
+        t.cur[b] = w[i].cur;
+        t.hstep[b] = w[i].h;
+        t.n_trans[b] = w[i].nt;
+        t.n_reset[b] = w[i].nr;
+        if (reward_sum) reward_sum[b] = w[i].sum;
+        if (last_obs) last_obs[b] = w[i].cur;
+      }
+    }
   }
 }
 
@@ -1634,6 +1701,193 @@ k_dp_regu(DpTables t) {
   }
 }
 
+// K2W: K2U with ONE WAVEFRONT per instance (lane t owns states t, t + 64, ...: up to 7 per lane, 448 states).  K2U's
+// sweep ends in a workgroup barrier among the four wavefronts of an instance (SQ counters: 43 % of the wave cycles parked)
+// and repeats its per-sweep overhead (reduction, loop, address set-up) in every wavefront.  With the whole instance in one
+// wavefront a sweep needs no barrier at all (LDS executes a wavefront's operations in order: the values lane i wrote in
+// sweep k are what lane j reads in sweep k + 1) and the max|dV| reduction is DPP + one readlane.  What hides latency
+// instead of the other wavefronts is instruction-level parallelism, and the sweep is written for it:
+//   * no `s < S` branch -- a lane's states past the instance's last one have all-zero tables (W, R = +0 -> v = +0, |dV| = 0)
+//     and LDS slots of their own, so the whole sweep is ONE basic block;
+//   * all reads first (the SPT x U gathers and the SPT old values: ~36 ds_read in flight), then the arithmetic, then the
+//     writes -- the compiler cannot know that the two value vectors do not alias, a write between reads would fence them;
+//   * the A accumulation chains of a state advance side by side (successor-major), so consecutive float instructions are
+//     independent (a dependent one issues ~1.7 x later, which nothing covers at two wavefronts per SIMD).
+// The price is registers: SPT (A U + U + A) resident table entries per lane (C3: 6 x 29 = 174 of 253 VGPRs), i.e. two
+// wavefronts per SIMD.  Same arithmetic in the same order per row: bit-equal to K2U, K2R, K2 and the oracle.
+// C3 (4 096 x FrozenLake 20x20): 2.00 ms against K2U's 2.43 ms; 322 VALU wave-instructions per instance-sweep against 419.
+template <int MODE, int A_T, int U_T, int KMAX, int SPT>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_dp_regw(DpTables t) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int b = blockIdx.x;
+  const int64_t soff = t.state_off[b];
+  const int S = (int)(t.state_off[b + 1] - soff);
+  const int64_t row0 = soff * A_T;
+  const int tid = threadIdx.x;
+  constexpr int NT = 64;
+  constexpr int VB_OFF = SPT * NT * 4;
+  constexpr int SENT = 0x7fffffff;
+
+  // LDS pointers (address space 3) of the distinct successors' values in vector A; the other vector is VB_OFF bytes on,
+  // which folds into the instruction's offset field
+  typedef const __attribute__((address_space(3))) float* lds_cf;
+  typedef __attribute__((address_space(3))) float* lds_f;
+  const lds_f vbase = (lds_f)(__attribute__((address_space(3))) unsigned char*)smem;
+  lds_cf vp[SPT][U_T];
+  float W[SPT][A_T][U_T];
+  float Rr[SPT][A_T], Pi[SPT][A_T];
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {
+    const int s = tid + j * NT;
+    int32_t ucol[U_T];
+#pragma unroll
+    for (int u = 0; u < U_T; ++u) ucol[u] = SENT;
+    int32_t ecol[A_T][KMAX];
+    float ecf[A_T][KMAX];
+#pragma unroll
+    for (int a = 0; a < A_T; ++a) {
+      const int64_t r = row0 + (int64_t)s * A_T + a;
+      int64_t lo = 0, hi = 0;
+      if (s < S) { lo = t.csr_ptr[r]; hi = t.csr_ptr[r + 1]; }
+      Rr[j][a] = (s < S) ? t.R[r] : 0.0f;
+      Pi[j][a] = (MODE == DP_PE && s < S) ? t.pi[r] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        const bool in = lo + k < hi;
+        ecol[a][k] = in ? t.csr_col[lo + k] : SENT;
+        const float v = in ? t.csr_val[lo + k] : 0.0f;
+        ecf[a][k] = (MODE == DP_PE) ? __fmul_rn(t.gamma, v) : v;
+        // sorted insertion without duplicates: the larger of (carried, slot) moves on
+        int32_t c = ecol[a][k];
+#pragma unroll
+        for (int u = 0; u < U_T; ++u) {
+          const int32_t cur = ucol[u];
+          const bool dup = c == cur;
+          const bool less = c < cur;
+          ucol[u] = less ? c : cur;
+          c = dup ? SENT : (less ? cur : c);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U_T; ++u) {
+      vp[j][u] = vbase + (ucol[u] == SENT ? 0 : ucol[u]);
+#pragma unroll
+      for (int a = 0; a < A_T; ++a) {
+        float w = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) w = (ecol[a][k] == ucol[u] && ucol[u] != SENT) ? ecf[a][k] : w;
+        W[j][a][u] = w;
+      }
+    }
+  }
+  for (int i = tid; i < 2 * SPT * NT; i += NT) reinterpret_cast<float*>(smem)[i] = 0.0f;
+  __builtin_amdgcn_wave_barrier();
+
+  const bool track_abs = t.max_abs > 0.0;
+  int64_t it = 0;
+  int status = -5;
+  auto gather = [&](auto rd_tag, int j, float (&v)[U_T]) {
+    constexpr int RD = decltype(rd_tag)::value;
+#pragma unroll
+    for (int u = 0; u < U_T; ++u) v[u] = vp[j][u][RD / 4];
+  };
+  auto backup_all = [&](int j, const float (&v)[U_T], float (&q)[A_T]) {
+    // the A accumulation chains advance side by side (successor-major): consecutive instructions are independent, which
+    // matters at two wavefronts per SIMD (a dependent float32 instruction issues ~1.7 x later than an independent one)
+    float acc[A_T];
+#pragma unroll
+    for (int a = 0; a < A_T; ++a) acc[a] = 0.0f;
+#pragma unroll
+    for (int u = 0; u < U_T; ++u) {
+      float p[A_T];
+#pragma unroll
+      for (int a = 0; a < A_T; ++a) p[a] = __fmul_rn(W[j][a][u], v[u]);
+#pragma unroll
+      for (int a = 0; a < A_T; ++a) acc[a] = __fadd_rn(acc[a], p[a]);
+    }
+#pragma unroll
+    for (int a = 0; a < A_T; ++a) acc[a] = (MODE == DP_VI) ? __fmul_rn(t.gamma, acc[a]) : acc[a];
+#pragma unroll
+    for (int a = 0; a < A_T; ++a) q[a] = __fadd_rn(Rr[j][a], acc[a]);
+  };
+  auto sweep = [&](auto rd_tag) -> int {
+    constexpr int RD = decltype(rd_tag)::value, WR = VB_OFF - RD;
+    ++it;
+    float dmax = 0.0f, vabs = 0.0f;
+    // No `s < S` branch: a lane's states past the instance's last one have all-zero tables (W, R = +0 -> v = +0, |dV| = 0)
+    // and their own LDS slots, so the sweep is ONE basic block.  All reads come before the first write (the compiler
+    // cannot know that the two value vectors do not alias), so the gathers of all SPT states are in flight together.
+    float vnew[SPT], vold[SPT], vg[SPT][U_T];
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+      gather(rd_tag, j, vg[j]);
+      vold[j] = vbase[RD / 4 + tid + j * NT];
+    }
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+      float q[A_T];
+      backup_all(j, vg[j], q);
+      float v = 0.0f;
+      if (MODE == DP_VI) {  // values are never NaN: bare max instructions
+        if constexpr (A_T == 2) v = fmax_nn(q[0], q[1]);
+        else if constexpr (A_T == 3) v = fmax3_nn(q[0], q[1], q[2]);
+        else v = fmax_nn(fmax3_nn(q[0], q[1], q[2]), q[A_T - 1]);
+      } else {
+#pragma unroll
+        for (int a = 0; a < A_T; ++a) {
+          const float qp = __fmul_rn(q[a], Pi[j][a]);
+          v = (a == 0) ? qp : __fadd_rn(v, qp);
+        }
+      }
+      vnew[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+      vbase[WR / 4 + tid + j * NT] = vnew[j];
+      dmax = fmax_abs_nn(dmax, vold[j] - vnew[j]);
+      if (track_abs) vabs = fmax_abs_nn(vabs, vnew[j]);
+    }
+    // lane 63 holds the wave's maximum; every lane needs it (the loop condition is uniform)
+    const float diff = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max_lane63_nn(dmax)), 63));
+    float vmax = 0.0f;
+    if (track_abs) vmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max_lane63_nn(vabs)), 63));
+    __builtin_amdgcn_wave_barrier();   // no instruction: keeps this sweep's LDS writes ahead of the next sweep's reads
+    if (track_abs && (double)vmax > t.max_abs) return 2;
+    if ((double)diff < t.eps) return 1;
+    return 0;
+  };
+  using Even = std::integral_constant<int, 0>;
+  using Odd = std::integral_constant<int, VB_OFF>;
+  int newest = 0;
+  while (it < t.max_sweeps) {
+    int rc = sweep(Even{});
+    newest = VB_OFF;
+    if (rc == 0 && it < t.max_sweeps) {
+      rc = sweep(Odd{});
+      newest = 0;
+    }
+    if (rc) { status = (rc == 1) ? 0 : -7; break; }
+  }
+  if (tid == 0) {
+    t.status[b] = status;
+    if (t.sweeps) t.sweeps[b] = it;
+  }
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {
+    const int s = tid + j * NT;
+    if (s < S) {
+      t.V[soff + s] = vbase[newest / 4 + s];
+      float q[A_T], v[U_T];
+      if (newest == VB_OFF) gather(Even{}, j, v); else gather(Odd{}, j, v);
+      backup_all(j, v, q);
+#pragma unroll
+      for (int a = 0; a < A_T; ++a) t.Q[row0 + (int64_t)s * A_T + a] = q[a];
+    }
+  }
+}
+
 // K3: Gauss-Seidel sweeps (numba paths of the reference), one wavefront per unit, V in LDS, states in
 // order.  Lane a < A backs up action a of the current state; later states see the updated V.
 template <int MODE, bool DIAM>
@@ -2067,9 +2321,13 @@ __global__ void __launch_bounds__(256) k_build_ell(int64_t n_rows, int K, const 
   }
 }
 
+// `new_of` (or null): the rows were stored in a locality order of the states (relabel_states in cmdp.hip) -- row n is the
+// row of the original state that was relabelled n, its entries in their ORIGINAL (ascending original column) order with
+// the column replaced by the successor's new label.  Every sum therefore adds the same terms in the same order and the
+// result is bit-equal to the unrelabelled kernel; only the target's label has to be translated.
 template <int NW, int A, int K>
 __global__ void __launch_bounds__(NW * 64) k_diam_lanes_ell(DpTables t, DiamLanesArgs g, const int32_t* __restrict__ ecol,
-                                                           const float* __restrict__ eval_) {
+                                                           const float* __restrict__ eval_, const int32_t* __restrict__ new_of) {
   constexpr int AK = A * K, U = 64 / AK;
   static_assert(U >= 1, "A*K must not exceed 64");
   __shared__ float red_d[2][NW][64];
@@ -2084,6 +2342,7 @@ __global__ void __launch_bounds__(NW * 64) k_diam_lanes_ell(DpTables t, DiamLane
   const float* ev = eval_ + soff * AK;
   const int target = g.grp_target0[grp] + lane;
   const bool active = lane < g.grp_count[grp];
+  const int target_row = (new_of && active) ? new_of[soff + target] : target;  // where the target's row and value live
   float* Vold = g.vbuf + g.grp_voff[grp];
   float* Vnew = Vold + (int64_t)S * 64;
   for (int64_t i = threadIdx.x; i < (int64_t)S * 128; i += NW * 64) Vold[i] = 0.0f;
@@ -2139,7 +2398,7 @@ __global__ void __launch_bounds__(NW * 64) k_diam_lanes_ell(DpTables t, DiamLane
               const float q = __fadd_rn(-1.0f, __fmul_rn(t.gamma, acc));
               v = (a == 0) ? q : fmaxf(v, q);
             }
-            if (s == target) v = __fadd_rn(0.0f, __fmul_rn(t.gamma, __fadd_rn(0.0f, __fmul_rn(1.0f, vo[u]))));
+            if (s == target_row) v = __fadd_rn(0.0f, __fmul_rn(t.gamma, __fadd_rn(0.0f, __fmul_rn(1.0f, vo[u]))));
             Vnew[(int64_t)s * 64 + lane] = v;
             dmax = fmaxf(dmax, fabsf(vo[u] - v));
             vmin = fminf(vmin, v);

@@ -178,7 +178,7 @@ int cmdp_synchronize(cmdp_t* h);
 /* Measurements taken inside the library (for bench.py's roofline objects; no reference counterpart).
    CMDP_STAT_DP_KERNEL_MS: HIP-event time, on the handle's stream, of the sweep kernel of the last
    cmdp_vi_discounted / cmdp_pe_discounted (kernel only: no upload, no result copy).
-   CMDP_STAT_DP_KERNEL: which kernel that was -- 1 K2 (workgroup, CSR in LDS/HBM), 2 K2R, 5 K2U, 6 K3 (Gauss-Seidel). */
+   CMDP_STAT_DP_KERNEL: which kernel that was -- 1 K2 (workgroup, CSR in LDS/HBM), 2 K2R, 5 K2U, 7 K2W, 6 K3 (Gauss-Seidel). */
 enum { CMDP_STAT_DP_KERNEL_MS = 1, CMDP_STAT_DP_KERNEL = 2 };
 int cmdp_stat(cmdp_t* h, int which, double* out);
 /* Latency floor of the LDS-resident rollout kernels, measured on the current device: one wavefront per CU follows
@@ -202,13 +202,19 @@ int cmdp_calibrate(int what, int64_t n_steps, double* ns_per_step);
    instead of the fixed-width-row variant; 6 = its tiled form K5T, which gathers the value rows of a cluster of states
    into LDS first: half the HBM traffic, same bits, not faster -- on request only), 5 = the distinct-successor form K2U of the register-resident kernel (taken
    by default when the A rows of a state share their successors: <= 8 distinct columns per state, rows in ascending
-   column order; 2 keeps the per-row form K2R).  All forms return identical bits.
+   column order; 2 keeps the per-row form K2R), 7 = K2W, K2U's tables with ONE wavefront per instance and no barrier per
+   sweep (taken by default for 257..448 states, <= 5 distinct successors per state, <= 4 non-zeros per row; 5 keeps K2U).
+   All forms return identical bits.
    CMDP_OPT_CHAIN_EXACT_ORDER (cmdp_average_reward / cmdp_qlearning_average_reward): 1 = every float64 sum of the GTH
    elimination in the reference's index order (bit-equal to cmdp_gth and the oracle, one serial chain per sum);
    0 (default) = wave butterfly sums, deterministic, within ~1e-15 relative of the former, several times faster on
    chains with hundreds of states.
    CMDP_OPT_DIAMETER_WORKSPACE_MB: HBM the value arrays of K5S may take per launch (default 24576; 512 bytes per
    state per group of 64 targets; more groups in flight = more of the GPU busy).
+   CMDP_OPT_DIAMETER_RELABEL_MIN_STATES: K5S stores the rows of instances with at least this many states (default 8192)
+   in a locality order of the states (breadth-first clusters of the transition graph) so that the value rows a chunk of
+   states gathers were fetched by the chunks before it; row contents and entry order are unchanged, results bit-equal.
+   A value above every instance's size keeps the caller's state order.
    CMDP_OPT_MIXING_PATH (cmdp_mixing_time): 0 = automatic (matrix powers when an instance has more than 1024 states or
    a float64 row does not fit LDS), 1 = matrix powers, 2 = one sparse step at a time with the row in LDS.
    CMDP_OPT_LDS_GROUPS_PER_CU: 1 or 2 workgroups of the fused-walker kernel K1L per CU (default: whichever needs
@@ -216,7 +222,8 @@ int cmdp_calibrate(int what, int64_t n_steps, double* ns_per_step);
    balanced number of instances per workgroup for that many groups (the pipeline kernel K1P always runs one workgroup
    per CU); CMDP_ERR_INVALID when the batch is not eligible for the LDS-resident kernels or two groups do not fit. */
 enum { CMDP_OPT_ROLLOUT_KERNEL = 1, CMDP_OPT_DP_KERNEL = 2, CMDP_OPT_LDS_GROUPS_PER_CU = 3,
-       CMDP_OPT_DIAMETER_WORKSPACE_MB = 4, CMDP_OPT_CHAIN_EXACT_ORDER = 5, CMDP_OPT_MIXING_PATH = 6 };
+       CMDP_OPT_DIAMETER_WORKSPACE_MB = 4, CMDP_OPT_CHAIN_EXACT_ORDER = 5, CMDP_OPT_MIXING_PATH = 6,
+       CMDP_OPT_DIAMETER_RELABEL_MIN_STATES = 7 };
 int cmdp_set_option(cmdp_t* h, int option, int64_t value);
 
 /* What the LDS-resident random-policy rollout of this handle is (introspection for benchmarks and tests; no

@@ -56,10 +56,10 @@ def test_c3_full_size_4096_frozenlake20_vi(need_gpu):
     B = 4096
     fl = frozenlake_dp_tables(np.arange(B), 20, workers=min(16, os.cpu_count() or 1), context="spawn")
     dp = BatchedMDP(tables=fl, with_env=False)
-    dp.set_dp_kernel(L.DP_REGISTER_DISTINCT)   # K2U, what the automatic choice takes for this batch
+    dp.set_dp_kernel(L.DP_REGISTER_DISTINCT)   # K2U (the automatic choice for this batch is its one-wavefront form K2W)
     Q, V, sw = dp.value_iteration(0.99, 1e-6)
     # (i) the distinct-successor, per-row register-resident and LDS/HBM workgroup kernels: identical bits and sweep counts
-    for which in (L.DP_REGISTER, L.DP_WORKGROUP, L.DP_AUTO):
+    for which in (L.DP_REGISTER, L.DP_WORKGROUP, L.DP_REGISTER_WAVEFRONT, L.DP_AUTO):
         dp.set_dp_kernel(which)
         Q2, V2, sw2 = dp.value_iteration(0.99, 1e-6)
         np.testing.assert_array_equal(V, V2)

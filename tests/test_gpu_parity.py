@@ -331,28 +331,36 @@ def test_vi_frozenlake20_vs_reference(need_gpu):
 
 
 def test_register_resident_sweeps_equal_workgroup_kernel_and_oracle(need_gpu):
-    """K2R (CSR in registers), K2U (its distinct-successor form) vs K2 (CSR in LDS/HBM) vs the oracle on A = 2, 3, 4,
-    ragged batches, VI and PE."""
+    """K2R (CSR in registers), K2U (its distinct-successor form), K2W (one wavefront per instance) vs K2 (CSR in LDS/HBM)
+    vs the oracle on A = 2, 3, 4, ragged batches, VI and PE."""
     batches = [
         [make_model("DeepSeaContinuous", seed=s, size=sz, p_rand=0.2) for s, sz in ((0, 9), (1, 14), (2, 23))],
         [make_model("MiniGridEmptyContinuous", seed=s, size=sz, p_rand=0.1, p_lazy=0.05) for s, sz in ((0, 4), (1, 7), (2, 9))],
         [make_model("FrozenLakeContinuous", seed=s, size=sz, p_frozen=0.9, p_rand=0.1) for s, sz in ((0, 6), (1, 17), (2, 30))],
         [make_model("MiniGridRoomsContinuous", seed=s, room_size=3, n_rooms=4, p_rand=0.3, p_lazy=0.1) for s in (0, 1)],
+        # <= 448 states: what K2W takes (5, 6 and 7 states per lane; A = 4, 3, 2)
+        [make_model("FrozenLakeContinuous", seed=s, size=sz, p_frozen=0.9, p_rand=0.1) for s, sz in ((3, 5), (4, 18), (5, 16))],
+        [make_model("FrozenLakeContinuous", seed=s, size=sz, p_frozen=0.9, p_rand=0.1) for s, sz in ((6, 20), (7, 12))],
+        [make_model("FrozenLakeContinuous", seed=s, size=sz, p_frozen=0.95, p_rand=0.1) for s, sz in ((8, 21), (9, 20), (10, 3))],
+        [make_model("MiniGridEmptyContinuous", seed=s, size=sz, p_rand=0.1) for s, sz in ((3, 10), (4, 5))],
+        [make_model("DeepSeaContinuous", seed=s, size=sz, p_rand=0.2) for s, sz in ((3, 28), (4, 11))],
     ]
+    n_k2w = 0
     for models in batches:
         A = models[0].n_actions
         dp = BatchedMDP(models, with_env=False)
         outs = {}
         n_distinct = 0
-        for which in (L.DP_WORKGROUP, L.DP_REGISTER, L.DP_REGISTER_DISTINCT):
+        for which in (L.DP_WORKGROUP, L.DP_REGISTER, L.DP_REGISTER_DISTINCT, L.DP_REGISTER_WAVEFRONT):
             dp.set_dp_kernel(which)
             pis = [np.random.RandomState(5 + i).dirichlet(np.ones(A), m.n_states).astype(np.float32) for i, m in enumerate(models)]
             try:
                 outs[which] = (dp.value_iteration(0.99, 1e-5, L.SCHEME_JACOBI), dp.policy_evaluation(pis, 0.95, 1e-6, L.SCHEME_JACOBI))
             except L.CmdpError as e:  # K2U exists for <= 8 distinct successors per state; it must say so otherwise
-                assert which == L.DP_REGISTER_DISTINCT and e.code == L.ERR_UNSUPPORTED
+                assert which in (L.DP_REGISTER_DISTINCT, L.DP_REGISTER_WAVEFRONT) and e.code == L.ERR_UNSUPPORTED
                 continue
             n_distinct += which == L.DP_REGISTER_DISTINCT
+            n_k2w += which == L.DP_REGISTER_WAVEFRONT
         for which in outs:
             for x, y in zip(outs[L.DP_WORKGROUP], outs[which]):
                 for u, v in zip(x, y):
@@ -369,6 +377,7 @@ def test_register_resident_sweeps_equal_workgroup_kernel_and_oracle(need_gpu):
             assert swp[i] == oit
         dp.close()
     assert n_k2u >= 2  # the distinct-successor kernel really ran for some of the batches
+    assert n_k2w >= 4  # and so did the one-wavefront kernel (5, 6 and 7 states per lane)
 
 
 def test_episodic_dp_vs_reference(need_gpu):
@@ -639,6 +648,12 @@ def test_diameter_lanes_kernel_equals_workgroup_kernel_and_oracle(need_gpu):
         diam1, per1 = dp.diameter(1e-3, L.SCHEME_JACOBI)
         np.testing.assert_array_equal(per1, per0)
         np.testing.assert_array_equal(diam1, diam0)
+        dp.set_option(L.OPT_DIAMETER_RELABEL_MIN_STATES, 1)  # rows stored in the locality order of the states (C5's default)
+        diam2, per2 = dp.diameter(1e-3, L.SCHEME_JACOBI)
+        np.testing.assert_array_equal(per2, per0)
+        np.testing.assert_array_equal(diam2, diam0)
+        np.testing.assert_array_equal(dp.diameter_range(3, len(per0) - 2), per0[3:-2])  # a target range (the multi-GPU split)
+        dp.set_option(L.OPT_DIAMETER_RELABEL_MIN_STATES, 1 << 40)
         dp.set_option(L.OPT_DP_KERNEL, 4)  # generic CSR walker instead of the fixed-width-row variant
         np.testing.assert_array_equal(dp.diameter(1e-3, L.SCHEME_JACOBI)[1], per0)
         dp.set_option(L.OPT_DP_KERNEL, 6)  # K5T: value rows of a cluster of states gathered into an LDS tile first (C5's kernel)
