@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (CPU rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: ranks share the visible GPUs (device = local_rank %% n_devices)")
     ap.add_argument("--lds-groups", type=int, default=0, help="K1L workgroups per CU (0: library default; needs CMDP_K1L_PIPE=0)")
-    ap.add_argument("--rollout-kernel", type=int, default=0, help="0 auto, 1 HBM tables, 2 LDS-resident")
+    ap.add_argument("--rollout-kernel", type=int, default=0, help="0 auto, 1 HBM tables, 2 LDS-resident K1L/K1P, 4 shared-table K1T")
     ap.add_argument("--layout", default="csr", choices=["csr", "dense"],
                     help="layout of the HEADLINE leg: csr (default, fastest) or dense (then --launch-steps applies to K1D)")
     args = ap.parse_args()
@@ -294,9 +294,17 @@ def main():
         # the latency of the dependent LDS read chain of one transition.  The chain latency is measured in this run.
         ns_read, ns_chain = C.c_double(), C.c_double()
         L.check(lib.cmdp_calibrate(L.CALIB_LDS_READ, 200000, C.byref(ns_read)))
-        L.check(lib.cmdp_calibrate(L.CALIB_LDS_CHAIN, 200000, C.byref(ns_chain)))
-        min_footprint = 2 * S * A + S * A  # uint16 successor words + 8-bit visit-count deltas: what a chain needs in LDS
-        chains_per_cu = LDS_BYTES // min_footprint
+        shared_table = plan.get("kernel") == "k_rollout_tmpl"   # K1T's chain reads the word pair and the swap bit
+        L.check(lib.cmdp_calibrate(L.CALIB_LDS_CHAIN_SHARED if shared_table else L.CALIB_LDS_CHAIN, 200000, C.byref(ns_chain)))
+        if shared_table:
+            # K1T: ONE uint16 successor table per CU; a chain needs its 8-bit visit-count deltas and one swap bit per state
+            min_footprint = S * A + (S + 7) // 8
+            chains_per_cu = (LDS_BYTES - 2 * S * A) // min_footprint
+            footprint_txt = "count deltas + swap bits per instance beside one shared %d-B table" % (2 * S * A)
+        else:
+            min_footprint = 2 * S * A + S * A  # uint16 successor words + 8-bit visit-count deltas: what a chain needs in LDS
+            chains_per_cu = LDS_BYTES // min_footprint
+            footprint_txt = "tables+count deltas per instance"
         peak = N_CUS * chains_per_cu / (ns_chain.value * 1e-9)  # transitions/s with every CU's LDS full of chains
         hv = hbm_view(8 + 8 * 1 + 28, "SURVEY 8(d) CSR figure (8 + 8*nnz + 28 = 44 B/transition); the tables are LDS-resident, so "
                       "these bytes never cross HBM -- reported as an equivalent rate, NOT a roofline fraction",
@@ -306,8 +314,8 @@ def main():
             "kernel": lds_kernel if args.rollout_kernel != 1 else "k_rollout<0,false>",
             "achieved": kernel_rate / 1e9, "peak": peak / 1e9, "unit": "G transitions/s (one dependent LDS read each)",
             "frac": kernel_rate / peak,
-            "model": "peak = %d CUs x floor(160 KiB / %d B of tables+count deltas per instance) = %d resident chains per CU / "
-                     "calibrated dependent-read chain latency" % (N_CUS, min_footprint, chains_per_cu),
+            "model": "peak = %d CUs x floor(160 KiB / %d B of %s) = %d resident chains per CU / "
+                     "calibrated dependent-read chain latency" % (N_CUS, min_footprint, footprint_txt, chains_per_cu),
             "calibrated_chain_ns": ns_chain.value, "calibrated_bare_lds_read_ns": ns_read.value,
             "resident_chains_per_cu": plan.get("instances_per_workgroup"), "lds_plan": plan,
             "traffic": hv["traffic"], "hbm": hv,

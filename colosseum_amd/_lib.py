@@ -24,11 +24,12 @@ OPT_MIXING_PATH = 6
 OPT_DIAMETER_RELABEL_MIN_STATES = 7
 STAT_DP_KERNEL_MS, STAT_DP_KERNEL = 1, 2
 NOISE_NONE, NOISE_GAUSSIAN, NOISE_GAUSSIAN_CORRELATED, NOISE_STUDENT_T, NOISE_STUDENT_T_CORRELATED = 0, 1, 2, 3, 4
-CALIB_LDS_READ, CALIB_LDS_CHAIN = 0, 1
+CALIB_LDS_READ, CALIB_LDS_CHAIN, CALIB_LDS_CHAIN_SHARED = 0, 1, 2
 DP_AUTO, DP_WORKGROUP, DP_REGISTER = 0, 1, 2
 DP_REGISTER_DISTINCT = 5  # K2U: register-resident, gathers deduplicated per state
 DP_REGISTER_WAVEFRONT = 7  # K2W: K2U's tables with one wavefront per instance (<= 448 states, <= 5 distinct successors)
 ROLLOUT_AUTO, ROLLOUT_GLOBAL, ROLLOUT_LDS, ROLLOUT_LDS_STOCHASTIC = 0, 1, 2, 3
+ROLLOUT_LDS_TEMPLATE = 4  # K1T: K1P with one successor table per workgroup (batches of action-permuted copies of one MDP)
 
 EXPORTS = [
     "cmdp_version", "cmdp_build_id", "cmdp_last_error", "cmdp_device_count", "cmdp_set_device", "cmdp_create", "cmdp_destroy",

@@ -21,6 +21,7 @@
 #include "cmdp_kernels.h"
 #include "cmdp_tracker.h"
 #include "cmdp_k1s.h"
+#include "cmdp_k1t.h"
 #include "cmdp_agent.h"
 #include "cmdp_chain.h"
 
@@ -144,6 +145,12 @@ struct cmdp {
   int rollout_kernel = 0;  // CMDP_OPT_ROLLOUT_KERNEL
   LdsPlan lds_plan{};
   size_t lds_bytes = 0;
+  bool tmpl_auto = false;
+  bool tmpl_ok = false;      // K1T: one shared successor table per workgroup + per-instance action-swap bits
+  TmplPlan tmpl_plan{};
+  size_t tmpl_lds = 0;
+  DevBuf<uint16_t> d_tmpl_words;
+  DevBuf<uint8_t> d_swap_bits;
   DevBuf<float> d_gp_q, d_gp_p;  // cmdp_greedy_policy_episodic workspace
   // K5S workspace (large-instance diameter)
   DevBuf<float> d_dl_v, d_ell_val;
@@ -639,6 +646,71 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
           for (int64_t r = 0; r < R; ++r)
             next16[(size_t)r] = (uint16_t)((next16[(size_t)r] * A * (p.pipe ? 2 : 1)) | (codes[(size_t)r] << p.code_shift));
         p.n_codes = (int)vals.size();
+        // K1T (cmdp_k1t.h): when every instance's packed words are, state by state, instance 0's words or their swap
+        // (A = 2; seeds of a family whose structure does not depend on the seed only permute the actions), the workgroup
+        // keeps ONE table and a swap bit per state and instance: 2-3 x the instances per CU.
+        static const int k1t_env = std::getenv("CMDP_K1T") ? std::atoi(std::getenv("CMDP_K1T")) : -1;   // tuning aid: 0 off, 1 on
+        if (best_cap >= 8 && p.pipe && A == 2 && k1t_env != 0) {
+          const int S = max_S, rws = S * 2;
+          TmplPlan q{};
+          q.rows = rws;
+          q.tmpl_bytes = (rws * 2 + 15) & ~15;
+          q.mask_bytes = ((S + 7) / 8 + 3) & ~3;
+          q.off_cnt = q.mask_bytes;
+          q.off_ovf = q.off_cnt + ((rws + 4 + 3) & ~3);
+          q.slot_bytes = q.off_ovf + ((2 * K1T_OVF + 3) & ~3);
+          if (((q.slot_bytes / 4) & 1) == 0) q.slot_bytes += 4;   // odd dword stride: the lanes' slots start on different banks
+          q.n_codes = p.n_codes;
+          q.code_shift = p.code_shift;
+          if (const char* de = std::getenv("CMDP_K1T_DEBUG")) q.debug = std::atoi(de);   // timing experiments: stages switched off
+          std::vector<uint8_t> bits((size_t)B * q.mask_bytes, 0);
+          bool same = true;
+          const uint16_t* T = next16.data();
+          for (int b = 0; same && b < B; ++b) {
+            const uint16_t* W = next16.data() + (size_t)b * rws;
+            uint8_t* mb = bits.data() + (size_t)b * q.mask_bytes;
+            for (int s2 = 0; s2 < S; ++s2) {
+              const uint16_t w0 = W[2 * s2], w1 = W[2 * s2 + 1], t0 = T[2 * s2], t1 = T[2 * s2 + 1];
+              if (w0 == t0 && w1 == t1) continue;
+              if (w0 == t1 && w1 == t0) { mb[s2 >> 3] |= (uint8_t)(1u << (s2 & 7)); continue; }
+              same = false;
+              break;
+            }
+          }
+          if (same) {
+            // chunk length and instances per workgroup: fewest rounds x time per transition (K1T's chain carries ~4 more
+            // dependent instructions than K1P's: ~1.3 x its time per transition), as for K1L / K1P above
+            double best_t = -1.0;
+            for (int ch : {64, 32, 16}) {
+              if (force_ch && ch != force_ch) continue;
+              q.ch = ch;
+              const int per = q.slot_bytes + 2 * K1P_ACT_STRIDE(ch) + 2 * K1P_TR_STRIDE(ch);
+              const int cap = std::min<int>(128, (kLdsBudget - K1T_FIXED - q.tmpl_bytes) / per);
+              if (cap < 16) continue;
+              const int64_t wgs = (B + cap - 1) / cap, rounds = (wgs + cus - 1) / cus;
+              const double cost = (double)rounds * 1.3 * 0.62 * (1.0 + 3.5 / ch);
+              if (best_t < 0 || cost < best_t) {
+                best_t = cost;
+                h->tmpl_plan = q;
+                h->tmpl_plan.G = (int)std::min<int64_t>(cap, std::max<int64_t>(1, (B + rounds * cus - 1) / (rounds * cus)));
+                if (const char* ge = std::getenv("CMDP_K1T_G"))   // tests: instances per workgroup (read per handle)
+                  h->tmpl_plan.G = std::max(1, std::min(cap, std::atoi(ge)));
+              }
+            }
+            if (best_t > 0) {
+              std::vector<uint16_t> tw(T, T + rws);
+              tw.resize((size_t)h->tmpl_plan.tmpl_bytes / 2, 0);
+              HIP_TRY(h->d_tmpl_words.upload(tw.data(), tw.size(), st));
+              HIP_TRY(h->d_swap_bits.upload(bits.data(), bits.size(), st));
+              HIP_TRY(hipStreamSynchronize(st));
+              h->tmpl_plan.tmpl = h->d_tmpl_words.p;
+              h->tmpl_plan.swap_bits = h->d_swap_bits.p;
+              h->tmpl_lds = k1t_lds_bytes(h->tmpl_plan, h->tmpl_plan.G);
+              h->tmpl_ok = true;                                   // eligible: CMDP_OPT_ROLLOUT_KERNEL 4 may force it
+              h->tmpl_auto = best_t < best_cost || k1t_env == 1;   // and the automatic choice when it needs fewer rounds x time
+            }
+          }
+        }
         if (best_cap >= 8) {
           // 16 bytes of slack in front of and behind both element arrays: the staging loads are 16-byte wide
           // from the aligned-down address of a group's first element
@@ -653,6 +725,7 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
           h->lds_plan = p;
           h->lds_bytes = k1l_lds_bytes(p, p.G);
           h->lds_ok = true;
+          h->tmpl_plan.rvals = p.rvals;
           HIP_TRY(hipStreamSynchronize(st));  // staging vectors die with this scope
         }
       }
@@ -857,6 +930,16 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
     return fail(CMDP_ERR_UNSUPPORTED, "LDS-resident rollout needs deterministic dynamics, one start state, <= 65535 "
                                       "states, <= 256 distinct rewards, the random policy and no trace");
   // the LDS kernel pays a fixed staging + flush cost per launch: worth it from a few dozen transitions on
+  if (h->rollout_kernel == 4 && !(lds_eligible && h->tmpl_ok))
+    return fail(CMDP_ERR_UNSUPPORTED, "the shared-table rollout K1T needs a batch eligible for K1P with two actions whose instances "
+                                      "are per-state action permutations of the first one, the random policy and no trace");
+  if (lds_eligible && h->tmpl_ok && (h->rollout_kernel == 4 || (h->rollout_kernel == 0 && h->tmpl_auto && n_steps >= 64))) {
+    if (int rc = set_lds(k_rollout_tmpl, h->tmpl_lds)) return rc;
+    hipLaunchKernelGGL(k_rollout_tmpl, dim3(grid_for(h->B, h->tmpl_plan.G)), dim3(K1T_THREADS), h->tmpl_lds, st, t, h->tmpl_plan,
+                       n_steps, d_rsum, d_last);
+    HIP_TRY(hipGetLastError());
+    return CMDP_OK;
+  }
   if (lds_eligible && (h->rollout_kernel == 2 || (h->rollout_kernel == 0 && n_steps >= 64))) {
     const dim3 lgrid(grid_for(h->B, h->lds_plan.G)), lblock(K1L_THREADS);
     if (h->lds_plan.pipe) {
@@ -878,7 +961,14 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
                                       "state counts, <= 16 entries per row and <= 16 distinct successors per state, <= 64 "
                                       "cumulative-probability patterns, deterministic rewards that depend on the successor or on "
                                       "the row alone, and room for four instances in LDS");
-  if (k1s_eligible && (h->rollout_kernel == 3 || (h->rollout_kernel == 0 && n_steps >= 64))) {
+  // K1S runs G instances per CU at a time however large the batch is (LDS capacity), K1's rate grows with the batch (more
+  // wavefronts cover its HBM latency) until bandwidth caps it: measured (tools/exp_k1s_batch.py, profiles/
+  // r02_k1_vs_k1s_batch.json) K1 ~ B x 2.5e5 / (1 + B / 40 000) transitions/s, K1S ~ CUs x G / 480 ns.  FrozenLake-20
+  // (G = 8): K1S up to ~35 000 instances, K1 beyond (131 072 instances: 6.7e9 against 4.5e9).
+  const double k1_rate = (double)h->B * 2.5e5 / (1.0 + (double)h->B / 4.0e4);
+  const double k1s_rate = (double)h->cus * (double)h->k1s.G / 480e-9;
+  const bool k1s_pays = k1_rate < 1.1 * k1s_rate;
+  if (k1s_eligible && (h->rollout_kernel == 3 || (h->rollout_kernel == 0 && n_steps >= 64 && k1s_pays))) {
     if (int rc = set_lds(k_rollout_stoch, h->k1s_bytes)) return rc;
     hipLaunchKernelGGL(k_rollout_stoch, dim3(grid_for(h->B, h->k1s.G)), dim3(K1S_THREADS), h->k1s_bytes, st, t, h->k1s, n_steps,
                        d_rsum, d_last);
@@ -963,7 +1053,7 @@ int cmdp_rollout_async(cmdp_t* h, int policy, int64_t n_steps) {
 
 int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
   if (!h) return fail(CMDP_ERR_INVALID, "null handle");
-  if (option == CMDP_OPT_ROLLOUT_KERNEL && value >= 0 && value <= 3) {
+  if (option == CMDP_OPT_ROLLOUT_KERNEL && value >= 0 && value <= 4) {
     h->rollout_kernel = (int)value;
     return CMDP_OK;
   }
@@ -1008,9 +1098,10 @@ int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
 int cmdp_lds_plan(cmdp_t* h, int32_t plan[4]) {
   if (!h || !plan) return fail(CMDP_ERR_INVALID, "bad argument");
   plan[0] = (h->lds_ok || h->k1s_ok) ? 1 : 0;
-  plan[1] = h->lds_ok ? h->lds_plan.pipe : (h->k1s_ok ? 2 : 0);
-  plan[2] = h->lds_ok ? h->lds_plan.G : (h->k1s_ok ? h->k1s.G : 0);
-  plan[3] = h->lds_ok ? h->lds_plan.ch : (h->k1s_ok ? h->k1s.ch : 0);
+  const bool k1t = h->lds_ok && h->tmpl_ok && (h->rollout_kernel == 4 || (h->rollout_kernel == 0 && h->tmpl_auto));   // what a launch takes
+  plan[1] = k1t ? 3 : (h->lds_ok ? h->lds_plan.pipe : (h->k1s_ok ? 2 : 0));
+  plan[2] = k1t ? h->tmpl_plan.G : (h->lds_ok ? h->lds_plan.G : (h->k1s_ok ? h->k1s.G : 0));
+  plan[3] = k1t ? h->tmpl_plan.ch : (h->lds_ok ? h->lds_plan.ch : (h->k1s_ok ? h->k1s.ch : 0));
   return CMDP_OK;
 }
 
@@ -1040,7 +1131,8 @@ int cmdp_stat(cmdp_t* h, int which, double* out) {
 
 int cmdp_calibrate(int what, int64_t n_steps, double* ns_per_step) {
   if (!ns_per_step || n_steps < 1 || n_steps > 10000000) return fail(CMDP_ERR_INVALID, "bad argument");
-  if (what != CMDP_CALIB_LDS_READ && what != CMDP_CALIB_LDS_CHAIN) return fail(CMDP_ERR_INVALID, "unknown calibration %d", what);
+  if (what != CMDP_CALIB_LDS_READ && what != CMDP_CALIB_LDS_CHAIN && what != CMDP_CALIB_LDS_CHAIN_SHARED)
+    return fail(CMDP_ERR_INVALID, "unknown calibration %d", what);
   int dev = 0, cus = 0;
   HIP_TRY(hipGetDevice(&dev));
   HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -1054,7 +1146,8 @@ int cmdp_calibrate(int what, int64_t n_steps, double* ns_per_step) {
     const int n = rep == 0 ? 1000 : (int)n_steps;
     HIP_TRY(hipEventRecord(e0, nullptr));
     if (what == CMDP_CALIB_LDS_READ) hipLaunchKernelGGL(k_calib_lds_chain<0>, dim3(cus), dim3(64), lds, nullptr, n, 30, sink.p);
-    else hipLaunchKernelGGL(k_calib_lds_chain<1>, dim3(cus), dim3(64), lds, nullptr, n, 30, sink.p);
+    else if (what == CMDP_CALIB_LDS_CHAIN) hipLaunchKernelGGL(k_calib_lds_chain<1>, dim3(cus), dim3(64), lds, nullptr, n, 30, sink.p);
+    else hipLaunchKernelGGL(k_calib_lds_chain<2>, dim3(cus), dim3(64), lds, nullptr, n, 30, sink.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipEventSynchronize(e1));

@@ -2439,6 +2439,8 @@ __global__ void __launch_bounds__(NW * 64) k_diam_lanes_ell(DpTables t, DiamLane
 //   CHAIN = 1: what a deterministic-dynamics transition cannot avoid on its dependency chain -- action bit into the
 //              address, the successor read, the field mask, the in-episode step count and the episode-end select
 //              (K1P's chain stage does exactly this plus the trace store, which is off the chain).
+//   CHAIN = 2: the same for K1T, whose transition reads the state's word pair AND its swap bit (two independent reads)
+//              and selects the word by a bit-field extract.
 template <int CHAIN>
 __global__ void __launch_bounds__(64) k_calib_lds_chain(int steps, int H, int32_t* __restrict__ sink) {
   extern __shared__ unsigned short calib_tab[];
@@ -2454,9 +2456,23 @@ __global__ void __launch_bounds__(64) k_calib_lds_chain(int steps, int H, int32_
   for (int s = 0; s < steps; ++s) {
     if (CHAIN == 0) {
       cur = calib_tab[base + cur] & (kPer - 1);
-    } else {
+    } else if (CHAIN == 1) {
       const int a = (s * 7 + threadIdx.x) & 1;
       const int nxt = calib_tab[base + cur + a] & (kPer - 2);
+      ++h;
+      const bool term = h >= H;
+      cur = term ? 0 : nxt;
+      h = term ? 0 : h;
+    } else {
+      // K1T's chain: the state's two words (one 32-bit read) and the byte with its swap bit (a second, independent read
+      // from the far end of the lane's table), word[a ^ bit] selected by a bit-field extract, the episode-end select.
+      // `cur` is the state's byte offset in the word table (4 s, s < 128: the last 32 entries of the lane's table serve as
+      // the 16 mask bytes)
+      const int a = (s * 7 + threadIdx.x) & 1;
+      const unsigned pair = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(calib_tab + base) + cur);
+      const unsigned mb = reinterpret_cast<const unsigned char*>(calib_tab + base)[960 + (cur >> 5)];
+      const unsigned sh = ((mb >> ((cur >> 2) & 7)) << 4) + (unsigned)(a << 4);
+      const int nxt = (int)(__builtin_amdgcn_ubfe(pair, sh, 16u) & 0x1fcu);   // a multiple of 4 below 512
       ++h;
       const bool term = h >= H;
       cur = term ? 0 : nxt;

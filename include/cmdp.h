@@ -184,8 +184,10 @@ int cmdp_stat(cmdp_t* h, int which, double* out);
 /* Latency floor of the LDS-resident rollout kernels, measured on the current device: one wavefront per CU follows
    per-lane uint16 tables in LDS for n_steps dependent reads.  CMDP_CALIB_LDS_READ: the bare dependent ds_read_u16
    (read, mask, address); CMDP_CALIB_LDS_CHAIN: the minimal dependency chain of one deterministic transition (action
-   bit, successor read, mask, in-episode step, episode-end select).  ns_per_step = launch time / n_steps. */
-enum { CMDP_CALIB_LDS_READ = 0, CMDP_CALIB_LDS_CHAIN = 1 };
+   bit, successor read, mask, in-episode step, episode-end select); CMDP_CALIB_LDS_CHAIN_SHARED: the same for the
+   shared-table kernel K1T (the state's word pair and its swap bit: two independent reads, the word selected by a bit-field
+   extract).  ns_per_step = launch time / n_steps. */
+enum { CMDP_CALIB_LDS_READ = 0, CMDP_CALIB_LDS_CHAIN = 1, CMDP_CALIB_LDS_CHAIN_SHARED = 2 };
 int cmdp_calibrate(int what, int64_t n_steps, double* ns_per_step);
 
 /* Tuning knobs (never change results).  CMDP_OPT_ROLLOUT_KERNEL: 0 = automatic, 1 = lane-per-instance
@@ -194,7 +196,12 @@ int cmdp_calibrate(int what, int64_t n_steps, double* ns_per_step);
    values, at least 8 instances per 160 KiB of LDS), 3 = LDS-resident kernel for STOCHASTIC dynamics K1S (Philox mode;
    the sampler tables compressed into shared cumulative-probability patterns and per-state successor sets: <= 16
    entries per row, <= 16 distinct successors per state, <= 64 patterns, rewards a function of the successor or of
-   the row, at least 4 instances per 160 KiB of LDS).
+   the row, at least 4 instances per 160 KiB of LDS), 4 = the shared-table pipeline K1T (a batch eligible for 2 with two
+   actions whose instances are, state by state, the first instance's rows or their swap -- the seeds of a family whose
+   structure does not depend on the seed: the workgroup keeps one successor table and a swap bit per state and
+   instance, 128 instances per CU at config C2 instead of 52; taken automatically when eligible, 2 keeps K1L / K1P).
+   For 3: the automatic choice takes it while the batch is small enough that
+   the HBM-table kernel's rate, which grows with the batch, stays below it -- FrozenLake 20x20: up to ~35 000 instances).
    CMDP_OPT_DP_KERNEL (Jacobi sweeps): 0 = automatic, 1 = workgroup kernel with the CSR in LDS or HBM,
    2 = register-resident CSR kernel (CMDP_ERR_UNSUPPORTED when no compiled shape fits: A in 2..4, <= 8
    non-zeros per row, <= 1024 states), 3 = (cmdp_diameter only) the 64-targets-per-workgroup kernel K5S that is
@@ -229,7 +236,7 @@ int cmdp_set_option(cmdp_t* h, int option, int64_t value);
 /* What the LDS-resident random-policy rollout of this handle is (introspection for benchmarks and tests; no
    reference counterpart): plan[0] = 1 if the batch is eligible for it, plan[1] = 1 for the wavefront-pipeline kernel
    K1P (k_rollout_pipe), 0 for the fused walker K1L (k_rollout_lds), 2 for the stochastic-dynamics kernel K1S
-   (k_rollout_stoch), plan[2] = instances per workgroup,
+   (k_rollout_stoch), 3 for the shared-table pipeline K1T (k_rollout_tmpl), plan[2] = instances per workgroup,
    plan[3] = transitions per chunk.  The kernel flavour and chunk length are chosen when the handle is created (fewest
    rounds of workgroups x measured time per transition). */
 int cmdp_lds_plan(cmdp_t* h, int32_t plan[4]);

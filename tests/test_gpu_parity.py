@@ -165,11 +165,16 @@ def test_lds_resident_rollout_equals_global_kernel_and_oracle(need_gpu):
     instances-per-workgroup), visits / last observation / reward sums bit-equal."""
     from colosseum_amd.mdp.fast_batch import deepsea_episodic_tables
 
-    for size, n2 in ((12, 70_000), (5, 9_000)):   # horizon 5 < 8: several episode ends inside one group of 8 transitions
-        _check_lds_rollout(75, size, 50, n2)
+    # horizon 5 < 8: several episode ends inside one group of 8 transitions; horizon 3: a row is arrived at every twelfth
+    # transition, so K1T's 8-bit deltas wrap before its flush period is over (its overflow list is used)
+    for size, n2 in ((12, 70_000), (5, 9_000), (3, 9_000)):
+        _check_lds_rollout(75, size, 50, n2, expect_k1t=True, k1t_g=50)   # K1T: groups of 50 and 25
+    # K1T with both halves of a workgroup in use (100 instances per group, the last group holds 61: half 1 empty)
+    _check_lds_rollout(261, 9, 50, 8_000, expect_k1t=True, k1t_g=100)
 
 
-def _check_lds_rollout(B, size, n1, n2, tables=None, models=None):
+def _check_lds_rollout(B, size, n1, n2, tables=None, models=None, expect_k1t=None, k1t_g=128):
+    """expect_k1t: True = the shared-table kernel must take the batch, False = it must refuse it, None = either."""
     import os
 
     from colosseum_amd.mdp.fast_batch import deepsea_episodic_tables
@@ -184,31 +189,48 @@ def _check_lds_rollout(B, size, n1, n2, tables=None, models=None):
     res = {}
     # the LDS-resident rollout exists as the fused walker (K1L) and as the wavefront pipeline (K1P); CMDP_K1L_PIPE
     # (read when the handle is created) forces one of them
-    for which, pipe in ((L.ROLLOUT_GLOBAL, None), (L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1")):
+    # ... and, for two-action batches whose instances are action-permuted copies of one MDP, as the shared-table
+    # pipeline K1T (CMDP_K1T_G: instances per workgroup, so that small batches exercise both halves and ragged groups)
+    for which, pipe in ((L.ROLLOUT_GLOBAL, None), (L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1"), (L.ROLLOUT_LDS_TEMPLATE, "1")):
         saved = os.environ.pop("CMDP_K1L_PIPE", None)
         if pipe is not None:
             os.environ["CMDP_K1L_PIPE"] = pipe
+        if which == L.ROLLOUT_LDS_TEMPLATE:
+            os.environ["CMDP_K1T_G"] = str(k1t_g)
         try:
             env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX, philox_keys=keys)
         finally:
             os.environ.pop("CMDP_K1L_PIPE", None)
+            os.environ.pop("CMDP_K1T_G", None)
             if saved is not None:
                 os.environ["CMDP_K1L_PIPE"] = saved
-        if pipe is not None:
+        env.set_rollout_kernel(which)
+        if which == L.ROLLOUT_LDS:
             plan = env.lds_plan()
             assert plan["eligible"] and plan["kernel"] == ("k_rollout_pipe" if pipe == "1" else "k_rollout_lds"), plan
-        env.set_rollout_kernel(which)
         env.reset()
-        a = env.rollout(n1)  # odd transition count: the next launch starts mid Philox block and mid episode
+        try:
+            a = env.rollout(n1)  # odd transition count: the next launch starts mid Philox block and mid episode
+        except L.CmdpError as e:  # K1T exists for A = 2 and action-permuted copies of one MDP; it must say so otherwise
+            assert which == L.ROLLOUT_LDS_TEMPLATE and e.code == L.ERR_UNSUPPORTED and not expect_k1t, e
+            env.close()
+            continue
+        if which == L.ROLLOUT_LDS_TEMPLATE:
+            plan = env.lds_plan()
+            assert expect_k1t is not False and plan["kernel"] == "k_rollout_tmpl" and plan["instances_per_workgroup"] == min(k1t_g, 128), plan
         b = env.rollout(n2)
         c = env.rollout(3)   # shorter than one Philox block / one group of 8
         vs, vsa = env.visits()
         res[(which, pipe)] = (a["last_obs"], a["reward_sum"], b["last_obs"], b["reward_sum"], c["last_obs"],
                               c["reward_sum"], vs, vsa, env.state())
         env.close()
+    if expect_k1t:
+        assert (L.ROLLOUT_LDS_TEMPLATE, "1") in res
     g = res[(L.ROLLOUT_GLOBAL, None)]
-    for pipe in ("0", "1"):
-        l = res[(L.ROLLOUT_LDS, pipe)]
+    for key in ((L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1"), (L.ROLLOUT_LDS_TEMPLATE, "1")):
+        if key not in res:
+            continue
+        l = res[key]
         for x, y in zip(g[:8], l[:8]):
             np.testing.assert_array_equal(x, y)
         for x, y in zip(g[8], l[8]):
@@ -226,10 +248,10 @@ def test_lds_rollout_continuous_and_other_families(need_gpu):
     """K1L / K1P on continuous (no horizon: the per-lane flavour of the walker) and episodic instances of other
     deterministic families, A = 2..5, against the HBM-table kernel and the oracle."""
     B = 70
-    for cls, kw in (("DeepSeaContinuous", dict(size=9)), ("SimpleGridContinuous", dict(size=7)),
-                    ("MiniGridEmptyEpisodic", dict(size=6)), ("RiverSwimEpisodic", dict(size=40))):
+    for cls, kw, k1t in (("DeepSeaContinuous", dict(size=9), True), ("SimpleGridContinuous", dict(size=7), False),
+                         ("MiniGridEmptyEpisodic", dict(size=6), False), ("RiverSwimEpisodic", dict(size=40), None)):
         models = [make_model(cls, seed=1000 + i, **kw) for i in range(B)]
-        _check_lds_rollout(B, None, 13, 9_001, models=models)
+        _check_lds_rollout(B, None, 13, 9_001, models=models, expect_k1t=k1t, k1t_g=40)
 
 
 def test_lds_rollout_with_per_instance_episode_phase(need_gpu):
@@ -244,14 +266,16 @@ def test_lds_rollout_with_per_instance_episode_phase(need_gpu):
     mask = (np.arange(B) % 3 == 0).astype(np.uint8)
     n1, n2 = 13, 6_007
     res = {}
-    for which, pipe in ((L.ROLLOUT_GLOBAL, None), (L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1")):
+    for which, pipe in ((L.ROLLOUT_GLOBAL, None), (L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1"), (L.ROLLOUT_LDS_TEMPLATE, "1")):
         saved = os.environ.pop("CMDP_K1L_PIPE", None)
         if pipe is not None:
             os.environ["CMDP_K1L_PIPE"] = pipe
+        os.environ["CMDP_K1T_G"] = "30"
         try:
             env = BatchedMDP(models, rng_mode=L.RNG_PHILOX, philox_keys=keys, with_dp=False)
         finally:
             os.environ.pop("CMDP_K1L_PIPE", None)
+            os.environ.pop("CMDP_K1T_G", None)
             if saved is not None:
                 os.environ["CMDP_K1L_PIPE"] = saved
         env.set_rollout_kernel(which)
@@ -264,8 +288,8 @@ def test_lds_rollout_with_per_instance_episode_phase(need_gpu):
         res[(which, pipe)] = (out["last_obs"], out["reward_sum"], vs, vsa) + tuple(env.state())
         env.close()
     g = res[(L.ROLLOUT_GLOBAL, None)]
-    for pipe in ("0", "1"):
-        for x, y in zip(g, res[(L.ROLLOUT_LDS, pipe)]):
+    for key in ((L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1"), (L.ROLLOUT_LDS_TEMPLATE, "1")):
+        for x, y in zip(g, res[key]):
             np.testing.assert_array_equal(x, y)
     off = np.concatenate([[0], np.cumsum([m.n_states for m in models])])
     for b in range(B):

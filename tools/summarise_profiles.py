@@ -50,6 +50,7 @@ for leg, ks_ in legs.items():
 
 cfg = line["config"]
 units = {"k_rollout_pipe": cfg["instances_per_gpu"] * cfg["transitions_per_instance_per_step"],
+         "k_rollout_tmpl": cfg["instances_per_gpu"] * cfg["transitions_per_instance_per_step"],
          "k_rollout_lds": cfg["instances_per_gpu"] * cfg["transitions_per_instance_per_step"],
          "k_rollout_dense": 65536 * 200}
 kernels = []
