@@ -14,8 +14,9 @@ synchronise on both sides, the max over ranks is taken, rank 0 prints ONE JSON l
 ranks / that time.
 
 Objects on the line (prompt section 4; DESIGN.md section 4 explains every figure):
-  roofline      the dominant kernel.  The default layout keeps the tables in LDS, so it is bound by the latency of
-                the dependent LDS read of a transition, not by HBM: bound = "lds_latency", achieved = transitions/s,
+  roofline      the dominant kernel (K1T `k_rollout_tmpl` at the default configuration: one successor table per
+                workgroup, per-instance swap bits and count deltas).  The tables are in LDS, so it is bound by the
+                latency of the dependent LDS reads of a transition, not by HBM: bound = "lds_latency", achieved = transitions/s,
                 peak = chains the LDS can hold / the dependent-read chain latency CALIBRATED IN THIS RUN
                 (cmdp_calibrate), frac <= 1.  The HBM view (algorithmic bytes and PMC traffic against 8 TB/s) is the
                 sub-object roofline.hbm.
