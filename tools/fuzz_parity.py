@@ -17,6 +17,7 @@ from colosseum_amd.agents import BatchedQLearningContinuous, BatchedQLearningEpi
 from helpers_agents import QLearningContinuous, QLearningEpisodic   # numpy restatements of the reference agents (pinned to G7 / G10)
 
 rng = np.random.default_rng(0)
+counts = {}   # rollout kernel -> cases it ran
 
 
 def random_model():
@@ -78,6 +79,10 @@ def check_one():
             d0, per0 = env.diameter(1e-3, L.SCHEME_JACOBI)
             env.set_option(L.OPT_DP_KERNEL, 3)
             d1, per1 = env.diameter(1e-3, L.SCHEME_JACOBI)
+            env.set_option(L.OPT_DIAMETER_RELABEL_MIN_STATES, 1)   # K5S with the rows in the locality order of the states
+            d2, per2 = env.diameter(1e-3, L.SCHEME_JACOBI)
+            assert np.array_equal(per2, per1) and np.array_equal(d2, d1), tag
+            env.set_option(L.OPT_DIAMETER_RELABEL_MIN_STATES, 1 << 40)
             env.set_option(L.OPT_DP_KERNEL, 0)
             _, oper = O.diameter_continuous(S, A, m.csr(), scheme=1)
             assert np.array_equal(per0[:S], oper) and np.array_equal(per1, per0), tag
@@ -106,6 +111,36 @@ def check_one():
             assert o2["last_obs"][b] == r2["last_obs"] and o2["reward_sum"][b] == r2["reward_sum"], tag
             assert np.array_equal(env.split_states(vs)[b], e.visits()[0]), tag
         env.close()
+        # the other rollout kernels on the same streams: HBM tables (K1), the LDS kernels where the batch is eligible
+        # (K1L / K1P, the shared-table K1T, the stochastic-dynamics K1S)
+        for which in (L.ROLLOUT_GLOBAL, L.ROLLOUT_LDS, L.ROLLOUT_LDS_TEMPLATE, L.ROLLOUT_LDS_STOCHASTIC):
+            env = BatchedMDP([m] * 3, rng_mode=L.RNG_PHILOX, philox_keys=keys, with_dp=False)
+            env.set_rollout_kernel(which)
+            env.reset()
+            try:
+                env.rollout(n1)
+            except L.CmdpError as ex:
+                assert ex.code == L.ERR_UNSUPPORTED and which != L.ROLLOUT_GLOBAL, (tag, which, ex)
+                env.close()
+                continue
+            o3 = env.rollout(n)
+            assert np.array_equal(o3["last_obs"], o2["last_obs"]) and np.array_equal(o3["reward_sum"], o2["reward_sum"]), (tag, which)
+            assert np.array_equal(env.visits()[0], vs), (tag, which)
+            env.close()
+            counts[which] = counts.get(which, 0) + 1
+        # dense-row layout (K1D; three instances: the second walker of the last wavefront idles)
+        if S <= 400:
+            env = BatchedMDP([m] * 3, rng_mode=L.RNG_PHILOX, philox_keys=keys, with_dp=False, layout=L.LAYOUT_DENSE)
+            env.reset()
+            env.rollout(n1)
+            o4 = env.rollout(n)
+            for b in range(3):
+                e = O.OracleEnv(m, rng_mode=1, philox_key=int(keys[b]), dense=True)
+                e.reset()
+                e.rollout(n1, trace=False)
+                r4 = e.rollout(n, trace=False)
+                assert o4["last_obs"][b] == r4["last_obs"] and o4["reward_sum"][b] == r4["reward_sum"], (tag, "dense")
+            env.close()
 
 
 class _Spec:
@@ -178,3 +213,4 @@ if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     print("fuzz parity: %d random MDPs, all checks bit-equal" % run(seconds=budget, seed=seed))
+    print("rollout kernels exercised (1 K1, 2 K1L/K1P, 3 K1S, 4 K1T):", counts)
