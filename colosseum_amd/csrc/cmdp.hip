@@ -650,8 +650,14 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
         // (A = 2; seeds of a family whose structure does not depend on the seed only permute the actions), the workgroup
         // keeps ONE table and a swap bit per state and instance: 2-3 x the instances per CU.
         static const int k1t_env = std::getenv("CMDP_K1T") ? std::atoi(std::getenv("CMDP_K1T")) : -1;   // tuning aid: 0 off, 1 on
-        if (best_cap >= 8 && p.pipe && A == 2 && k1t_env != 0) {
+        // (K1T packs its own words -- successor row base as a byte offset | reward code above it, K1P's format -- whichever
+        // of K1L / K1P the plan above chose: small instances plan onto two K1L workgroups per CU, and K1T still beats that)
+        if (best_cap >= 8 && pipe_ok && A == 2 && k1t_env != 0) {
           const int S = max_S, rws = S * 2;
+          const int cs_t = bits_s + 1;
+          std::vector<uint16_t> w16((size_t)R);
+          for (int64_t r = 0; r < R; ++r)
+            w16[(size_t)r] = (uint16_t)((rows[(size_t)r].next_if_det * A * 2) | (codes[(size_t)r] << cs_t));
           TmplPlan q{};
           q.rows = rws;
           q.tmpl_bytes = (rws * 2 + 15) & ~15;
@@ -661,13 +667,16 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
           q.slot_bytes = q.off_ovf + ((2 * K1T_OVF + 3) & ~3);
           if (((q.slot_bytes / 4) & 1) == 0) q.slot_bytes += 4;   // odd dword stride: the lanes' slots start on different banks
           q.n_codes = p.n_codes;
-          q.code_shift = p.code_shift;
-          if (const char* de = std::getenv("CMDP_K1T_DEBUG")) q.debug = std::atoi(de);   // timing experiments: stages switched off
+          q.code_shift = cs_t;
+          if (const char* de = std::getenv("CMDP_K1T_DEBUG")) {   // timing experiments: stages switched off
+            q.debug = std::atoi(de);
+            if (q.debug) std::fprintf(stderr, "libcmdp: CMDP_K1T_DEBUG=%d switches stages of k_rollout_tmpl off -- results are INVALID (timing experiments only)\n", q.debug);
+          }
           std::vector<uint8_t> bits((size_t)B * q.mask_bytes, 0);
           bool same = true;
-          const uint16_t* T = next16.data();
+          const uint16_t* T = w16.data();
           for (int b = 0; same && b < B; ++b) {
-            const uint16_t* W = next16.data() + (size_t)b * rws;
+            const uint16_t* W = w16.data() + (size_t)b * rws;
             uint8_t* mb = bits.data() + (size_t)b * q.mask_bytes;
             for (int s2 = 0; s2 < S; ++s2) {
               const uint16_t w0 = W[2 * s2], w1 = W[2 * s2 + 1], t0 = T[2 * s2], t1 = T[2 * s2 + 1];
