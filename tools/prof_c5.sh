@@ -14,3 +14,6 @@ rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_c5_stats --output-format csv -- 
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_c5_fetch --output-format csv -- python3 $R/tools/run_c5.py > /dev/null 2>> $OUT/${TAG}_c5.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_c5_write --output-format csv -- python3 $R/tools/run_c5.py > /dev/null 2>> $OUT/${TAG}_c5.err
 echo done > $OUT/${TAG}_c5_progress.txt
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
+  --kernel-trace -d $OUT/${TAG}_c5_sq --output-format csv -- python3 $R/tools/run_c5.py > /dev/null 2>> $OUT/${TAG}_c5.err
+echo "sq done" >> $OUT/${TAG}_c5_progress.txt

@@ -36,5 +36,17 @@ j = dict(kernel=kern, workload="C5: MiniGridRoomsContinuous(seed=0,room_size=28,
          algorithmic_bytes="8 B per state per (target, sweep) = 2 x the bytes written", algorithmic_bytes_total=alg,
          achieved_algorithmic_GBps=alg / (kernel_ns * 1e-9) / 1e9, frac_of_8TBps=alg / (kernel_ns * 1e-9) / 8e12,
          traffic_GBps=(rd + wr) / (kernel_ns * 1e-9) / 1e9, read_amplification=rd / wr, run=run)
+sq = {}
+for name in ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"):
+    v, _ = counter("sq", name)
+    if v:
+        sq[name] = v
+if sq:
+    cyc = sq["GRBM_GUI_ACTIVE"] / 8   # rocprofv3 sums the 8 XCDs
+    j["sq"] = dict(sq, kernel_cycles=cyc, valu_issue_frac_at_2_cycles=sq["SQ_INSTS_VALU"] * 2 / (1024 * cyc),
+                   wave_cycles_waiting_frac=sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
+                   wave_cycles_issue_stalled_frac=sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"],
+                   valu_insts_per_state_and_group_sweep=sq["SQ_INSTS_VALU"] / (wr / 256.0),
+                   salu_insts_per_state_and_group_sweep=sq["SQ_INSTS_SALU"] / (wr / 256.0))
 json.dump(j, open(f"{prof}/r02_c5_diameter_pmc.json", "w"), indent=1)
 print({k: v for k, v in j.items() if k != "run"})
