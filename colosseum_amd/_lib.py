@@ -15,6 +15,7 @@ POLICY_RANDOM, POLICY_HOST_ACTIONS, POLICY_GREEDY_Q = 0, 1, 2
 SCHEME_AUTO, SCHEME_JACOBI, SCHEME_GAUSS_SEIDEL = 0, 1, 2
 LAYOUT_CSR, LAYOUT_DENSE = 0, 1
 FLAG_REWARD_MEANS = 1
+FLAG_REWARD_CACHE = 2  # reference-exact per-triple reward caches for batches (csrc/cmdp_reward_cache.h)
 OPT_ROLLOUT_KERNEL = 1
 OPT_DP_KERNEL = 2
 OPT_LDS_GROUPS_PER_CU = 3
@@ -22,7 +23,7 @@ OPT_DIAMETER_WORKSPACE_MB = 4
 OPT_CHAIN_EXACT_ORDER = 5
 OPT_MIXING_PATH = 6
 OPT_DIAMETER_RELABEL_MIN_STATES = 7
-STAT_DP_KERNEL_MS, STAT_DP_KERNEL = 1, 2
+STAT_DP_KERNEL_MS, STAT_DP_KERNEL, STAT_REWARD_FILLS, STAT_REWARD_ROUNDS = 1, 2, 3, 4
 NOISE_NONE, NOISE_GAUSSIAN, NOISE_GAUSSIAN_CORRELATED, NOISE_STUDENT_T, NOISE_STUDENT_T_CORRELATED = 0, 1, 2, 3, 4
 CALIB_LDS_READ, CALIB_LDS_CHAIN, CALIB_LDS_CHAIN_SHARED = 0, 1, 2
 DP_AUTO, DP_WORKGROUP, DP_REGISTER = 0, 1, 2
@@ -38,6 +39,7 @@ EXPORTS = [
     "cmdp_vi_episodic", "cmdp_pe_episodic", "cmdp_diameter", "cmdp_diameter_episodic", "cmdp_value_norm", "cmdp_gth", "cmdp_qlearning_create", "cmdp_qlearning_destroy", "cmdp_qlearning_run",
     "cmdp_qlearning_tables", "cmdp_qlearning_evaluate", "cmdp_greedy_policy_episodic", "cmdp_qlearning_continuous_create",
     "cmdp_qlearning_policy", "cmdp_qlearning_average_reward", "cmdp_qlearning_run_logged", "cmdp_tracker_replay", "cmdp_average_reward", "cmdp_diameter_range", "cmdp_diameter_sparse_f64", "cmdp_mixing_time", "cmdp_set_observation_table", "cmdp_observe", "cmdp_observe_noise",
+    "cmdp_set_reward_streams", "cmdp_legacy_beta",
 ]
 
 
@@ -180,6 +182,8 @@ def load():
         L.cmdp_observe_noise.argtypes = [vp, i32, C.c_double, C.c_double, vp, vp]
         L.cmdp_greedy_policy_episodic.argtypes = [vp, i32, i32, vp, vp]
         L.cmdp_qlearning_tables.argtypes = [vp, vp, vp]
+        L.cmdp_set_reward_streams.argtypes = [vp, vp, vp, vp, vp]
+        L.cmdp_legacy_beta.argtypes = [vp, vp, vp, vp, f64, f64, i64, vp]
         _lib = L
     return _lib
 

@@ -102,6 +102,29 @@ class BatchedMDP:
         self._h = C.c_void_p()
         L.check(lib.cmdp_create(C.byref(self._h), C.byref(d)))
         self._lib = lib
+        self.flags = int(flags)
+        if flags & L.FLAG_REWARD_CACHE and models is not None:
+            self.set_reward_streams([m.extra["rng_state"] for m in models])
+
+    def set_reward_streams(self, states):
+        """CMDP_FLAG_REWARD_CACHE: the numpy stream `BaseMDP._rng` of every instance as `RandomState.get_state()` gives it
+        after the MDP's construction (`TabularModel.extra["rng_state"]`); the library continues these streams whenever it
+        fills a cache of 5000 reward samples (colosseum/mdp/base.py:1196-1203)."""
+        assert len(states) == self.B
+        key = np.ascontiguousarray(np.stack([np.asarray(s[1], np.uint32) for s in states]))
+        pos = np.ascontiguousarray([int(s[2]) for s in states], np.int32)
+        has = np.ascontiguousarray([int(s[3]) for s in states], np.int32)
+        cached = np.ascontiguousarray([float(s[4]) for s in states], np.float64)
+        L.check(self._lib.cmdp_set_reward_streams(self._h, L.ptr(key), L.ptr(pos), L.ptr(has), L.ptr(cached)))
+
+    def reward_cache_stats(self) -> dict:
+        """Blocks of 5000 samples drawn so far and park / fill / relaunch rounds (CMDP_FLAG_REWARD_CACHE)."""
+        v = C.c_double()
+        out = {}
+        for k, w in (("fills", L.STAT_REWARD_FILLS), ("rounds", L.STAT_REWARD_ROUNDS)):
+            L.check(self._lib.cmdp_stat(self._h, w, C.byref(v)))
+            out[k] = int(v.value)
+        return out
 
     @property
     def handle(self):

@@ -120,12 +120,18 @@ def build_shard_models(instances: Sequence[Instance], rank: int = 0, world: int 
     return dict(zip(mine, _build_models([instances[i] for i in mine], workers)))
 
 
-def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_mode, device, max_time=np.inf):
+def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_mode, device, max_time=np.inf,
+               beta_rewards="reference"):
     L.check(L.load().cmdp_set_device(device))
     stochastic = any(not m.deterministic_rewards for m in models)
-    # Beta rewards: sampled on the device in Philox mode (the reference-exact host sampler is a per-step path)
-    env = BatchedMDP(models, rng_mode=L.RNG_PHILOX if stochastic else rng_mode,
-                     philox_keys=np.asarray(seeds, np.uint64) * np.uint64(0x9E3779B1) + np.uint64(17))
+    # Beta rewards, "reference": the reference's own per-triple caches of 5000 samples from the MDP's numpy stream
+    # (CMDP_FLAG_REWARD_CACHE: blocks in HBM, drawn by the library on the host whenever an instance needs one), next to
+    # the reference's transition streams -- rows equal the reference's for that seed.  "philox": sampled on the device
+    # from counter-based streams (distribution-exact throughput mode; no host work).
+    exact = stochastic and beta_rewards == "reference"
+    env = BatchedMDP(models, rng_mode=L.RNG_PHILOX if stochastic and not exact else rng_mode,
+                     philox_keys=np.asarray(seeds, np.uint64) * np.uint64(0x9E3779B1) + np.uint64(17),
+                     flags=L.FLAG_REWARD_CACHE if exact else 0)
     if agent_cls == "QLearningEpisodic":
         agent = BatchedQLearningEpisodic(env, seeds, optimization_horizon=n_steps, **agent_kwargs)
         loop = BatchedEpisodicLoop(env, agent)
@@ -144,12 +150,16 @@ def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, r
                   agent_configs: Optional[Dict[str, Dict[str, Any]]] = None, rng_mode: int = L.RNG_MT_COMPAT,
                   device: int = 0, max_concurrent_groups: int = 6, build_workers: int = 0, progress=None,
                   max_batch: int = 128, models: Optional[Dict[int, Any]] = None, max_time: float = np.inf,
-                  skip: Optional[Sequence[int]] = None):
+                  skip: Optional[Sequence[int]] = None, beta_rewards: str = "reference", on_group_done=None):
     """Runs this rank's contiguous shard; returns {global instance index: logger rows}.  `models` = the shard's
     models from `build_shard_models` (a caller that must initialise RCCL between the fork()ed build and the first HIP
     call builds them itself).  `max_time`: the experiment's `max_interaction_time_s` (training of an instance is frozen
     once its batch has run that long, agent_mdp_interaction.py:160-177).  `skip`: global indices not to run -- instances
-    whose log file already exists (`unfinished_instances`), as the reference's resume does."""
+    whose log file already exists (`unfinished_instances`), as the reference's resume does.  `beta_rewards`: "reference"
+    (default: the reference's reward caches and streams, rows equal the reference's) or "philox" (device-sampled Beta
+    rewards, distribution-exact).  `on_group_done(indices, rows)` is called from the worker thread as soon as a device
+    batch has finished (the runner writes that batch's log files then, so an interrupted run resumes from them)."""
+    assert beta_rewards in ("reference", "philox")
     agent_configs = agent_configs or DEFAULT_AGENT_CONFIGS
     lo, hi = shard_range(len(instances), rank, world)
     skip = set(skip or ())
@@ -164,9 +174,9 @@ def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, r
         # continuous baselines use discounted VI under the reference's own scheme rule, which depends on the instance's
         # size and density: one scheme per device batch
         scheme = 0 if m.is_episodic else _vi_rule(m.n_states, m.n_actions, len(m.csr()[1]))
-        # deterministic-reward instances run the reference's own random streams (MT_COMPAT: rows equal to the reference's
-        # for that seed), Beta-reward instances sample their rewards on the device from Philox streams: never in one
-        # batch, so that what an instance produces does not depend on which other instances the benchmark holds
+        # deterministic- and Beta-reward instances never share a device batch: in "philox" mode the two run different
+        # transition streams (MT_COMPAT / Philox), and what an instance produces must not depend on which other
+        # instances the benchmark holds
         groups.setdefault((instances[i].mdp_cls, m.H, m.n_actions, tuple(m.rewards_range), scheme, m.deterministic_rewards),
                           []).append(i)
     results: Dict[int, list] = {}
@@ -177,7 +187,9 @@ def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, r
         ins = instances[idx[0]]
         t0 = time.time()
         rows = _run_group([models[i] for i in idx], [instances[i].seed for i in idx], ins.agent_cls,
-                          agent_configs[ins.agent_cls], n_steps, log_every, rng_mode, device, max_time)
+                          agent_configs[ins.agent_cls], n_steps, log_every, rng_mode, device, max_time, beta_rewards)
+        if on_group_done:
+            on_group_done(idx, rows)
         if progress:
             progress(f"{ins.label}: {len(idx)} instances, S={models[idx[0]].n_states}, H={models[idx[0]].H}, "
                      f"{time.time() - t0:.1f} s")
@@ -210,9 +222,52 @@ def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, r
     return results
 
 
+def _write_atomic(path: str, text: str):
+    """The log file appears complete or not at all: a run killed mid-write must not leave a truncated file that the
+    resume (`unfinished_instances`) would take for a finished instance."""
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "w", newline="") as f:
+        f.write(text)
+    os.replace(tmp, path)
+
+
+def _write_slice(task):
+    """Worker of `submit_group_logs` (runs in a spawned process): formats the CSV texts of a slice of one device batch
+    and writes them, each file atomically, with the `time_exceeded.txt` ledger lines."""
+    from .experiment.vector_tracker import _csv_texts_of_slice
+
+    steps, cols, n, paths, last_steps = task
+    for text, path, last in zip(_csv_texts_of_slice((steps, cols, n)), paths, last_steps):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        _write_atomic(path, text)
+        if last != -1:  # the ledger run_experiment_instance appends to (experiment_instances.py:218-222)
+            with open(os.path.join(os.path.dirname(path), "time_exceeded.txt"), "a") as f:
+                f.write(f"last training step at ({last}) for {path}\n")
+    return len(paths)
+
+
+def submit_group_logs(pool, folder: str, instances: Sequence[Instance], idx: Sequence[int], rows, chunk: int = 16):
+    """Hands the log files of ONE finished device batch to `pool` (a concurrent.futures executor of spawned processes:
+    the float -> text conversion is Python-level work that must not hold the GIL of the threads driving the other
+    batches).  Returns the futures.  Files are written as their batch finishes, so an interrupted benchmark resumes from
+    what is on disk (the reference writes every instance's file at its own end, experiment_instance.py:53-82)."""
+    log = rows[0].log
+    fin = log.finalize()
+    futs = []
+    for b0 in range(0, len(idx), chunk):
+        b1 = min(len(idx), b0 + chunk)
+        bs = [rows[j].b for j in range(b0, b1)]
+        assert bs == list(range(bs[0], bs[0] + len(bs)))
+        cols = {n: (v[:, bs[0]:bs[-1] + 1], k if isinstance(k, int) else k[:, bs[0]:bs[-1] + 1]) for n, (v, k) in fin.items()}
+        paths = [log_file(folder, instances[idx[j]]) for j in range(b0, b1)]
+        lasts = [int(getattr(rows[j], "last_training_step", -1)) for j in range(b0, b1)]
+        futs.append(pool.submit(_write_slice, (list(log.steps), cols, b1 - b0, paths, lasts)))
+    return futs
+
+
 def write_csv_logs(folder: str, instances: Sequence[Instance], results: Dict[int, list], workers: int = 0):
     """The reference's on-disk wire format (CSVLogger with add_uid=False; header = sorted keys).  `workers` > 1
-    formats the column stores of the device batches in a process pool."""
+    formats the column stores of the device batches in a process pool.  Every file is written atomically."""
     from .experiment.vector_tracker import LogTable, csv_texts_parallel
 
     logs = {}
@@ -224,15 +279,19 @@ def write_csv_logs(folder: str, instances: Sequence[Instance], results: Dict[int
         ins = instances[i]
         d = os.path.join(folder, "logs", ins.label)
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, f"seed{ins.seed}_logs.csv"), "w", newline="") as f:
-            if isinstance(rows, LogTable):
-                f.write(texts[id(rows.log)][rows.b])
-            else:
-                fields = sorted(rows[0].keys())
-                w = csv.DictWriter(f, fieldnames=fields, extrasaction="ignore")
-                w.writeheader()
-                for r in rows:
-                    w.writerow({k: np.array(v) for k, v in r.items()})
+        path = os.path.join(d, f"seed{ins.seed}_logs.csv")
+        if isinstance(rows, LogTable):
+            _write_atomic(path, texts[id(rows.log)][rows.b])
+        else:
+            import io
+
+            buf = io.StringIO(newline="")
+            fields = sorted(rows[0].keys())
+            w = csv.DictWriter(buf, fieldnames=fields, extrasaction="ignore")
+            w.writeheader()
+            for r in rows:
+                w.writerow({k: np.array(v) for k, v in r.items()})
+            _write_atomic(path, buf.getvalue())
         last = getattr(rows, "last_training_step", -1)
         if last != -1:  # the ledger run_experiment_instance appends to (experiment_instances.py:218-222)
             with open(os.path.join(d, "time_exceeded.txt"), "a") as f:

@@ -103,6 +103,33 @@ struct cmdp {
   int64_t n_states = 0, n_rows = 0, n_entries = 0, n_csr = 0, n_slots = 0;
   bool has_env = false, has_dp = false;
   bool sample_beta = false;  // Beta rewards drawn on the device (CMDP_RNG_PHILOX without CMDP_FLAG_REWARD_MEANS)
+  // CMDP_FLAG_REWARD_CACHE: the reference's per-triple caches of 5000 samples from the MDP's own numpy stream
+  // (cmdp_reward_cache.h): blocks in HBM, drawn on the host whenever an instance parks
+  bool reward_cache = false, rc_streams_set = false;
+  std::vector<uint8_t> h_rkind;
+  std::vector<double> h_rp0, h_rp1;
+  std::vector<int32_t> h_canon;
+  std::vector<cmdp_rc::NumpyStream> rc_streams;   // [B] BaseMDP._rng of every instance, where construction left it
+  std::vector<double*> rc_blk_h;                  // [E] host mirror of the block pointers
+  std::vector<double*> rc_chunks;                 // pool of blocks: chunks of rc_chunk_blocks blocks each
+  size_t rc_chunk_blocks = 0, rc_next_block = 0;  // blocks handed out so far
+  int rc_cap = 0;                                 // blocks one install pass can stage
+  int64_t rc_fills = 0, rc_rounds = 0;            // CMDP_STAT_REWARD_FILLS / _ROUNDS
+  double* rc_stage_h = nullptr;                   // pinned [rc_cap][5000]
+  double** rc_dst_h = nullptr;                    // pinned [rc_cap]
+  int32_t* rc_ent_h = nullptr;                    // pinned [rc_cap]
+  int32_t* rc_list_h = nullptr;                   // pinned [B]
+  int32_t* rc_pend_h = nullptr;                   // pinned [B]
+  DevBuf<int32_t> d_rc_canon, d_rc_pos, d_rc_pend_e, d_rc_pend_prev, d_rc_pend_act, d_rc_park_count, d_rc_park_list, d_rc_ent;
+  DevBuf<double*> d_rc_blk, d_rc_dst;
+  DevBuf<long long> d_rc_left;
+  DevBuf<double> d_rc_stage;
+  RewardCache rcache() {
+    RewardCache c{};
+    c.canon = d_rc_canon.p; c.blk = d_rc_blk.p; c.pos = d_rc_pos.p; c.pend_e = d_rc_pend_e.p; c.pend_prev = d_rc_pend_prev.p;
+    c.pend_act = d_rc_pend_act.p; c.park_count = d_rc_park_count.p; c.park_list = d_rc_park_list.p; c.left = d_rc_left.p;
+    return c;
+  }
   std::vector<int64_t> state_off;  // host copy
   std::vector<int64_t> csr_nnz;    // per instance
   int max_S = 0;
@@ -229,7 +256,7 @@ int set_lds(K kernel, size_t bytes) {
 // h->k1s_ok false (the batch then takes K1) whenever a limit of the format is exceeded.
 static int build_k1s(cmdp_t* h, const cmdp_desc* d) {
   const int B = h->B, A = h->A;
-  if (h->rng_mode != CMDP_RNG_PHILOX || h->sample_beta || h->layout != CMDP_LAYOUT_CSR) return CMDP_OK;
+  if (h->rng_mode != CMDP_RNG_PHILOX || h->sample_beta || h->reward_cache || h->layout != CMDP_LAYOUT_CSR) return CMDP_OK;
   const int64_t S0 = h->max_S;   // slots are sized for the largest instance
   if (S0 * A >= 65536 || S0 < 1) return CMDP_OK;
   if (d->sp_rkind)
@@ -383,6 +410,12 @@ int cmdp_destroy(cmdp_t* h) {
     (void)hipStreamSynchronize(h->stream);
     (void)hipStreamDestroy(h->stream);
   }
+  for (double* c : h->rc_chunks) (void)hipFree(c);
+  if (h->rc_stage_h) (void)hipHostFree(h->rc_stage_h);
+  if (h->rc_dst_h) (void)hipHostFree(h->rc_dst_h);
+  if (h->rc_ent_h) (void)hipHostFree(h->rc_ent_h);
+  if (h->rc_list_h) (void)hipHostFree(h->rc_list_h);
+  if (h->rc_pend_h) (void)hipHostFree(h->rc_pend_h);
   delete h;
   return CMDP_OK;
 }
@@ -446,8 +479,56 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
         if (d->sp_rkind[e] > 1) return fail(CMDP_ERR_UNSUPPORTED, "unknown reward distribution kind at entry %lld", (long long)e);
         any_beta |= d->sp_rkind[e] == 1;
       }
-    const bool sample_beta = any_beta && !(d->flags & CMDP_FLAG_REWARD_MEANS);
+    if ((d->flags & CMDP_FLAG_REWARD_MEANS) && (d->flags & CMDP_FLAG_REWARD_CACHE))
+      return fail(CMDP_ERR_INVALID, "CMDP_FLAG_REWARD_MEANS and CMDP_FLAG_REWARD_CACHE exclude each other");
+    const bool reward_cache = any_beta && (d->flags & CMDP_FLAG_REWARD_CACHE);
+    const bool sample_beta = any_beta && !(d->flags & (CMDP_FLAG_REWARD_MEANS | CMDP_FLAG_REWARD_CACHE));
     h->sample_beta = sample_beta;
+    h->reward_cache = reward_cache;
+    if (reward_cache) {
+      if (!d->sp_rp0 || !d->sp_rp1 || d->layout != CMDP_LAYOUT_CSR)
+        return fail(CMDP_ERR_INVALID, "CMDP_FLAG_REWARD_CACHE needs sp_rp0 / sp_rp1 and the CSR layout");
+      if (E > 0x7fffffffLL) return fail(CMDP_ERR_UNSUPPORTED, "CMDP_FLAG_REWARD_CACHE: more than 2^31 entries");
+      for (int64_t e = 0; e < E; ++e)
+        if (d->sp_rkind[e] == 1 && !(d->sp_rp0[e] > 0.0 && d->sp_rp1[e] > 0.0))
+          return fail(CMDP_ERR_INVALID, "Beta parameters must be positive (entry %lld)", (long long)e);
+      h->h_rkind.assign(d->sp_rkind, d->sp_rkind + E);
+      h->h_rp0.assign(d->sp_rp0, d->sp_rp0 + E);
+      h->h_rp1.assign(d->sp_rp1, d->sp_rp1 + E);
+      // the reference keys its caches by (node, action, next_node): entries of a row that name the same successor
+      // (p_rand adds repeated successors) share one cache -- represented by the first of them
+      h->h_canon.resize((size_t)E);
+      for (int64_t r = 0; r < R; ++r) {
+        const int64_t lo = d->sp_ptr[r], hi = d->sp_ptr[r + 1];
+        for (int64_t e = lo; e < hi; ++e) {
+          int64_t c = e;
+          for (int64_t f = lo; f < e; ++f)
+            if (d->sp_next[f] == d->sp_next[e]) { c = f; break; }
+          h->h_canon[(size_t)e] = (int32_t)c;
+        }
+      }
+      HIP_TRY(h->d_sp_rkind.upload(d->sp_rkind, E, st));
+      HIP_TRY(h->d_rc_canon.upload(h->h_canon.data(), E, st));
+      HIP_TRY(h->d_rc_blk.alloc(E)); HIP_TRY(h->d_rc_blk.zero(st));
+      HIP_TRY(h->d_rc_pos.alloc(E)); HIP_TRY(h->d_rc_pos.zero(st));
+      HIP_TRY(h->d_rc_pend_e.alloc(B)); HIP_TRY(hipMemsetAsync(h->d_rc_pend_e.p, 0xff, sizeof(int32_t) * B, st));
+      HIP_TRY(h->d_rc_pend_prev.alloc(B)); HIP_TRY(h->d_rc_pend_prev.zero(st));
+      HIP_TRY(h->d_rc_pend_act.alloc(B)); HIP_TRY(h->d_rc_pend_act.zero(st));
+      HIP_TRY(h->d_rc_park_count.alloc(1)); HIP_TRY(h->d_rc_park_count.zero(st));
+      HIP_TRY(h->d_rc_park_list.alloc(B));
+      HIP_TRY(h->d_rc_left.alloc(B)); HIP_TRY(h->d_rc_left.zero(st));
+      h->rc_blk_h.assign((size_t)E, nullptr);
+      h->rc_cap = std::min(B, 1024);
+      h->rc_chunk_blocks = (size_t)std::max(256, std::min(B * 8, 4096));  // 10 .. 164 MB per chunk
+      HIP_TRY(h->d_rc_stage.alloc((size_t)h->rc_cap * CMDP_RC_BLOCK));
+      HIP_TRY(h->d_rc_dst.alloc(h->rc_cap));
+      HIP_TRY(h->d_rc_ent.alloc(h->rc_cap));
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->rc_stage_h), sizeof(double) * (size_t)h->rc_cap * CMDP_RC_BLOCK, 0));
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->rc_dst_h), sizeof(double*) * (size_t)h->rc_cap, 0));
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->rc_ent_h), sizeof(int32_t) * (size_t)h->rc_cap, 0));
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->rc_list_h), sizeof(int32_t) * (size_t)B, 0));
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->rc_pend_h), sizeof(int32_t) * (size_t)B, 0));
+    }
     if (sample_beta) {
       if (d->rng_mode != CMDP_RNG_PHILOX || !d->sp_rp0 || !d->sp_rp1)
         return fail(CMDP_ERR_UNSUPPORTED, "Beta rewards are sampled on the device only in CMDP_RNG_PHILOX mode with sp_rp0/"
@@ -543,7 +624,7 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
     HIP_TRY(h->d_visits_sa.zero(st));
     // ---- eligibility of the LDS-resident rollout kernel --------------------------------------------------
     {
-      bool ok = max_S <= 65535 && h->n_slots == 0 && !sample_beta;
+      bool ok = max_S <= 65535 && h->n_slots == 0 && !sample_beta && !reward_cache;
       for (int b = 0; ok && b < B; ++b) ok = (d->state_off[b + 1] - d->state_off[b]) == max_S;  // uniform S
       for (int64_t r = 0; ok && r < R; ++r) ok = rows[(size_t)r].n == 1;
       for (int b = 0; ok && b < B; ++b) ok = (d->start_off[b + 1] - d->start_off[b]) == 1;
@@ -664,7 +745,9 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
           q.mask_bytes = ((S + 7) / 8 + 3) & ~3;
           q.off_cnt = q.mask_bytes;
           q.off_ovf = q.off_cnt + ((rws + 4 + 3) & ~3);
-          q.slot_bytes = q.off_ovf + ((2 * K1T_OVF + 3) & ~3);
+          // two spare entries: the counts wavefront stores ovf[n_ovf] unconditionally before it knows whether a counter
+          // wrapped (branch-free), so with the list full the store must still land inside the instance's own slot
+          q.slot_bytes = q.off_ovf + ((2 * (K1T_OVF + 2) + 3) & ~3);
           if (((q.slot_bytes / 4) & 1) == 0) q.slot_bytes += 4;   // odd dword stride: the lanes' slots start on different banks
           q.n_codes = p.n_codes;
           q.code_shift = cs_t;
@@ -850,6 +933,104 @@ int cmdp_reset(cmdp_t* h, const uint8_t* mask, int32_t* obs_out) {
   return CMDP_OK;
 }
 
+}  // extern "C"
+// ---- reference-exact reward caches: the park / fill / relaunch loop (cmdp_reward_cache.h) ------------------------------
+// `launch(resume)` enqueues the interaction kernel of the call on the handle's stream (resume 0: every lane starts the
+// call's steps; 1: only lanes that parked continue).  Returns when no instance is parked any more; the stream is idle then.
+template <typename F>
+static int rc_drive(cmdp_t* h, F&& launch) {
+  hipStream_t st = h->stream;
+  const int B = h->B;
+  HIP_TRY(h->d_rc_park_count.zero(st));
+  if (int rc = launch(0)) return rc;
+  for (;;) {
+    HIP_TRY(hipMemcpyAsync(h->rc_list_h, h->d_rc_park_count.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int count = h->rc_list_h[0];
+    if (count == 0) return CMDP_OK;
+    if (count < 0 || count > B) return fail(CMDP_ERR_HIP, "reward cache: corrupt park count %d", count);
+    if (!h->rc_streams_set)
+      return fail(CMDP_ERR_INVALID, "CMDP_FLAG_REWARD_CACHE: a Beta reward is needed but cmdp_set_reward_streams was not called");
+    HIP_TRY(hipMemcpyAsync(h->rc_list_h, h->d_rc_park_list.p, sizeof(int32_t) * count, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h->rc_pend_h, h->d_rc_pend_e.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    h->rc_rounds++;
+    for (int j0 = 0; j0 < count; j0 += h->rc_cap) {
+      const int n = std::min(h->rc_cap, count - j0);
+      // one task per parked instance: 5000 draws of its triple's distribution from the instance's own numpy stream
+      const std::function<void(int)> fill = [&](int j) {
+        const int b = h->rc_list_h[j0 + j];
+        const int32_t c = h->h_canon[(size_t)h->rc_pend_h[b]];
+        const double pa = h->h_rp0[(size_t)c], pb = h->h_rp1[(size_t)c];
+        cmdp_rc::NumpyStream& rs = h->rc_streams[(size_t)b];
+        double* out = h->rc_stage_h + (size_t)j * CMDP_RC_BLOCK;
+        for (int k = 0; k < CMDP_RC_BLOCK; ++k) out[k] = rs.beta(pa, pb);
+      };
+      cmdp_rc::Pool::get().parallel_for(n, fill);
+      for (int j = 0; j < n; ++j) {
+        const int b = h->rc_list_h[j0 + j];
+        const int32_t c = h->h_canon[(size_t)h->rc_pend_h[b]];
+        double* blk = h->rc_blk_h[(size_t)c];
+        if (!blk) {  // first fill of the triple: a block of its own from the pool (a refill overwrites it in place)
+          const size_t chunk = h->rc_next_block / h->rc_chunk_blocks, slot = h->rc_next_block % h->rc_chunk_blocks;
+          if (chunk == h->rc_chunks.size()) {
+            double* cp = nullptr;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&cp), sizeof(double) * h->rc_chunk_blocks * CMDP_RC_BLOCK));
+            h->rc_chunks.push_back(cp);
+          }
+          blk = h->rc_chunks[chunk] + slot * CMDP_RC_BLOCK;
+          h->rc_next_block++;
+          h->rc_blk_h[(size_t)c] = blk;
+        }
+        h->rc_dst_h[j] = blk;
+        h->rc_ent_h[j] = c;
+      }
+      h->rc_fills += n;
+      HIP_TRY(hipMemcpyAsync(h->d_rc_stage.p, h->rc_stage_h, sizeof(double) * (size_t)n * CMDP_RC_BLOCK, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(h->d_rc_dst.p, h->rc_dst_h, sizeof(double*) * (size_t)n, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(h->d_rc_ent.p, h->rc_ent_h, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_rc_install, dim3(n), dim3(256), 0, st, n, h->d_rc_stage.p, h->d_rc_dst.p, h->d_rc_ent.p, h->rcache());
+      HIP_TRY(hipGetLastError());
+      if (j0 + n < count) HIP_TRY(hipStreamSynchronize(st));  // the pinned staging area is reused by the next slice
+    }
+    if (int rc = launch(1)) return rc;
+  }
+}
+
+extern "C" {
+int cmdp_set_reward_streams(cmdp_t* h, const uint32_t* mt_key, const int32_t* mt_pos, const int32_t* has_gauss,
+                            const double* cached_gaussian) {
+  if (!h || !mt_key || !mt_pos) return fail(CMDP_ERR_INVALID, "null argument");
+  const int B = h->B;
+  for (int b = 0; b < B; ++b)
+    if (mt_pos[b] < 0 || mt_pos[b] > 624) return fail(CMDP_ERR_INVALID, "instance %d: MT19937 position %d outside [0, 624]", b, mt_pos[b]);
+  h->rc_streams.resize((size_t)B);
+  for (int b = 0; b < B; ++b) {
+    cmdp_rc::NumpyStream& rs = h->rc_streams[(size_t)b];
+    std::memcpy(rs.key, mt_key + (size_t)b * 624, sizeof rs.key);
+    rs.pos = mt_pos[b];
+    rs.has_gauss = has_gauss ? has_gauss[b] : 0;
+    rs.gauss = cached_gaussian ? cached_gaussian[b] : 0.0;
+  }
+  h->rc_streams_set = true;
+  return CMDP_OK;
+}
+
+int cmdp_legacy_beta(uint32_t* mt_key, int32_t* mt_pos, int32_t* has_gauss, double* cached_gaussian, double a, double b,
+                     int64_t n, double* out) {
+  if (!mt_key || !mt_pos || !has_gauss || !cached_gaussian || !out || n < 0) return fail(CMDP_ERR_INVALID, "null argument");
+  if (!(a > 0.0 && b > 0.0)) return fail(CMDP_ERR_INVALID, "Beta parameters must be positive");
+  if (*mt_pos < 0 || *mt_pos > 624) return fail(CMDP_ERR_INVALID, "MT19937 position outside [0, 624]");
+  cmdp_rc::NumpyStream rs;
+  std::memcpy(rs.key, mt_key, sizeof rs.key);
+  rs.pos = *mt_pos; rs.has_gauss = *has_gauss; rs.gauss = *cached_gaussian;
+  // several blocks in parallel would not be the reference's stream: one stream, sequential draws
+  for (int64_t i = 0; i < n; ++i) out[i] = rs.beta(a, b);
+  std::memcpy(mt_key, rs.key, sizeof rs.key);
+  *mt_pos = rs.pos; *has_gauss = rs.has_gauss; *cached_gaussian = rs.gauss;
+  return CMDP_OK;
+}
+
 static int any_needs_reset(cmdp_t* h, bool* any) {
   hipStream_t st = h->stream;
   HIP_TRY(h->d_flag.zero(st));
@@ -887,9 +1068,19 @@ int cmdp_step(cmdp_t* h, const int32_t* actions, int auto_reset, int32_t* obs, d
   if (f & 2) return fail(CMDP_ERR_INVALID, "action out of range [0, %d)", h->A);
   if (f & 1) return fail(CMDP_ERR_NEEDS_RESET, "step() on an instance that needs reset()");
   h->known_reset = false;  // a step may end an episode (LAST): the async rollout re-checks before its next launch
-  hipLaunchKernelGGL(k_step, dim3(grid_for(B, 256)), dim3(256), 0, st, h->env(), d_act, auto_reset, d_obs,
-                     h->d_f64_scratch.p, h->d_u8_scratch.p);
-  HIP_TRY(hipGetLastError());
+  if (h->reward_cache) {
+    if (int rc = rc_drive(h, [&](int resume) -> int {
+          hipLaunchKernelGGL(k_step<true>, dim3(grid_for(B, 256)), dim3(256), 0, st, h->env(), d_act, auto_reset, d_obs,
+                             h->d_f64_scratch.p, h->d_u8_scratch.p, h->rcache(), resume);
+          HIP_TRY(hipGetLastError());
+          return CMDP_OK;
+        }))
+      return rc;
+  } else {
+    hipLaunchKernelGGL(k_step<false>, dim3(grid_for(B, 256)), dim3(256), 0, st, h->env(), d_act, auto_reset, d_obs,
+                       h->d_f64_scratch.p, h->d_u8_scratch.p, RewardCache{}, 0);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipMemcpyAsync(obs, d_obs, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(reward, h->d_f64_scratch.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(step_type, h->d_u8_scratch.p, B, hipMemcpyDeviceToHost, st));
@@ -898,11 +1089,23 @@ int cmdp_step(cmdp_t* h, const int32_t* actions, int auto_reset, int32_t* obs, d
 }
 
 static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_t n_steps, double* d_rsum,
-                          int32_t* d_last, int32_t* d_tobs, double* d_trew, uint8_t* d_ttype, const float* d_q = nullptr) {
+                          int32_t* d_last, int32_t* d_tobs, double* d_trew, uint8_t* d_ttype, const float* d_q = nullptr,
+                          int resume = 0) {
   hipStream_t st = h->stream;
   const dim3 grid(grid_for(h->B, 256)), block(256);
   const bool trace = d_tobs || d_trew || d_ttype;
   EnvTables t = h->env();
+  if (h->reward_cache) {  // reference-exact reward caches: the lane-per-instance kernel with the park protocol
+    const RewardCache rc = h->rcache();
+#define ROLL_RC(P, TR) \
+  hipLaunchKernelGGL((k_rollout<P, TR, false, true>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype, d_q, rc, resume)
+    if (policy == CMDP_POLICY_RANDOM) { if (trace) ROLL_RC(0, true); else ROLL_RC(0, false); }
+    else if (policy == CMDP_POLICY_HOST_ACTIONS) { if (trace) ROLL_RC(1, true); else ROLL_RC(1, false); }
+    else { if (trace) ROLL_RC(2, true); else ROLL_RC(2, false); }
+#undef ROLL_RC
+    HIP_TRY(hipGetLastError());
+    return CMDP_OK;
+  }
   if (policy == CMDP_POLICY_GREEDY_Q) {
     if (h->layout == CMDP_LAYOUT_DENSE) return fail(CMDP_ERR_UNSUPPORTED, "CMDP_POLICY_GREEDY_Q runs on the CSR layout");
     if (trace) hipLaunchKernelGGL((k_rollout<2, true, true>), grid, block, 0, st, t, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype, d_q);
@@ -1032,9 +1235,12 @@ int cmdp_rollout(cmdp_t* h, int policy, const void* policy_arg, int64_t n_steps,
   if (trace_obs && h->d_tr_obs.n < NB) HIP_TRY(h->d_tr_obs.alloc(NB));
   if (trace_reward && h->d_tr_rew.n < NB) HIP_TRY(h->d_tr_rew.alloc(NB));
   if (trace_type && h->d_tr_type.n < NB) HIP_TRY(h->d_tr_type.alloc(NB));
-  if (int rc = launch_rollout(h, policy, d_act, n_steps, h->d_rsum.p, h->d_last_obs.p, trace_obs ? h->d_tr_obs.p : nullptr,
-                              trace_reward ? h->d_tr_rew.p : nullptr, trace_type ? h->d_tr_type.p : nullptr, d_q))
-    return rc;
+  auto launch = [&](int resume) -> int {
+    return launch_rollout(h, policy, d_act, n_steps, h->d_rsum.p, h->d_last_obs.p, trace_obs ? h->d_tr_obs.p : nullptr,
+                          trace_reward ? h->d_tr_rew.p : nullptr, trace_type ? h->d_tr_type.p : nullptr, d_q, resume);
+  };
+  if (h->reward_cache) { if (int rc = rc_drive(h, launch)) return rc; }
+  else if (int rc = launch(0)) return rc;
   if (last_obs) HIP_TRY(hipMemcpyAsync(last_obs, h->d_last_obs.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
   if (reward_sum) HIP_TRY(hipMemcpyAsync(reward_sum, h->d_rsum.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
   if (trace_obs) HIP_TRY(hipMemcpyAsync(trace_obs, h->d_tr_obs.p, sizeof(int32_t) * NB, hipMemcpyDeviceToHost, st));
@@ -1057,6 +1263,10 @@ int cmdp_rollout_async(cmdp_t* h, int policy, int64_t n_steps) {
   }
   if (h->d_rsum.n < (size_t)h->B) HIP_TRY(h->d_rsum.alloc(h->B));
   if (h->d_last_obs.n < (size_t)h->B) HIP_TRY(h->d_last_obs.alloc(h->B));
+  if (h->reward_cache)  // the park / fill / relaunch loop needs the host: synchronous in this mode
+    return rc_drive(h, [&](int resume) -> int {
+      return launch_rollout(h, policy, nullptr, n_steps, h->d_rsum.p, h->d_last_obs.p, nullptr, nullptr, nullptr, nullptr, resume);
+    });
   return launch_rollout(h, policy, nullptr, n_steps, h->d_rsum.p, h->d_last_obs.p, nullptr, nullptr, nullptr);
 }
 
@@ -1133,6 +1343,10 @@ int cmdp_stat(cmdp_t* h, int which, double* out) {
   }
   if (which == CMDP_STAT_DP_KERNEL) {
     *out = h->last_dp_kernel;
+    return CMDP_OK;
+  }
+  if (which == CMDP_STAT_REWARD_FILLS || which == CMDP_STAT_REWARD_ROUNDS) {
+    *out = (double)(which == CMDP_STAT_REWARD_FILLS ? h->rc_fills : h->rc_rounds);
     return CMDP_OK;
   }
   return fail(CMDP_ERR_INVALID, "unknown statistic %d", which);
@@ -2673,18 +2887,30 @@ int cmdp_qlearning_destroy(cmdp_agent_t* a) {
 }
 
 // the interaction kernel of `n_steps` steps on the handle's stream (no synchronisation, no copies)
-static int ql_enqueue_run(cmdp_agent_t* a, int64_t n_steps, const uint8_t* dmask, int8_t* d_actions) {
+static int ql_launch(cmdp_agent_t* a, int64_t n_steps, const uint8_t* dmask, int8_t* d_actions, int resume) {
   cmdp_t* h = a->env;
   hipStream_t st = h->stream;
   const dim3 grid(grid_for(h->B, 256)), block(256);
-  if (a->continuous)
-    hipLaunchKernelGGL(k_qlearn_continuous, grid, block, 0, st, h->env(), a->cargs, n_steps, dmask, d_actions, a->d_rsum.p);
-  else if (a->args.ucb == 0)
-    hipLaunchKernelGGL((k_qlearn_episodic<0>), grid, block, 0, st, h->env(), a->args, n_steps, dmask, d_actions, a->d_rsum.p);
-  else
-    hipLaunchKernelGGL((k_qlearn_episodic<1>), grid, block, 0, st, h->env(), a->args, n_steps, dmask, d_actions, a->d_rsum.p);
+  const RewardCache rc = h->rcache();
+#define QL_LAUNCH(K, ARGS) hipLaunchKernelGGL(K, grid, block, 0, st, h->env(), ARGS, n_steps, dmask, d_actions, a->d_rsum.p, rc, resume)
+  if (h->reward_cache) {
+    if (a->continuous) QL_LAUNCH(k_qlearn_continuous<true>, a->cargs);
+    else if (a->args.ucb == 0) QL_LAUNCH((k_qlearn_episodic<0, true>), a->args);
+    else QL_LAUNCH((k_qlearn_episodic<1, true>), a->args);
+  } else {
+    if (a->continuous) QL_LAUNCH(k_qlearn_continuous<false>, a->cargs);
+    else if (a->args.ucb == 0) QL_LAUNCH((k_qlearn_episodic<0, false>), a->args);
+    else QL_LAUNCH((k_qlearn_episodic<1, false>), a->args);
+  }
+#undef QL_LAUNCH
   HIP_TRY(hipGetLastError());
   return CMDP_OK;
+}
+// With reference-exact reward caches the call returns with the stream idle (instances park, the host fills their blocks,
+// the kernel is relaunched); otherwise nothing is synchronised.
+static int ql_enqueue_run(cmdp_agent_t* a, int64_t n_steps, const uint8_t* dmask, int8_t* d_actions) {
+  if (a->env->reward_cache) return rc_drive(a->env, [&](int resume) -> int { return ql_launch(a, n_steps, dmask, d_actions, resume); });
+  return ql_launch(a, n_steps, dmask, d_actions, 0);
 }
 
 int cmdp_qlearning_run(cmdp_agent_t* a, int64_t n_steps, const uint8_t* train_mask, int8_t* actions_trace,
@@ -2773,6 +2999,11 @@ int cmdp_qlearning_run_logged(cmdp_agent_t* a, const cmdp_loop_desc* d, int64_t 
     for (int b = 0; b < B; ++b)
       if (!(d->base_val[3 * b] - d->base_val[3 * b + 1] > 0.0002))   // agent_mdp_interaction.py:379-382
         return fail(CMDP_ERR_INVALID, "instance %d: optimal and worst average reward are closer than 0.0002", b);
+  // refused before anything is stepped or reset: a caller that falls back to another loop must find the agent untouched
+  if (!episodic && log_every > 0 && chain_lds_bytes(h->max_S, h->max_row_nnz) > (size_t)kLdsBudget)
+    return fail(CMDP_ERR_UNSUPPORTED, "instance with %d states (max %d successors per row) exceeds the LDS budget of K9",
+                h->max_S, h->max_row_nnz);
+  if (!episodic && !h->has_dp) return fail(CMDP_ERR_INVALID, "the handle was created without the DP half (CSR transition matrices)");
   hipStream_t st = h->stream;
   const int64_t NS = h->n_states;
   Tracker tr;
@@ -2850,9 +3081,10 @@ int cmdp_qlearning_run_logged(cmdp_agent_t* a, const cmdp_loop_desc* d, int64_t 
     // tl-1, then step tl runs (whose update the logged policy already contains)
     if (tl - done > 0) {
       if (int rc = ql_enqueue_run(a, tl - done, a->d_mask.p, nullptr)) return rc;
-      HIP_TRY(hipMemcpyAsync(cum.p, a->d_rsum.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
       n_since += tl - done;
     }
+    // also when no step lies between two rows (log_every == 1): the sum through step tl-1, not the one of an earlier row
+    HIP_TRY(hipMemcpyAsync(cum.p, a->d_rsum.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
     if (int rc = ql_enqueue_run(a, 1, a->d_mask.p, nullptr)) return rc;
     done = tl + 1;
     if (int rc = log_row((int64_t)i, tl, n_since, true)) return rc;

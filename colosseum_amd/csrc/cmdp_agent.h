@@ -44,12 +44,23 @@ __global__ void k_fill_i32(int32_t* __restrict__ p, int32_t v, int64_t n) {
   if (i < n) p[i] = v;
 }
 
-template <int UCB>
+// RC: reference-exact reward caches (cmdp_reward_cache.h) -- a lane parks after a transition whose reward block is
+// missing; the relaunch (`resume`) completes the saved step first and continues with the steps the lane still owes.
+template <int UCB, bool RC>
 __global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, int64_t n_steps,
                                                          const uint8_t* __restrict__ train_mask,
-                                                         int8_t* __restrict__ act_trace, double* __restrict__ cum_reward) {
+                                                         int8_t* __restrict__ act_trace, double* __restrict__ cum_reward,
+                                                         RewardCache rc, int resume) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= t.B) return;
+  int64_t step0 = 0;
+  bool pending = false, parked = false;
+  if (RC && resume) {
+    const long long left = rc.left[b];
+    if (left == 0) return;
+    step0 = n_steps - left;
+    pending = rc.pend_e[b] >= 0;
+  }
   const int64_t soff = t.state_off[b], ebase = t.entry_base[b];
   const int S = (int)(t.state_off[b + 1] - soff);
   const int A = t.A, H = q.H;
@@ -68,33 +79,57 @@ __global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, 
   const bool train = train_mask ? train_mask[b] != 0 : true;
   // `self._cumulative_reward += new_ts.reward` (agent_mdp_interaction.py:291) continues across launches
   double sum = cum_reward[b];
-  for (int64_t step = 0; step < n_steps; ++step) {
-    // ---- QValuesActor.select_action: greedy with uniform tie-break --------------------------------------
-    const float* qrow = Q + ((int64_t)h * S + cur) * A;
-    float qmax = qrow[0];
-    for (int a = 1; a < A; ++a) qmax = fmaxf(qmax, qrow[a]);
-    int n_tie = 0;
-    for (int a = 0; a < A; ++a) n_tie += (qrow[a] == qmax) ? 1 : 0;
-    int pick = 0;
-    if (n_tie > 1) {  // RandomState.choice(ties) == ties[randint(0, n)]: masked rejection on 32-bit draws
-      const uint32_t mx = (uint32_t)(n_tie - 1);
-      uint32_t mask = mx;
-      mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-      int pos = *mtp;
-      uint32_t v;
-      do { v = mt_next_word(mt, pos) & mask; } while (v > mx);
-      *mtp = pos;
-      pick = (int)v;
-    }
+  int64_t step = step0;
+  for (; step < n_steps; ++step) {
     int action = 0;
-    for (int a = 0, k = 0; a < A; ++a)
-      if (qrow[a] == qmax) { if (k == pick) action = a; ++k; }
-    if (act_trace) act_trace[step * t.B + b] = (int8_t)action;
-    // ---- BaseMDP.step -------------------------------------------------------------------------------------------
-    const int32_t s_t = cur, time = h;
-    int32_t obs;
+    int32_t s_t, time, obs;
     double reward;
-    const int ty = env_step(t, soff, ebase, key, cur, h, nt, action, obs, reward);
+    int ty;
+    if (RC && pending) {  // the step this lane parked in: transition committed, reward and update outstanding
+      s_t = rc.pend_prev[b];
+      action = rc.pend_act[b];
+      time = h - 1;
+      ty = (h >= H) ? 2 : 1;
+      obs = (ty == 2) ? -1 : cur;
+    } else {
+      // ---- QValuesActor.select_action: greedy with uniform tie-break --------------------------------------
+      const float* qrow = Q + ((int64_t)h * S + cur) * A;
+      float qmax = qrow[0];
+      for (int a = 1; a < A; ++a) qmax = fmaxf(qmax, qrow[a]);
+      int n_tie = 0;
+      for (int a = 0; a < A; ++a) n_tie += (qrow[a] == qmax) ? 1 : 0;
+      int pick = 0;
+      if (n_tie > 1) {  // RandomState.choice(ties) == ties[randint(0, n)]: masked rejection on 32-bit draws
+        const uint32_t mx = (uint32_t)(n_tie - 1);
+        uint32_t mask = mx;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        int pos = *mtp;
+        uint32_t v;
+        do { v = mt_next_word(mt, pos) & mask; } while (v > mx);
+        *mtp = pos;
+        pick = (int)v;
+      }
+      for (int a = 0, k = 0; a < A; ++a)
+        if (qrow[a] == qmax) { if (k == pick) action = a; ++k; }
+      if (act_trace) act_trace[step * t.B + b] = (int8_t)action;
+      s_t = cur;
+      time = h;
+    }
+    // ---- BaseMDP.step -------------------------------------------------------------------------------------------
+    if (RC) {
+      double rraw = 0.0;
+      int64_t e;
+      if (pending) { e = rc.pend_e[b]; pending = false; }
+      else ty = env_transition(t, soff, ebase, key, cur, h, nt, action, obs, rraw, e);
+      if (!rc_fetch(t.sp_rkind, rc, e, rraw)) {
+        rc_park(rc, b, e, s_t, action);
+        parked = true;
+        break;
+      }
+      reward = rraw * t.rscale - t.rmin;
+    } else {
+      ty = env_step(t, soff, ebase, key, cur, h, nt, action, obs, reward);
+    }
     sum += reward;
     // ---- QValuesModel.step_update ---------------------------------------------------------------------------------
     if (train) {
@@ -152,6 +187,10 @@ __global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, 
   t.n_trans[b] = nt;
   t.n_reset[b] = nr;
   cum_reward[b] = sum;
+  if (RC) {
+    rc.left[b] = parked ? (long long)(n_steps - step) : 0;
+    if (!parked) rc.pend_e[b] = -1;
+  }
 }
 
 
@@ -361,11 +400,21 @@ struct QlcArgs {
   int32_t* mt_pos;
 };
 
+template <bool RC>
 __global__ void __launch_bounds__(256) k_qlearn_continuous(EnvTables t, QlcArgs q, int64_t n_steps,
                                                            const uint8_t* __restrict__ train_mask,
-                                                           int8_t* __restrict__ act_trace, double* __restrict__ cum_reward) {
+                                                           int8_t* __restrict__ act_trace, double* __restrict__ cum_reward,
+                                                           RewardCache rc, int resume) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= t.B) return;
+  int64_t step0 = 0;
+  bool pending = false, parked = false;
+  if (RC && resume) {
+    const long long left = rc.left[b];
+    if (left == 0) return;
+    step0 = n_steps - left;
+    pending = rc.pend_e[b] >= 0;
+  }
   const int64_t soff = t.state_off[b], ebase = t.entry_base[b];
   const int A = t.A;
   const uint2 key = t.philox_key ? t.philox_key[b] : make_uint2(0, 0);
@@ -380,31 +429,51 @@ __global__ void __launch_bounds__(256) k_qlearn_continuous(EnvTables t, QlcArgs 
   const double Hh = q.Hh[b], gamma = q.gamma[b];
   const bool train = train_mask ? train_mask[b] != 0 : true;
   double sum = cum_reward[b];
-  for (int64_t step = 0; step < n_steps; ++step) {
-    const double* qrow = Q + (int64_t)cur * A;
-    double qmax = qrow[0];
-    for (int a = 1; a < A; ++a) qmax = fmax(qmax, qrow[a]);
-    int n_tie = 0;
-    for (int a = 0; a < A; ++a) n_tie += (qrow[a] == qmax) ? 1 : 0;
-    int pick = 0;
-    if (n_tie > 1) {
-      const uint32_t mx = (uint32_t)(n_tie - 1);
-      uint32_t mask = mx;
-      mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-      int pos = *mtp;
-      uint32_t v;
-      do { v = mt_next_word(mt, pos) & mask; } while (v > mx);
-      *mtp = pos;
-      pick = (int)v;
-    }
+  int64_t step = step0;
+  for (; step < n_steps; ++step) {
     int action = 0;
-    for (int a = 0, k = 0; a < A; ++a)
-      if (qrow[a] == qmax) { if (k == pick) action = a; ++k; }
-    if (act_trace) act_trace[step * t.B + b] = (int8_t)action;
-    const int32_t s_t = cur;
-    int32_t obs;
+    int32_t s_t, obs;
     double reward;
-    env_step(t, soff, ebase, key, cur, h, nt, action, obs, reward);  // continuous: never terminates
+    if (RC && pending) {  // the step this lane parked in: transition committed, reward and update outstanding
+      s_t = rc.pend_prev[b];
+      action = rc.pend_act[b];
+      obs = cur;
+    } else {
+      const double* qrow = Q + (int64_t)cur * A;
+      double qmax = qrow[0];
+      for (int a = 1; a < A; ++a) qmax = fmax(qmax, qrow[a]);
+      int n_tie = 0;
+      for (int a = 0; a < A; ++a) n_tie += (qrow[a] == qmax) ? 1 : 0;
+      int pick = 0;
+      if (n_tie > 1) {
+        const uint32_t mx = (uint32_t)(n_tie - 1);
+        uint32_t mask = mx;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        int pos = *mtp;
+        uint32_t v;
+        do { v = mt_next_word(mt, pos) & mask; } while (v > mx);
+        *mtp = pos;
+        pick = (int)v;
+      }
+      for (int a = 0, k = 0; a < A; ++a)
+        if (qrow[a] == qmax) { if (k == pick) action = a; ++k; }
+      if (act_trace) act_trace[step * t.B + b] = (int8_t)action;
+      s_t = cur;
+    }
+    if (RC) {
+      double rraw = 0.0;
+      int64_t e;
+      if (pending) { e = rc.pend_e[b]; pending = false; }
+      else env_transition(t, soff, ebase, key, cur, h, nt, action, obs, rraw, e);  // continuous: never terminates
+      if (!rc_fetch(t.sp_rkind, rc, e, rraw)) {
+        rc_park(rc, b, e, s_t, action);
+        parked = true;
+        break;
+      }
+      reward = rraw * t.rscale - t.rmin;
+    } else {
+      env_step(t, soff, ebase, key, cur, h, nt, action, obs, reward);  // continuous: never terminates
+    }
     sum += reward;
     if (train) {
       const int64_t idx = (int64_t)s_t * A + action;
@@ -428,4 +497,8 @@ __global__ void __launch_bounds__(256) k_qlearn_continuous(EnvTables t, QlcArgs 
   t.hstep[b] = h;
   t.n_trans[b] = nt;
   cum_reward[b] = sum;
+  if (RC) {
+    rc.left[b] = parked ? (long long)(n_steps - step) : 0;
+    if (!parked) rc.pend_e[b] = -1;
+  }
 }

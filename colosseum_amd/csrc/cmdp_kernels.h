@@ -13,6 +13,7 @@
 #pragma once
 #include <type_traits>
 #include "cmdp_device.h"
+#include "cmdp_reward_cache.h"
 
 struct __attribute__((aligned(32))) RowDesc {  // 32 B, one per (instance, state, action): ONE load per transition
   int32_t first;         // first entry of the row, relative to the instance's entry base
@@ -104,14 +105,13 @@ __device__ __forceinline__ int32_t env_reset(const EnvTables& t, int b, int64_t 
   return s;
 }
 
-// BaseMDP.step (reference colosseum/mdp/base.py:1293-1317) for one instance.
-// Returns the step type (1 MID, 2 LAST); `action` < 0 requests the Philox random-policy action.
-// BETA = false compiles the Beta-reward sampler (Marsaglia-Tsang gammas: log/pow/cos in float64, ~100 VGPRs) out of
-// the kernel: handles without stochastic rewards then run at twice the occupancy.
-template <bool BETA = true>
-__device__ __forceinline__ int env_step(const EnvTables& t, int64_t soff, int64_t ebase, uint2 key, int32_t& cur,
-                                        int32_t& h, unsigned long long& n_trans, int action, int32_t& obs,
-                                        double& reward) {
+// BaseMDP.step (reference colosseum/mdp/base.py:1293-1317) for one instance, up to (not including) the reward sample:
+// action -> successor, visit counts, in-episode time.  Returns the step type (1 MID, 2 LAST); `action` < 0 requests the
+// Philox random-policy action; `e` receives the global entry of the transition taken, `rraw` its deterministic reward /
+// distribution mean before the range rescale.
+__device__ __forceinline__ int env_transition(const EnvTables& t, int64_t soff, int64_t ebase, uint2 key, int32_t& cur,
+                                              int32_t& h, unsigned long long& n_trans, int& action, int32_t& obs,
+                                              double& rraw, int64_t& e) {
   const unsigned long long n = n_trans;
   if (action < 0) action = philox_action(n, key, t.A);
   n_trans++;
@@ -119,8 +119,8 @@ __device__ __forceinline__ int env_step(const EnvTables& t, int64_t soff, int64_
   const int64_t r = (soff + cur) * t.A + action;
   const RowDesc d = t.row[r];
   int32_t nxt = d.next_if_det;
-  double rraw = d.reward_if_det;
-  int64_t e = ebase + d.first;
+  rraw = d.reward_if_det;
+  e = ebase + d.first;
   if (d.n > 1) {  // NextStateSampler.sample (custom_samplers.py:59-72)
     double u;
     if (t.rng_mode == 0) {
@@ -134,11 +134,9 @@ __device__ __forceinline__ int env_step(const EnvTables& t, int64_t soff, int64_
     nxt = t.sp_next[e];
     rraw = t.sp_reward[e];
   }
-  if (BETA && t.sp_rkind && t.sp_rkind[e] == 1) rraw = philox_beta(t.sp_rp0[e], t.sp_rp1[e], n, key);  // throughput mode only
   // visit counts on the arrival node with the action taken at the departure node (base.py:1302-1303)
   bump(t.visits_s + soff + nxt);
   bump(t.visits_sa + (soff + nxt) * t.A + action);
-  reward = rraw * t.rscale - t.rmin;  // `r * (max - min) - min`, base.py:1205-1207
   cur = nxt;
   if (t.H > 0 && h >= t.H) {
     obs = -1;
@@ -146,6 +144,22 @@ __device__ __forceinline__ int env_step(const EnvTables& t, int64_t soff, int64_
   }
   obs = nxt;
   return 1;
+}
+
+// The whole step incl. the reward (`sample_reward`, base.py:1187-1207) for handles whose rewards are deterministic or
+// sampled on the device.  BETA = false compiles the Beta-reward sampler (Marsaglia-Tsang gammas: log/pow/cos in float64,
+// ~100 VGPRs) out of the kernel: handles without stochastic rewards then run at twice the occupancy.
+template <bool BETA = true>
+__device__ __forceinline__ int env_step(const EnvTables& t, int64_t soff, int64_t ebase, uint2 key, int32_t& cur,
+                                        int32_t& h, unsigned long long& n_trans, int action, int32_t& obs,
+                                        double& reward) {
+  const unsigned long long n = n_trans;
+  double rraw;
+  int64_t e;
+  const int ty = env_transition(t, soff, ebase, key, cur, h, n_trans, action, obs, rraw, e);
+  if (BETA && t.sp_rkind && t.sp_rkind[e] == 1) rraw = philox_beta(t.sp_rp0[e], t.sp_rp1[e], n, key);  // throughput mode only
+  reward = rraw * t.rscale - t.rmin;  // `r * (max - min) - min`, base.py:1205-1207
+  return ty;
 }
 
 __global__ void k_reset(EnvTables t, const uint8_t* __restrict__ mask, int32_t* __restrict__ obs_out) {
@@ -171,11 +185,26 @@ __global__ void k_check_actions(const int32_t* __restrict__ actions, int B, int 
   if (b < B && (actions[b] < 0 || actions[b] >= A)) atomicOr(flag, 2);
 }
 
+// RC: reference-exact reward caches (cmdp_reward_cache.h).  A lane whose reward block is missing parks after the
+// transition; the relaunch (`resume` != 0) only completes the parked lanes.
+template <bool RC>
 __global__ void k_step(EnvTables t, const int32_t* __restrict__ actions, int auto_reset, int32_t* __restrict__ obs,
-                       double* __restrict__ reward, uint8_t* __restrict__ step_type) {
+                       double* __restrict__ reward, uint8_t* __restrict__ step_type, RewardCache rc, int resume) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= t.B) return;
   const int64_t soff = t.state_off[b];
+  if (RC && resume) {
+    const int32_t pe = rc.pend_e[b];
+    if (pe < 0) return;
+    double rraw = 0.0;
+    if (!rc_fetch(t.sp_rkind, rc, pe, rraw)) {  // cannot happen after an install; parks again rather than inventing a value
+      rc_park(rc, b, pe, rc.pend_prev[b], rc.pend_act[b]);
+      return;
+    }
+    rc.pend_e[b] = -1;
+    reward[b] = rraw * t.rscale - t.rmin;
+    return;
+  }
   if (t.need_reset[b]) {  // only reachable with auto_reset (the host pre-checks otherwise): step() == reset()
     unsigned long long nr = t.n_reset[b];
     const int32_t s = env_reset(t, b, soff, t.philox_key ? t.philox_key[b] : make_uint2(0, 0), nr);
@@ -191,8 +220,19 @@ __global__ void k_step(EnvTables t, const int32_t* __restrict__ actions, int aut
   int32_t cur = t.cur[b], h = t.hstep[b], o;
   unsigned long long nt = t.n_trans[b];
   double r;
-  const int ty = env_step(t, soff, t.entry_base[b], t.philox_key ? t.philox_key[b] : make_uint2(0, 0), cur, h, nt,
-                          actions[b], o, r);
+  int ty;
+  const uint2 key = t.philox_key ? t.philox_key[b] : make_uint2(0, 0);
+  if (RC) {
+    const int32_t prev = cur;
+    int a = actions[b];
+    double rraw;
+    int64_t e;
+    ty = env_transition(t, soff, t.entry_base[b], key, cur, h, nt, a, o, rraw, e);
+    if (rc_fetch(t.sp_rkind, rc, e, rraw)) r = rraw * t.rscale - t.rmin;
+    else { rc_park(rc, b, e, prev, a); r = 0.0; }
+  } else {
+    ty = env_step(t, soff, t.entry_base[b], key, cur, h, nt, actions[b], o, r);
+  }
   t.cur[b] = cur;
   t.hstep[b] = h;
   t.n_trans[b] = nt;
@@ -204,34 +244,79 @@ __global__ void k_step(EnvTables t, const int32_t* __restrict__ actions, int aut
 
 // The env side of MDPLoop.run's loop (reference colosseum/experiment/agent_mdp_interaction.py:238-298),
 // fused: n_steps transitions per instance, every termination followed at once by reset().
-// POLICY 0: Philox random action; 1: actions[t][B] (int8).
-// POLICY 0: on-device uniform random; 1: host action stream; 2: greedy in a Q table (`qtab`: per instance [S][A], or
-// [H][S][A] indexed by the in-episode time when the handle is episodic), first maximiser.
-template <int POLICY, bool TRACE, bool BETA>
+// POLICY 0: on-device uniform random (Philox); 1: host action stream actions[t][B] (int8); 2: greedy in a Q table
+// (`qtab`: per instance [S][A], or [H][S][A] indexed by the in-episode time when the handle is episodic), first maximiser.
+// RC: reference-exact reward caches -- a lane parks when its block is missing and the relaunch (`resume`) continues it
+// where it stopped, first completing the saved step (cmdp_reward_cache.h); `reward_sum` then accumulates across the
+// launches of one call (the host zeroes it first).
+template <int POLICY, bool TRACE, bool BETA, bool RC = false>
 __global__ void __launch_bounds__(256) k_rollout(EnvTables t, const int8_t* __restrict__ actions, int64_t n_steps,
                                                  double* __restrict__ reward_sum, int32_t* __restrict__ last_obs,
                                                  int32_t* __restrict__ tr_obs, double* __restrict__ tr_rew,
-                                                 uint8_t* __restrict__ tr_type, const float* __restrict__ qtab = nullptr) {
+                                                 uint8_t* __restrict__ tr_type, const float* __restrict__ qtab = nullptr,
+                                                 RewardCache rc = RewardCache{}, int resume = 0) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= t.B) return;
+  int64_t s0 = 0;
+  bool pending = false;
+  if (RC && resume) {
+    const long long left = rc.left[b];
+    if (left == 0) return;
+    s0 = n_steps - left;
+    pending = rc.pend_e[b] >= 0;
+  }
   const int64_t soff = t.state_off[b], ebase = t.entry_base[b];
   const int64_t S_b = t.state_off[b + 1] - soff;
   const uint2 key = t.philox_key ? t.philox_key[b] : make_uint2(0, 0);
   int32_t cur = t.cur[b], h = t.hstep[b], obs = cur;
   unsigned long long nt = t.n_trans[b], nr = t.n_reset[b];
-  double sum = 0.0;
-  for (int64_t s = 0; s < n_steps; ++s) {
-    int a = -1;
-    if (POLICY == 1) a = (int)actions[s * t.B + b];
-    if (POLICY == 2) {
-      const float* q = qtab + ((t.H > 0 ? (int64_t)t.H * soff + (int64_t)h * S_b : soff) + cur) * t.A;
-      float best = q[0];
-      a = 0;
-      for (int k = 1; k < t.A; ++k)
-        if (q[k] > best) { best = q[k]; a = k; }
-    }
+  double sum = (RC && resume) ? reward_sum[b] : 0.0;
+  bool parked = false;
+  int64_t s = s0;
+  for (; s < n_steps; ++s) {
     double r;
-    const int ty = env_step<BETA>(t, soff, ebase, key, cur, h, nt, a, obs, r);
+    int ty;
+    if (RC) {
+      int a = -1;
+      int32_t prev = cur;
+      double rraw = 0.0;
+      int64_t e;
+      if (pending) {  // the step this lane parked in: transition committed, reward outstanding
+        e = rc.pend_e[b];
+        prev = rc.pend_prev[b];
+        a = rc.pend_act[b];
+        ty = (t.H > 0 && h >= t.H) ? 2 : 1;
+        obs = (ty == 2) ? -1 : cur;
+        pending = false;
+      } else {
+        if (POLICY == 1) a = (int)actions[s * t.B + b];
+        if (POLICY == 2) {
+          const float* q = qtab + ((t.H > 0 ? (int64_t)t.H * soff + (int64_t)h * S_b : soff) + cur) * t.A;
+          float best = q[0];
+          a = 0;
+          for (int k = 1; k < t.A; ++k)
+            if (q[k] > best) { best = q[k]; a = k; }
+        }
+        ty = env_transition(t, soff, ebase, key, cur, h, nt, a, obs, rraw, e);
+      }
+      if (!rc_fetch(t.sp_rkind, rc, e, rraw)) {
+        rc_park(rc, b, e, prev, a);
+        parked = true;
+        break;
+      }
+      r = rraw * t.rscale - t.rmin;
+    } else {
+      int a = -1;
+      if (POLICY == 1) a = (int)actions[s * t.B + b];
+      if (POLICY == 2) {
+        const float* q = qtab + ((t.H > 0 ? (int64_t)t.H * soff + (int64_t)h * S_b : soff) + cur) * t.A;
+        float best = q[0];
+        a = 0;
+        for (int k = 1; k < t.A; ++k)
+          if (q[k] > best) { best = q[k]; a = k; }
+      }
+      ty = env_step<BETA>(t, soff, ebase, key, cur, h, nt, a, obs, r);
+    }
     sum += r;
     if (TRACE) {
       if (tr_obs) tr_obs[s * t.B + b] = obs;
@@ -248,6 +333,10 @@ __global__ void __launch_bounds__(256) k_rollout(EnvTables t, const int8_t* __re
   t.hstep[b] = h;
   t.n_trans[b] = nt;
   t.n_reset[b] = nr;
+  if (RC) {
+    rc.left[b] = parked ? (long long)(n_steps - s) : 0;
+    if (!parked) rc.pend_e[b] = -1;
+  }
   if (reward_sum) reward_sum[b] = sum;
   if (last_obs) last_obs[b] = obs;
 }

@@ -43,6 +43,8 @@ class _BatchedLoop:
             try:
                 return self._run_native(T, log_every, max_time)
             except L.CmdpError as e:  # e.g. a continuous instance beyond the LDS budget of the chain kernel K9
+                # cmdp_qlearning_run_logged refuses such a batch BEFORE it resets or steps anything, so the agent the
+                # Python-driven loop starts from is the untouched one
                 if e.code != L.ERR_UNSUPPORTED:
                     raise
         return self._run_python(T, log_every, max_time)
@@ -73,11 +75,14 @@ class _BatchedLoop:
         log_ts = [t for t in range(log_every, T, log_every)] if log_every and log_every > 0 else []
         for tl in log_ts:
             # the reference reads `_cumulative_reward` at step tl BEFORE adding that step's reward: stop after step
-            # tl-1 to read the sum, then execute step tl (whose update the logged policy already contains)
+            # tl-1 to read the sum, then execute step tl (whose update the logged policy already contains); when no step
+            # lies between two rows (log_every == 1) that sum is what the previous row's single step returned
             if tl - done > 0:
                 cum = agent.run(tl - done, train=mask)["cumulative_reward"]
                 n_since += tl - done
-            agent.run(1, train=mask)
+            elif done > 0:
+                cum = cum_after
+            cum_after = agent.run(1, train=mask)["cumulative_reward"]
             done = tl + 1
             self._log(tl, cum, n_since, T, in_loop=True)
             if max_time - (time() - timer) < 0.5:  # `_limit_exceeded` (agent_mdp_interaction.py:172-177) for the batch

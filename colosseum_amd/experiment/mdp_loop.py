@@ -126,7 +126,9 @@ class MDPLoop:
         else:
             tr.update(t, T, lambda need: [self._policy_average_reward()], np.array([self._cumulative_reward]),
                       self._n_since_log, in_loop)
-        row = tr.tables()[0][-1]
+        # the row from the columns just appended (what `tr.tables()[0][-1]` would materialise, without re-stacking every
+        # earlier row of every column at every logging step)
+        row = {"steps": t, **{k: v.round5().scalar(0) for k, v in tr.last_cols.items()}}
         self._last_logs = {"steps": t, **{k: v.scalar(0) for k, v in tr.last_cols.items()}}
         self.logger.write(row)
 

@@ -285,6 +285,9 @@ def build_model(
     # the MDP's numpy stream, positioned exactly where the reference's `mdp._rng` stands after construction: the
     # reward caches (mdp/base.py:1196-1203) and `random_step` (:1336,1353) continue from here
     model.extra["rng"] = rng
+    # the same position as an immutable snapshot: batched handles with reference-exact reward caches
+    # (CMDP_FLAG_REWARD_CACHE) continue a COPY of the stream, whatever a host sampler did to the object above meanwhile
+    model.extra["rng_state"] = rng.get_state()
     model.extra["successors"] = [[index[x] for x in adjacency[n]] for n in nodes]  # networkx adjacency order
     if episodic:
         model.H = _time_horizon(model, family, H)

@@ -88,7 +88,17 @@ enum {
   /* Accept entries with sp_rkind != 0 (stochastic reward distributions) and report sp_reward -- which then holds
      the distribution MEAN -- as the reward of such transitions.  For callers that sample those rewards themselves
      (the reference-exact host sampler of colosseum_amd/mdp/reward_sampler.py) or only need expectations. */
-  CMDP_FLAG_REWARD_MEANS = 1
+  CMDP_FLAG_REWARD_MEANS = 1,
+  /* REFERENCE-EXACT stochastic rewards for a whole batch: BaseMDP.sample_reward (colosseum/mdp/base.py:1187-1207) keeps a
+     FIFO cache of 5000 samples per visited (node, action, next_node) triple, drawn from the MDP's single numpy stream
+     `self._rng` when the triple is first needed and whenever its cache runs dry, so the draw order follows the
+     trajectory.  With this flag the device serves rewards from such caches in HBM; an instance that needs a block it does
+     not have parks (its transition committed, the step unfinished), the host draws the block from that instance's own
+     stream with numpy's legacy Beta sampler (cmdp_set_reward_streams positions the streams; csrc/cmdp_reward_cache.h)
+     and the kernel is relaunched -- inside cmdp_step, cmdp_rollout, cmdp_qlearning_run and cmdp_qlearning_run_logged.
+     Needs sp_rp0 / sp_rp1 and the CSR layout; the transition streams are whatever rng_mode says (CMDP_RNG_MT_COMPAT for
+     the reference's).  Rollouts run on the lane-per-instance kernel; cmdp_rollout_async is synchronous in this mode. */
+  CMDP_FLAG_REWARD_CACHE = 2
 };
 
 typedef struct cmdp cmdp_t;
@@ -150,6 +160,20 @@ int cmdp_destroy(cmdp_t* h);
 /* Handle's HIP stream (a hipStream_t) so that a caller can time it with HIP events. */
 void* cmdp_stream(cmdp_t* h);
 
+/* CMDP_FLAG_REWARD_CACHE: hands over `BaseMDP._rng` (colosseum/mdp/base.py:408) of every instance as
+   numpy.random.RandomState.get_state() leaves it after the MDP's construction: mt_key [B][624], mt_pos [B] (0..624),
+   has_gauss [B] and cached_gaussian [B] (either may be NULL = 0).  The library continues these streams whenever it
+   fills a reward cache.  May be called again to reposition the streams (e.g. a new run on a fresh copy). */
+int cmdp_set_reward_streams(cmdp_t* h, const uint32_t* mt_key, const int32_t* mt_pos, const int32_t* has_gauss,
+                            const double* cached_gaussian);
+/* `RandomState.beta(a, b, n)` on a caller-held stream state (updated in place): numpy's LEGACY sampler
+   (numpy/random/src/legacy/legacy-distributions.c: Johnk for a, b <= 1, else Ga / (Ga + Gb) with Marsaglia-Tsang /
+   Ahrens-Dieter gammas on the polar Gaussian) -- what scipy.stats.beta(a, b).rvs(n, random_state=rs) draws in
+   BaseMDP.sample_reward.  Host only (libm); exists so that the CPU test suite can hold the sampler the reward caches are
+   filled with against numpy itself, draw for draw. */
+int cmdp_legacy_beta(uint32_t* mt_key, int32_t* mt_pos, int32_t* has_gauss, double* cached_gaussian, double a, double b,
+                     int64_t n, double* out);
+
 /* ---- interaction: BaseMDP.reset / BaseMDP.step -------------------------------------------------- */
 /* BaseMDP.reset (colosseum/mdp/base.py:1268-1277) on every instance with mask[b] != 0 (all when mask
    is NULL): h = 0, start state sampled, its state-visit count bumped.  obs_out[b] = start state index
@@ -179,7 +203,9 @@ int cmdp_synchronize(cmdp_t* h);
    CMDP_STAT_DP_KERNEL_MS: HIP-event time, on the handle's stream, of the sweep kernel of the last
    cmdp_vi_discounted / cmdp_pe_discounted (kernel only: no upload, no result copy).
    CMDP_STAT_DP_KERNEL: which kernel that was -- 1 K2 (workgroup, CSR in LDS/HBM), 2 K2R, 5 K2U, 7 K2W, 6 K3 (Gauss-Seidel). */
-enum { CMDP_STAT_DP_KERNEL_MS = 1, CMDP_STAT_DP_KERNEL = 2 };
+enum { CMDP_STAT_DP_KERNEL_MS = 1, CMDP_STAT_DP_KERNEL = 2,
+       CMDP_STAT_REWARD_FILLS = 3,   /* CMDP_FLAG_REWARD_CACHE: blocks of 5000 samples drawn so far                */
+       CMDP_STAT_REWARD_ROUNDS = 4   /* ... and park / fill / relaunch rounds                                        */ };
 int cmdp_stat(cmdp_t* h, int which, double* out);
 /* Latency floor of the LDS-resident rollout kernels, measured on the current device: one wavefront per CU follows
    per-lane uint16 tables in LDS for n_steps dependent reads.  CMDP_CALIB_LDS_READ: the bare dependent ds_read_u16

@@ -29,6 +29,7 @@ Fixture groups:
   G10 MDPLoop + QLearningContinuous logger rows (continuous-setting regret via stationary distributions)
   G9  stationary distributions / average rewards of the continuous setting
   G8  trajectories with Beta rewards (the MDP's numpy stream, 5000-sample caches per visited triple)
+  G17 MDPLoop + Q-learning agents on MDPs with Beta rewards (benchmark parameterisations): rows, actions, tables
 """
 import json
 import os
@@ -1169,7 +1170,84 @@ def g16():
         json.dump(rows, f, indent=0)
 
 
-GROUPS = dict(G16=g16, G15=g15, G14=g14, G13=g13, G12=g12, G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11)
+def g17():
+    """The reference's MDPLoop + tabular Q-learning agents on MDPs with STOCHASTIC (Beta) rewards -- parameterisations of
+    the default benchmark suites (make_reward_stochastic=True; G11) -- long enough that reward caches are refilled: the
+    agent's actions depend on the sampled rewards, the order in which (s, a, s') triples draw their 5000-sample blocks
+    from the MDP's numpy stream depends on the actions.  Golden: logger rows, action stream, final tables."""
+    import importlib
+    import types
+
+    from colosseum.experiment.agent_mdp_interaction import MDPLoop
+    from colosseum.utils.acme.specs import make_mdp_spec
+
+    QLearningEpisodic = _import_reference_qlearning()
+    name = "colosseum.agent.agents.infinite_horizon"
+    if name not in sys.modules:
+        try:
+            importlib.import_module(name)
+        except Exception:
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(ref_env.REFERENCE, "colosseum", "agent", "agents", "infinite_horizon")]
+            sys.modules[name] = m
+    from colosseum.agent.agents.infinite_horizon.q_learning import QLearningContinuous
+
+    hp_e = dict(p=0.05, UCB_type="bernstein", c_1=0.9415278732894797, c_2=0.013873778519317169, min_at=0.07263563483119442)
+    hp_c = dict(h_weight=0.942, span_approx_weight=0.014, min_at=0.073)
+    bench = json.load(open(os.path.join(OUT, "G11_benchmark_configs.json")))
+    picks = [  # (suite, class, scope, seed, T, log_every)
+        # 8 000 episodes of 5 steps: the first transition of the policy the agent settles on is taken > 5 000 times, so its
+        # cache runs dry and is refilled from wherever the stream stands then
+        ("benchmark_episodic_communicating", "DeepSeaEpisodic", "prms_0", 0, 40_000, 1000),
+        ("benchmark_episodic_communicating", "FrozenLakeEpisodic", "prms_0", 1, 12_000, 500),
+        ("benchmark_episodic_ergodic", "FrozenLakeEpisodic", "prms_0", 2, 12_000, 1000),
+        ("benchmark_continuous_communicating", "FrozenLakeContinuous", "prms_0", 0, 16_000, 500),
+        ("benchmark_continuous_ergodic", "FrozenLakeContinuous", "prms_0", 3, 12_000, 1000),
+    ]
+    cases, arrays = [], {}
+    for suite, cls, scope, seed, T, log_every in picks:
+        kw = dict(bench[suite]["mdp_configs"][cls][scope])
+        assert kw.get("make_reward_stochastic")
+        mdp_kw = dict(seed=seed, **kw)
+        mdp = CLASSES[cls](**mdp_kw)
+        episodic = cls.endswith("Episodic")
+        agent_cls, hp = (QLearningEpisodic, hp_e) if episodic else (QLearningContinuous, hp_c)
+        agent = agent_cls(seed=seed, mdp_specs=make_mdp_spec(mdp), optimization_horizon=T, **hp)
+        actions = []
+        sel = agent.select_action
+
+        def select_action(ts, h, _sel=sel, _log=actions):
+            a = _sel(ts, h)
+            _log.append(int(a))
+            return a
+
+        agent.select_action = select_action
+        loop = MDPLoop(mdp, agent)
+        last_training_step, _ = loop.run(T=T, log_every=log_every)
+        rows = [{k: float(v) for k, v in r.items() if k != "steps_per_second"} for r in loop.logger.data]
+        model = agent._mdp_model
+        n_blocks = len(mdp._cached_rewards)
+        key = f"c{len(cases)}_"
+        rew = np.asarray(loop.actions_sequence, np.float64)  # MDPLoop.actions_sequence holds the REWARDS (sic, :246)
+        arrays[key + "actions"] = np.asarray(actions, np.int8)
+        arrays[key + "rewards_every_8th"] = rew[::8]
+        arrays[key + "Q_final"] = np.asarray(model.Q)
+        arrays[key + "N_final"] = np.asarray(model.N)
+        acc = 0.0
+        for r in rew.tolist():
+            acc += r  # `self._cumulative_reward += new_ts.reward`: sequential float64
+        cases.append(dict(suite=suite, mdp_scope=scope, mdp_cls=cls, mdp_kwargs=mdp_kw,
+                          agent="QLearningEpisodic" if episodic else "QLearningContinuous",
+                          agent_kwargs=dict(seed=seed, optimization_horizon=T, **hp), T=T, log_every=log_every,
+                          last_training_step=int(last_training_step), rows=rows, visited_triples=n_blocks,
+                          reward_sum=acc, is_training_at_end=bool(loop._is_training)))
+        print("   ", cls, mdp_kw, "rows", len(rows), "cum reward", rows[-1]["cumulative_reward"], "triples", n_blocks,
+              "Q dtype", np.asarray(model.Q).dtype, "training", loop._is_training)
+    arrays["cases"] = np.array(json.dumps(cases))
+    save("G17_mdploop_beta_rewards", **arrays)
+
+
+GROUPS = dict(G17=g17, G16=g16, G15=g15, G14=g14, G13=g13, G12=g12, G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

@@ -200,3 +200,39 @@ def test_device_continuous_qlearning_and_batched_loop(need_gpu):
         _assert_same_rows(rows, loop.run(T=c["T"], log_every=c["log_every"]))
         ag.close()
         env.close()
+
+
+def test_log_every_one_reads_the_reward_sum_of_the_previous_step(need_gpu):
+    """A row at EVERY step (log_every = 1): no step lies between two rows, and the logged `cumulative_reward` must still be
+    the sum through step t-1 (agent_mdp_interaction.py:291 adds the reward after the row is written) -- in the one-call
+    loop, in the Python-driven loop, and equal to the per-instance MDPLoop with the numpy agent."""
+    from colosseum_amd.experiment import MDPLoop, make_mdp_spec
+    from colosseum_amd.experiment.batched_loop import BatchedEpisodicLoop
+    from colosseum_amd.mdp import gpu_mdp
+
+    kw = dict(seed=3, size=5, p_rand=0.2)
+    hp = dict(p=0.05, UCB_type="bernstein", c_1=0.9415278732894797, c_2=0.013873778519317169, min_at=0.07263563483119442)
+    m = make_model("DeepSeaEpisodic", **kw)
+    T = 60
+    runs = []
+    for native in (True, False):
+        env = BatchedMDP([m, m], rng_mode=L.RNG_MT_COMPAT)
+        ag = BatchedQLearningEpisodic(env, [3, 3], optimization_horizon=T, **hp)
+        loop = BatchedEpisodicLoop(env, ag)
+        loop.native = native
+        runs.append(loop.run(T=T, log_every=1))
+        ag.close()
+        env.close()
+    _assert_same_rows(*runs)
+    mdp = gpu_mdp.DeepSeaEpisodic(**kw)
+    agent = QLearningEpisodic(seed=3, mdp_specs=make_mdp_spec(mdp), optimization_horizon=T, **hp)
+    host = MDPLoop(mdp, agent)
+    host.run(T=T, log_every=1)
+    assert len(host.logger.data) == len(runs[0][0]) == T - 1 + 1
+    cums = [float(r["cumulative_reward"]) for r in runs[0][0]]
+    assert len(set(cums)) > 3  # the sum moves from row to row
+    for got, ref in zip(runs[0][0], host.logger.data):
+        for k in ref:
+            if k != "steps_per_second":
+                assert float(got[k]) == pytest.approx(float(ref[k]), rel=1e-6, abs=1e-5), (k, got["steps"])
+    mdp.close()

@@ -102,10 +102,11 @@ def test_time_limit_ledger_and_resume(need_gpu, tmp_path):
 def test_c4_full_enumeration_of_the_four_default_suites(need_gpu):
     """Config C4 with the FULL instance enumeration of the reference's four default benchmark suites (every family x gin
     setting x 20 seeds = 1 000 instances; `benchmark/experiment_config.yml`) at a reduced step count, and one instance of
-    every (suite, MDP class, setting) cross-checked against the per-instance path `GpuMDP` + `MDPLoop` + numpy agent
-    (bit-equal to the reference loop, tests/test_gpu_mdploop.py) where the batch runs reference-exact streams
-    (deterministic rewards -> MT_COMPAT); Beta-reward settings run Philox streams on the device and are compared with
-    the same instance run alone."""
+    EVERY (suite, MDP class, setting) -- the 16 deterministic-reward and the 34 Beta-reward ones alike -- cross-checked
+    against the per-instance path `GpuMDP` + `MDPLoop` + numpy agent (bit-equal to the reference loop,
+    tests/test_gpu_mdploop.py; its Beta rewards come from numpy's own `RandomState.beta` continuing the MDP's stream,
+    tests/test_rewards.py).  The batch runs the reference's streams throughout: MT19937 transition samplers and, for Beta
+    rewards, the reference's per-triple caches of 5000 samples (CMDP_FLAG_REWARD_CACHE) -- no self-comparison."""
     from colosseum_amd.experiment import MDPLoop, make_mdp_spec
     from colosseum_amd.mdp import gpu_mdp
     from helpers_agents import QLearningContinuous, QLearningEpisodic
@@ -113,14 +114,14 @@ def test_c4_full_enumeration_of_the_four_default_suites(need_gpu):
     suites = ["benchmark_episodic_ergodic", "benchmark_episodic_communicating",
               "benchmark_continuous_ergodic", "benchmark_continuous_communicating"]
     n_steps, log_every = 1500, 500
-    total = checked = invariants = 0
+    total = checked = checked_beta = 0
     settings = set()
     for suite in suites:
         allcfg = json.load(open(os.path.join(GOLDEN, "G11_benchmark_configs.json")))[suite]
         assert allcfg["experiment_config"]["n_seeds"] == 20
         instances = bm.enumerate_instances(allcfg["mdp_configs"], n_seeds=20)
         total += len(instances)
-        results = bm.run_instances(instances, n_steps=n_steps, log_every=log_every)
+        results = bm.run_instances(instances, n_steps=n_steps, log_every=log_every, beta_rewards="reference")
         assert sorted(results) == list(range(len(instances)))
         seen = set()
         for i, ins in enumerate(instances):
@@ -131,20 +132,10 @@ def test_c4_full_enumeration_of_the_four_default_suites(need_gpu):
             assert last["optimal_normalized_cumulative_expected_reward"] >= n_steps - 1  # t + optimal / (optimal - worst)
             key = (suite, ins.mdp_cls, ins.mdp_scope)
             settings.add(key)
-            if key in seen:
+            # one seed per setting, a different one from setting to setting
+            if key in seen or ins.seed != len(seen) % 20:
                 continue
             seen.add(key)
-            if ins.mdp_kwargs.get("make_reward_stochastic"):
-                # Beta rewards: the batch samples them on the device from the instance's Philox stream (the
-                # reference-exact Beta stream is a per-step host path), so the cross-check is the same instance run
-                # ALONE: a row may not depend on what else is in the device batch
-                alone = bm.run_instances([ins], n_steps=n_steps, log_every=log_every)[0]
-                for got, ref in zip(rows, alone):
-                    for k in ref:
-                        if k != "steps_per_second":
-                            assert got[k] == ref[k] and type(got[k]) is type(ref[k]), (key, ins.seed, k)
-                invariants += 1
-                continue
             mdp = getattr(gpu_mdp, ins.mdp_cls)(seed=ins.seed, **ins.mdp_kwargs)
             agent_cls = QLearningEpisodic if ins.agent_cls == "QLearningEpisodic" else QLearningContinuous
             agent = agent_cls(seed=ins.seed, mdp_specs=make_mdp_spec(mdp), optimization_horizon=n_steps,
@@ -156,7 +147,26 @@ def test_c4_full_enumeration_of_the_four_default_suites(need_gpu):
                     if k != "steps_per_second":
                         assert float(got[k]) == pytest.approx(float(ref[k]), rel=1e-6, abs=1e-5), (key, ins.seed, k)
             checked += 1
+            checked_beta += bool(ins.mdp_kwargs.get("make_reward_stochastic"))
             mdp.close()
     print(f"C4: {total} instances over {len(settings)} (suite, class, setting) triples; {checked} cross-checked against "
-          f"the per-instance host loop, {invariants} Beta-reward settings against the instance run alone")
-    assert total == 1000 and len(settings) == 50 and checked == 16 and invariants == 34
+          f"the per-instance host loop, {checked_beta} of them with Beta rewards")
+    assert total == 1000 and len(settings) == 50 and checked == 50 and checked_beta == 34
+
+
+def test_c4_philox_reward_mode_is_batch_independent(need_gpu):
+    """The throughput mode of the runner (`beta_rewards="philox"`: Beta rewards sampled on the device from the instance's
+    counter-based stream) is distribution-exact, not stream-exact; what it must guarantee is that an instance's rows do
+    not depend on what else is in its device batch."""
+    allcfg = json.load(open(os.path.join(GOLDEN, "G11_benchmark_configs.json")))["benchmark_continuous_communicating"]
+    instances = [i for i in bm.enumerate_instances(allcfg["mdp_configs"], n_seeds=3)
+                 if i.mdp_cls == "FrozenLakeContinuous" and i.mdp_kwargs.get("make_reward_stochastic")]
+    assert len(instances) >= 3
+    results = bm.run_instances(instances, n_steps=1500, log_every=500, beta_rewards="philox")
+    alone = bm.run_instances(instances[1:2], n_steps=1500, log_every=500, beta_rewards="philox")[0]
+    for got, ref in zip(results[1], alone):
+        for k in ref:
+            if k != "steps_per_second":
+                assert got[k] == ref[k] and type(got[k]) is type(ref[k]), (k,)
+    exact = bm.run_instances(instances[1:2], n_steps=1500, log_every=500, beta_rewards="reference")[0]
+    assert exact[-1]["cumulative_reward"] != alone[-1]["cumulative_reward"]  # other streams, same distribution

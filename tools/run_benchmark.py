@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0")
     ap.add_argument("--max-time", type=float, help="seconds of training per instance (default: the experiment's max_interaction_time_s)")
+    ap.add_argument("--beta-rewards", default="reference", choices=["reference", "philox"],
+                    help="stochastic (Beta) rewards: 'reference' = the reference's per-triple caches of 5000 samples from the MDP's own "
+                         "numpy stream (rows equal the reference's); 'philox' = sampled on the device (distribution-exact, no host work)")
     ap.add_argument("--overwrite", action="store_true",
                     help="run every instance; default: skip those whose log file exists, as the reference's resume does")
     args = ap.parse_args()
@@ -80,20 +83,31 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=timeout)
         else:
             dist.init_process_group(args.dist_backend, timeout=timeout)
+    # log files are written as each device batch finishes (spawned writer processes: the text conversion must not hold
+    # the GIL of the threads driving the other batches), each file atomically: an interrupted run resumes from them
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+
+    writers = ProcessPoolExecutor(max_workers=max(1, min(16, (os.cpu_count() or 1) // world // 2)), mp_context=mp.get_context("spawn"))
+    pending = []
     results = bm.run_instances(instances, n_steps, log_every, rank, world, device=local, max_concurrent_groups=args.concurrent_groups, max_batch=args.max_batch,
-                               models=models, max_time=max_time, skip=skip,
+                               models=models, max_time=max_time, skip=skip, beta_rewards=args.beta_rewards,
+                               on_group_done=lambda idx, rows: pending.extend(bm.submit_group_logs(writers, args.out, instances, idx, rows)),
                                progress=lambda msg: print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True))
     t_run = time.time() - t0
-    bm.write_csv_logs(args.out, instances, results, workers=max(1, min(32, (os.cpu_count() or 1) // world)))
-    print(f"[rank {rank}] instances done in {t_run:.1f} s, logs written in {time.time() - t0 - t_run:.1f} s", file=sys.stderr, flush=True)
+    n_written = sum(f.result() for f in pending)
+    writers.shutdown()
+    assert n_written == len(results), (n_written, len(results))
+    print(f"[rank {rank}] instances done in {t_run:.1f} s, last log files written {time.time() - t0 - t_run:.1f} s later", file=sys.stderr, flush=True)
     lo, hi = shard_range(len(instances), rank, world)
     local_vec = (np.stack([bm.summary_vector(results[i]) if i in results else bm.read_summary(args.out, instances[i])
                            for i in range(lo, hi)]) if hi > lo else np.zeros((0, 3)))
     allv = gather_instances(local_vec, len(instances), dist,
                             device="cuda" if dist is not None and args.dist_backend == "nccl" else None)
     if rank == 0:
-        print(json.dumps(dict(instances=len(instances), skipped_existing=len(skip), steps_each=n_steps, wall_s=time.time() - t0,
-                              agent_steps_per_s=len(instances) * n_steps / (time.time() - t0),
+        n_run = len(instances) - len(skip)  # instances found on disk were not run: they do not count as throughput
+        print(json.dumps(dict(instances=len(instances), skipped_existing=len(skip), run=n_run, steps_each=n_steps, wall_s=time.time() - t0,
+                              beta_rewards=args.beta_rewards, agent_steps_per_s=n_run * n_steps / (time.time() - t0),
                               mean_normalized_cumulative_regret=float(allv[:, 1].mean()))))
     if dist is not None:
         dist.destroy_process_group()
