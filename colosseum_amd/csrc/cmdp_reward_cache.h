@@ -201,8 +201,10 @@ struct NumpyStream {  // `RandomState.get_state()`: MT19937 key + position, and 
 class Pool {
  public:
   static Pool& get() {
-    static Pool p;
-    return p;
+    // never destroyed: the detached workers wait on the condition variable for the life of the process, and destroying a
+    // condition variable that has waiters blocks (glibc) -- the process would hang in its exit handlers
+    static Pool* p = new Pool;
+    return *p;
   }
   // runs fn(i) for i in [0, n) on the workers and the calling thread; returns when all are done
   void parallel_for(int n, const std::function<void(int)>& fn) {
