@@ -159,7 +159,7 @@ class BatchedContinuousLoop(_BatchedLoop):
             pi_w = get_policy_from_q_values(env.split_rows(Qw)[b].reshape(S, A), True)
             pi_r = np.ones((S, A), np.float32) / A
             probs += [(T, R, pi_o, starts), (T, R, pi_w, starts), (T, R, pi_r, None)]
-        vals = get_average_reward_batch(probs)
+        vals = get_average_reward_batch(probs, builtin_sum=True)  # the MDP's properties, not get_average_reward
         self.cache = AverageRewardCache(self._TR)
         self.vt = ContinuousVectorTracker(*(MP.from_scalars(vals[j::3]) for j in range(3)),
                                           n_log_intervals_to_check_for_agent_optimality)

@@ -152,9 +152,12 @@ def _stationary_plan(tps: np.ndarray, starting_states_and_probs):
     return None, [(np.arange(n), None)]
 
 
-def get_average_reward_batch(problems) -> List[float]:
+def get_average_reward_batch(problems, builtin_sum: bool = False) -> List[float]:
     """`get_average_reward` for many (T, R, policy, starting_states_and_probs) at once: the recurrent-class bookkeeping
-    per problem on the host, ALL GTH eliminations in one device call."""
+    per problem on the host, ALL GTH eliminations in one device call.  `builtin_sum`: the final dot product as Python's
+    `sum(sd * ars)` (index order) instead of numpy's pairwise `.sum()` -- how `BaseMDP.optimal_average_reward` /
+    `worst_average_reward` / `random_average_reward` add it up (colosseum/mdp/base.py:895-941), which is what MDPLoop's
+    normalisers read (agent_mdp_interaction.py:362-386); the two differ by an ulp on some chains."""
     prepared, mats = [], []
     for T, R, policy, starts in problems:
         assert np.isclose(policy.sum(-1), 1).all(), "the policy specification is incorrect."
@@ -183,7 +186,7 @@ def get_average_reward_batch(problems) -> List[float]:
                     sd[cls] = x
                 else:
                     sd[cls] += w * x
-        out.append((ars * sd).sum())
+        out.append(sum(ars * sd) if builtin_sum else (ars * sd).sum())
     return out
 
 
