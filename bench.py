@@ -24,7 +24,13 @@ Objects on the line (prompt section 4; DESIGN.md section 4 explains every figure
                 roofline, bound = "hbm".
   vi            config C3 (FrozenLake 20x20 discounted value iteration to 1e-6): sweeps/s + its own roofline
                 (bound = "valu_issue": the CSR stays in registers, V in LDS).
-  cpu_baseline  the CPU oracle (oracle/cmdp_oracle.c, "port") timed on this host, one core, bounded sample
+  cpu_baseline  the CPU oracle (oracle/cmdp_oracle.c, "port") timed on this host, one core, bounded sample;
+                cpu_baseline_numpy: the numpy restatement (oracle/numpy_port.py); reference_in_container: the reference's
+                own per-step rate measured at survey time -- quoted, not re-measured
+  sustained     >= 10 s of back-to-back launches of the headline kernel after the timed region: achieved rate, the
+                engine clock and GPU-busy figure the SMI shows meanwhile (a witness for the burst number above)
+  strong        SURVEY 8(e)'s partition of 65 536 instances TOTAL over 8 GPUs, rehearsed on this GPU with one rank's
+                share (8 192 instances): what strong scaling of a latency-bound chain can give
 """
 import argparse
 import ctypes as C
@@ -99,6 +105,66 @@ def spawn_ranks(n, argv):
     return max(abs(rc) for rc in rcs)
 
 
+def smi_sample():
+    """(engine clock in MHz, busy percent) of the busiest card the SMI's sysfs files show, or (None, None)."""
+    import glob
+
+    best = (None, None)
+    for dev in glob.glob("/sys/class/drm/card*/device"):
+        try:
+            busy = int(open(dev + "/gpu_busy_percent").read().strip())
+            mhz = None
+            for ln in open(dev + "/pp_dpm_sclk").read().splitlines():
+                if ln.strip().endswith("*"):
+                    mhz = int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
+            if best[1] is None or busy > best[1]:
+                best = (mhz, busy)
+        except Exception:
+            continue
+    return best
+
+
+def sustained_leg(env, ev, launch_steps, seconds, B):
+    """Back-to-back launches of the headline kernel for >= `seconds`, in queue-sized bursts; the SMI's engine clock and
+    busy figure are sampled from sysfs by a thread meanwhile."""
+    import threading
+
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            samples.append(smi_sample())
+            stop.wait(0.25)
+
+    th = threading.Thread(target=sampler, daemon=True)
+    stream = env.stream
+    a, b = ev.create(), ev.create()
+    env.synchronize()
+    th.start()
+    t0 = time.perf_counter()
+    ev.record(a, stream)
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(64):
+            env.rollout_async(launch_steps)
+        n += 64
+        env.synchronize()
+    ev.record(b, stream)
+    ms = ev.elapsed_ms(a, b)
+    wall = time.perf_counter() - t0
+    stop.set()
+    th.join()
+    clocks = [c for c, _ in samples if c]
+    busy = [x for _, x in samples if x is not None]
+    return {
+        "seconds": wall, "launches": n, "value": n * B * launch_steps / (ms * 1e-3), "unit": "env steps/s",
+        "ms_per_launch": ms / n,
+        "sclk_mhz": {"min": min(clocks), "median": float(np.median(clocks)), "max": max(clocks), "samples": len(clocks)} if clocks else None,
+        "gpu_busy_percent": {"min": min(busy), "median": float(np.median(busy)), "max": max(busy)} if busy else None,
+        "smi_source": "/sys/class/drm/card*/device/{pp_dpm_sclk,gpu_busy_percent}, 4 Hz, busiest card",
+    }
+
+
 def pmc_entry(kernel_prefix, units_per_launch, build_id):
     """HBM bytes per launch of a kernel from the committed summary of this round's `--pmc FETCH_SIZE` / `--pmc
     WRITE_SIZE` passes (their own rocprofv3 runs, tools/collect_profiles.sh).  Returned only when the summary was
@@ -134,6 +200,11 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: ranks share the visible GPUs (device = local_rank %% n_devices)")
     ap.add_argument("--lds-groups", type=int, default=0, help="K1L workgroups per CU (0: library default; needs CMDP_K1L_PIPE=0)")
     ap.add_argument("--rollout-kernel", type=int, default=0, help="0 auto, 1 HBM tables, 2 LDS-resident K1L/K1P, 4 shared-table K1T")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --instances per GPU; strong: --instances in TOTAL, rank r takes the contiguous block "
+                         "[r*B/N, (r+1)*B/N) of SURVEY 8(e)")
+    ap.add_argument("--sustained-seconds", type=float, default=10.0, help="length of the sustained leg (0: skip)")
+    ap.add_argument("--strong-share", type=int, default=8, help="rehearse one rank's share of a strong split over this many GPUs (0: skip)")
     ap.add_argument("--layout", default="csr", choices=["csr", "dense"],
                     help="layout of the HEADLINE leg: csr (default, fastest) or dense (then --launch-steps applies to K1D)")
     args = ap.parse_args()
@@ -224,7 +295,11 @@ def main():
         return wall, [ev.elapsed_ms(marks[k], marks[k + 1]) for k in range(n_launch)]
 
     # ---- C2 workload: this rank's shard of DeepSeaEpisodic(seed=i, size=30), i in [rank*B, (rank+1)*B) ----
-    B = args.instances
+    if args.scaling == "strong":
+        assert args.instances % world == 0, "--scaling strong: --instances must be divisible by the number of ranks"
+        B = args.instances // world
+    else:
+        B = args.instances
     seeds = np.arange(rank * B, (rank + 1) * B, dtype=np.int64)
     t_build = time.time()
     dense_headline = args.layout == "dense"
@@ -263,6 +338,11 @@ def main():
             torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
         assert bool((allv[rank * B:(rank + 1) * B] == local).all())
+
+    # ---- sustained leg: back-to-back launches for >= --sustained-seconds, SMI sampled meanwhile (N = 1 only) -------------
+    sustained = None
+    if args.sustained_seconds > 0 and world == 1 and not dense_headline:
+        sustained = sustained_leg(env, ev, args.launch_steps, args.sustained_seconds, B)
 
     units_per_launch = B * args.launch_steps
     total_steps = world * units_per_launch * args.steps
@@ -333,7 +413,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "i32 state/visit indices, f64 rewards+CDF",
         "data": "synthetic",
@@ -352,6 +432,31 @@ def main():
     }
     if gather_ms is not None:
         line["gather_ms"] = gather_ms
+    if sustained is not None:
+        line["sustained"] = sustained
+
+    # ---- strong-scaling rehearsal: one rank's share of 65 536 instances TOTAL over `--strong-share` GPUs ---------------
+    if args.strong_share > 1 and world == 1 and args.scaling == "weak" and not dense_headline and B % args.strong_share == 0:
+        Bs = B // args.strong_share
+        senv = BatchedMDP(tables=deepsea_episodic_tables(seeds[:Bs], args.size, with_dp=False), rng_mode=L.RNG_PHILOX,
+                          philox_keys=keys[:Bs])
+        senv.reset()
+        if args.rollout_kernel:
+            senv.set_rollout_kernel(args.rollout_kernel)
+        s_wall, s_ms = timed_launches(senv, args.steps, args.launch_steps, args.warmup)
+        s_launch = float(np.mean(s_ms)) * 1e-3
+        line["strong"] = {
+            "what": "SURVEY 8(e): instance_id -> gpu = id*N/B.  %d instances in TOTAL over %d GPUs = %d per GPU, rehearsed on this "
+                    "GPU with rank 0's share; no data-path collective, so the N-GPU step time is one rank's step time" % (B, args.strong_share, Bs),
+            "instances_per_gpu": Bs, "n_gpus_modelled": args.strong_share, "lds_plan": senv.lds_plan(),
+            "ms_per_step": s_launch * 1e3, "env_steps_per_s_per_gpu": Bs * args.launch_steps / s_launch,
+            "implied_value_at_n_gpus": args.strong_share * Bs * args.launch_steps / s_launch,
+            "implied_speedup_vs_1_gpu": avg_launch_s / s_launch,
+            "note": "a launch lasts (rounds of workgroups) x (transitions) x (chain latency): with 1/8 of the instances a CU holds "
+                    "1/8 of the chains but the chain is as long, so the speed-up is far below 8 -- inherent to a latency-bound "
+                    "chain; weak scaling (65 536 per GPU, the default line) is what fills the chips",
+        }
+        senv.close()
 
     # ---- dense-row leg (north-star layout, K1D): same instances, rows streamed from HBM -------------------------
     dense_env = None
@@ -390,6 +495,7 @@ def main():
         t1 = time.perf_counter()
         Q, V, sw = dp.value_iteration(0.99, 1e-6, out=bufs)
         barrier()
+        vi_V, vi_sweeps = np.array(V, copy=True), np.array(sw, copy=True)
         vi_s = max_over_ranks(time.perf_counter() - t1)
         my_sweeps = float(sw.sum())
         sweeps = sum_over_ranks(my_sweeps)
@@ -490,13 +596,60 @@ def main():
                 "sample": "instances 0..%d, %d transitions each, %.1f s on %d threads (CPU quota of this box; %d host cores, %s)"
                           % (n_mt - 1, n_steps, mt_s, len(ranges), os.cpu_count() or 0, model),
             }
+        # ---- numpy restatement of the step loop (oracle/numpy_port.py), same Philox streams, checked against the
+        # C port: (i) one numpy operation per step over a slice of instances, (ii) one Python iteration per step of one
+        # instance -- the reference's execution model.  The reference's own rate is quoted beside them.
+        from oracle import numpy_port as NP
+
+        nn, nsteps_np = min(512, B), 3000
+        c0 = time.perf_counter()
+        _, np_rsum, np_vs, _ = NP.rollout_vectorised(tables, 0, nn, nsteps_np, keys)
+        np_s = time.perf_counter() - c0
+        _, o_rsum, o_vs, _ = O.batch_rollout(tables, 0, nn, nsteps_np, rng_mode=1, philox_keys=keys, want_visits=True)
+        assert np.array_equal(np_vs, o_vs) and np.array_equal(np_rsum, o_rsum), "numpy restatement differs from the C oracle"
+        c0 = time.perf_counter()
+        NP.step_loop_python(tables, 0, 300_000, int(keys[0]))
+        py_s = time.perf_counter() - c0
+        line["cpu_baseline_numpy"] = {
+            "value": nn * nsteps_np / np_s, "unit": "env steps/s", "cores": 1, "kind": "port (numpy restatement, vectorised over instances)",
+            "sample": "instances 0..%d, %d transitions each, %.1f s; visit counts and reward sums bit-equal to the C port" % (nn - 1, nsteps_np, np_s),
+            "python_step_loop": {"value": 300_000 / py_s, "unit": "env steps/s", "cores": 1,
+                                 "what": "one instance, one Python iteration per step over plain tables (the reference's execution model "
+                                         "without its dm_env / sampler-object overhead)"},
+        }
+        line["reference_in_container"] = {
+            "value": 5.8e4, "unit": "env steps/s per core", "measured": False,
+            "source": "BASELINE.md section 2: bare BaseMDP.step loop of the reference itself, DeepSeaEpisodic(size=30), 200 000 random "
+                      "actions, one core of the development container (survey-time measurement; the reference does not travel to "
+                      "the GPU box).  With its Q-learning agent in the loop: 1.9e4.  This, not the C port above, is what "
+                      "'Colosseum on a CPU core' means (reference default: 1 core, colosseum/config.py:19)"}
         if "vi" in line and args.vi_instances > 0:
             nv = min(256, args.vi_instances)
             c0 = time.perf_counter()
-            _, _, swc = O.batch_vi(fl, 0, nv, 0.99, 1e-6, 0)
+            _, oracle_V, swc = O.batch_vi(fl, 0, nv, 0.99, 1e-6, 0)
             cv = time.perf_counter() - c0
             line["vi"]["cpu_baseline"] = {"value": float(swc.sum()) / cv, "unit": "sweeps/s", "cores": 1, "kind": "port",
                                           "sample": "instances 0..%d, %.1f s" % (nv - 1, cv)}
+            # the timed VI leg is checked, not just timed: V and the sweep counts of the sampled instances are bit-equal
+            n_states_v = int(fl["state_off"][nv])
+            assert np.array_equal(swc, vi_sweeps[:nv]), "GPU sweep counts differ from the CPU oracle"
+            assert np.array_equal(oracle_V[:n_states_v], vi_V[:n_states_v]), "GPU value functions differ from the CPU oracle"
+            line["vi"]["verified_against_oracle"] = "V and sweep counts of instances 0..%d: bit-equal" % (nv - 1)
+            # numpy restatement of the sweep (oracle/numpy_port.py), a few instances
+            from oracle import numpy_port as NP
+
+            so, cp = fl["state_off"], fl["csr_ptr"]
+            c0 = time.perf_counter()
+            nsw = 0
+            for b in range(4):
+                r0, r1 = int(so[b]) * 4, int(so[b + 1]) * 4
+                e0, e1 = int(cp[r0]), int(cp[r1])
+                _, Vn, k = NP.jacobi_vi(np.asarray(cp[r0:r1 + 1]) - e0, fl["csr_col"][e0:e1], fl["csr_val"][e0:e1], fl["R"][r0:r1],
+                                        int(so[b + 1] - so[b]), 4, 0.99, 1e-6)
+                assert k == int(swc[b]) and np.array_equal(Vn, oracle_V[int(so[b]):int(so[b + 1])])
+                nsw += k
+            line["vi"]["cpu_baseline_numpy"] = {"value": nsw / (time.perf_counter() - c0), "unit": "sweeps/s", "cores": 1,
+                                                "kind": "port (numpy restatement, bit-equal to the C port)", "sample": "instances 0..3"}
     if dense_env is not None:
         dense_env.close()
     env.close()

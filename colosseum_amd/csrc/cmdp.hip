@@ -22,6 +22,7 @@
 #include "cmdp_tracker.h"
 #include "cmdp_k1s.h"
 #include "cmdp_k1t.h"
+#include "cmdp_k1u.h"
 #include "cmdp_agent.h"
 #include "cmdp_chain.h"
 
@@ -178,6 +179,12 @@ struct cmdp {
   size_t tmpl_lds = 0;
   DevBuf<uint16_t> d_tmpl_words;
   DevBuf<uint8_t> d_swap_bits;
+  // K1U: K1T with the trace streamed to HBM and histogrammed by a second kernel (all instances of a CU resident at once)
+  bool k1u_ok = false, k1u_auto = false;
+  K1uPlan k1u{};
+  size_t k1u_lds = 0;
+  DevBuf<uint4> d_k1u_trace;
+  DevBuf<int32_t> d_k1u_resets;
   DevBuf<float> d_gp_q, d_gp_p;  // cmdp_greedy_policy_episodic workspace
   // K5S workspace (large-instance diameter)
   DevBuf<float> d_dl_v, d_ell_val;
@@ -800,6 +807,32 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
               h->tmpl_lds = k1t_lds_bytes(h->tmpl_plan, h->tmpl_plan.G);
               h->tmpl_ok = true;                                   // eligible: CMDP_OPT_ROLLOUT_KERNEL 4 may force it
               h->tmpl_auto = best_t < best_cost || k1t_env == 1;   // and the automatic choice when it needs fewer rounds x time
+              // K1U: the same chain with the visit counts histogrammed from an HBM trace -- an instance keeps only its swap
+              // bits and the rings in LDS, up to 256 instances per workgroup.  Taken automatically when that saves a round
+              // of workgroups over K1T (config C2: one round of 256 instead of two of 128); otherwise the histogram pass
+              // is pure overhead and K1T stays.
+              {
+                K1uPlan u{};
+                u.rows = q.rows; u.tmpl_bytes = q.tmpl_bytes; u.mask_bytes = q.mask_bytes;
+                u.slot_bytes = q.mask_bytes + ((((q.mask_bytes / 4) & 1) == 0) ? 4 : 0);
+                u.n_codes = q.n_codes; u.code_shift = q.code_shift;
+                u.ch = 32;
+                if (const char* ce = std::getenv("CMDP_K1U_CH")) u.ch = std::max(8, std::min(256, std::atoi(ce) & ~7));
+                const int per = u.slot_bytes + 2 * K1P_ACT_STRIDE(u.ch) + 2 * K1P_TR_STRIDE(u.ch);
+                const int cap = std::min<int>(256, (kLdsBudget - K1U_FIXED - u.tmpl_bytes) / per);
+                if (cap >= 64 && k1h_lds_bytes(S) <= (size_t)kLdsBudget) {
+                  const int64_t wgs = (B + cap - 1) / cap, rounds_u = (wgs + cus - 1) / cus;
+                  u.G = (int)std::min<int64_t>(cap, std::max<int64_t>(1, (B + rounds_u * cus - 1) / (rounds_u * cus)));
+                  if (const char* ge = std::getenv("CMDP_K1U_G")) u.G = std::max(1, std::min(cap, std::atoi(ge)));
+                  const int64_t wgs_t = (B + h->tmpl_plan.G - 1) / h->tmpl_plan.G, rounds_t = (wgs_t + cus - 1) / cus;
+                  u.tmpl = h->d_tmpl_words.p; u.swap_bits = h->d_swap_bits.p;
+                  h->k1u = u;
+                  h->k1u_lds = k1u_lds_bytes(u, u.G);
+                  h->k1u_ok = true;
+                  h->k1u_auto = h->tmpl_auto && rounds_u < rounds_t;
+                  if (const char* ue = std::getenv("CMDP_K1U")) h->k1u_auto = std::atoi(ue) != 0;
+                }
+              }
             }
           }
         }
@@ -818,6 +851,7 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
           h->lds_bytes = k1l_lds_bytes(p, p.G);
           h->lds_ok = true;
           h->tmpl_plan.rvals = p.rvals;
+          h->k1u.rvals = p.rvals;
           HIP_TRY(hipStreamSynchronize(st));  // staging vectors die with this scope
         }
       }
@@ -1145,6 +1179,31 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
   if (h->rollout_kernel == 4 && !(lds_eligible && h->tmpl_ok))
     return fail(CMDP_ERR_UNSUPPORTED, "the shared-table rollout K1T needs a batch eligible for K1P with two actions whose instances "
                                       "are per-state action permutations of the first one, the random policy and no trace");
+  if (h->rollout_kernel == 5 && !(lds_eligible && h->k1u_ok))
+    return fail(CMDP_ERR_UNSUPPORTED, "the streamed-trace rollout K1U needs a batch eligible for the shared-table rollout K1T (CMDP_OPT_ROLLOUT_KERNEL 4) "
+                                      "and room for 64 instances per workgroup");
+  if (lds_eligible && h->k1u_ok && (h->rollout_kernel == 5 || (h->rollout_kernel == 0 && h->k1u_auto && n_steps >= 64))) {
+    // K1U: per segment of <= K1U_SEG transitions the chain kernel (trace -> HBM), then the histogram of that trace
+    const int64_t seg_max = std::min<int64_t>(n_steps, K1U_SEG);
+    const size_t need = (size_t)((seg_max + 7) / 8) * (size_t)h->B;
+    if (h->d_k1u_trace.n < need) HIP_TRY(h->d_k1u_trace.alloc(need));
+    if (h->d_k1u_resets.n < (size_t)h->B) HIP_TRY(h->d_k1u_resets.alloc(h->B));
+    K1uPlan u = h->k1u;
+    u.trace = h->d_k1u_trace.p;
+    u.seg_resets = h->d_k1u_resets.p;
+    if (int rc = set_lds(k_rollout_tmpl_stream, h->k1u_lds)) return rc;
+    const size_t hist_lds = k1h_lds_bytes(h->max_S);
+    if (int rc = set_lds(k_trace_hist, hist_lds)) return rc;
+    for (int64_t s0 = 0; s0 < n_steps; s0 += K1U_SEG) {
+      const int64_t n = std::min<int64_t>(K1U_SEG, n_steps - s0);
+      hipLaunchKernelGGL(k_rollout_tmpl_stream, dim3(grid_for(h->B, u.G)), dim3(K1U_THREADS), h->k1u_lds, st, t, u, n, d_rsum, d_last,
+                         s0 > 0 ? 1 : 0);
+      hipLaunchKernelGGL(k_trace_hist, dim3(grid_for(h->B, K1H_G)), dim3(K1H_THREADS), hist_lds, st, t, u.trace, u.seg_resets, n,
+                         u.code_shift);
+    }
+    HIP_TRY(hipGetLastError());
+    return CMDP_OK;
+  }
   if (lds_eligible && h->tmpl_ok && (h->rollout_kernel == 4 || (h->rollout_kernel == 0 && h->tmpl_auto && n_steps >= 64))) {
     if (int rc = set_lds(k_rollout_tmpl, h->tmpl_lds)) return rc;
     hipLaunchKernelGGL(k_rollout_tmpl, dim3(grid_for(h->B, h->tmpl_plan.G)), dim3(K1T_THREADS), h->tmpl_lds, st, t, h->tmpl_plan,
@@ -1272,7 +1331,7 @@ int cmdp_rollout_async(cmdp_t* h, int policy, int64_t n_steps) {
 
 int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
   if (!h) return fail(CMDP_ERR_INVALID, "null handle");
-  if (option == CMDP_OPT_ROLLOUT_KERNEL && value >= 0 && value <= 4) {
+  if (option == CMDP_OPT_ROLLOUT_KERNEL && value >= 0 && value <= 5) {
     h->rollout_kernel = (int)value;
     return CMDP_OK;
   }
@@ -1317,10 +1376,11 @@ int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
 int cmdp_lds_plan(cmdp_t* h, int32_t plan[4]) {
   if (!h || !plan) return fail(CMDP_ERR_INVALID, "bad argument");
   plan[0] = (h->lds_ok || h->k1s_ok) ? 1 : 0;
-  const bool k1t = h->lds_ok && h->tmpl_ok && (h->rollout_kernel == 4 || (h->rollout_kernel == 0 && h->tmpl_auto));   // what a launch takes
-  plan[1] = k1t ? 3 : (h->lds_ok ? h->lds_plan.pipe : (h->k1s_ok ? 2 : 0));
-  plan[2] = k1t ? h->tmpl_plan.G : (h->lds_ok ? h->lds_plan.G : (h->k1s_ok ? h->k1s.G : 0));
-  plan[3] = k1t ? h->tmpl_plan.ch : (h->lds_ok ? h->lds_plan.ch : (h->k1s_ok ? h->k1s.ch : 0));
+  const bool k1u = h->lds_ok && h->k1u_ok && (h->rollout_kernel == 5 || (h->rollout_kernel == 0 && h->k1u_auto));
+  const bool k1t = !k1u && h->lds_ok && h->tmpl_ok && (h->rollout_kernel == 4 || (h->rollout_kernel == 0 && h->tmpl_auto));   // what a launch takes
+  plan[1] = k1u ? 4 : k1t ? 3 : (h->lds_ok ? h->lds_plan.pipe : (h->k1s_ok ? 2 : 0));
+  plan[2] = k1u ? h->k1u.G : k1t ? h->tmpl_plan.G : (h->lds_ok ? h->lds_plan.G : (h->k1s_ok ? h->k1s.G : 0));
+  plan[3] = k1u ? h->k1u.ch : k1t ? h->tmpl_plan.ch : (h->lds_ok ? h->lds_plan.ch : (h->k1s_ok ? h->k1s.ch : 0));
   return CMDP_OK;
 }
 

@@ -225,7 +225,10 @@ int cmdp_calibrate(int what, int64_t n_steps, double* ns_per_step);
    the row, at least 4 instances per 160 KiB of LDS), 4 = the shared-table pipeline K1T (a batch eligible for 2 with two
    actions whose instances are, state by state, the first instance's rows or their swap -- the seeds of a family whose
    structure does not depend on the seed: the workgroup keeps one successor table and a swap bit per state and
-   instance, 128 instances per CU at config C2 instead of 52; taken automatically when eligible, 2 keeps K1L / K1P).
+   instance, 128 instances per CU at config C2 instead of 52; taken automatically when eligible, 2 keeps K1L / K1P),
+   5 = K1U, K1T's chain with the 16-bit trace streamed to HBM and histogrammed by a second kernel instead of 8-bit count
+   deltas in LDS: up to 256 instances per CU resident at once (taken automatically when that saves a round of workgroups
+   over K1T -- config C2: one round instead of two; 4 keeps K1T).
    For 3: the automatic choice takes it while the batch is small enough that
    the HBM-table kernel's rate, which grows with the batch, stays below it -- FrozenLake 20x20: up to ~35 000 instances).
    CMDP_OPT_DP_KERNEL (Jacobi sweeps): 0 = automatic, 1 = workgroup kernel with the CSR in LDS or HBM,
@@ -262,7 +265,8 @@ int cmdp_set_option(cmdp_t* h, int option, int64_t value);
 /* What the LDS-resident random-policy rollout of this handle is (introspection for benchmarks and tests; no
    reference counterpart): plan[0] = 1 if the batch is eligible for it, plan[1] = 1 for the wavefront-pipeline kernel
    K1P (k_rollout_pipe), 0 for the fused walker K1L (k_rollout_lds), 2 for the stochastic-dynamics kernel K1S
-   (k_rollout_stoch), 3 for the shared-table pipeline K1T (k_rollout_tmpl), plan[2] = instances per workgroup,
+   (k_rollout_stoch), 3 for the shared-table pipeline K1T (k_rollout_tmpl), 4 for its streamed-trace form K1U
+   (k_rollout_tmpl_stream + k_trace_hist), plan[2] = instances per workgroup,
    plan[3] = transitions per chunk.  The kernel flavour and chunk length are chosen when the handle is created (fewest
    rounds of workgroups x measured time per transition). */
 int cmdp_lds_plan(cmdp_t* h, int32_t plan[4]);

@@ -171,6 +171,8 @@ def test_lds_resident_rollout_equals_global_kernel_and_oracle(need_gpu):
         _check_lds_rollout(75, size, 50, n2, expect_k1t=True, k1t_g=50)   # K1T: groups of 50 and 25
     # K1T with both halves of a workgroup in use (100 instances per group, the last group holds 61: half 1 empty)
     _check_lds_rollout(261, 9, 50, 8_000, expect_k1t=True, k1t_g=100)
+    # K1U with all four quarters of a workgroup in use (250 per group, the last group holds 97: quarters 2, 3 empty / ragged)
+    _check_lds_rollout(597, 7, 50, 4_000, expect_k1t=True, k1t_g=250)
 
 
 def _check_lds_rollout(B, size, n1, n2, tables=None, models=None, expect_k1t=None, k1t_g=128):
@@ -191,17 +193,23 @@ def _check_lds_rollout(B, size, n1, n2, tables=None, models=None, expect_k1t=Non
     # (read when the handle is created) forces one of them
     # ... and, for two-action batches whose instances are action-permuted copies of one MDP, as the shared-table
     # pipeline K1T (CMDP_K1T_G: instances per workgroup, so that small batches exercise both halves and ragged groups)
-    for which, pipe in ((L.ROLLOUT_GLOBAL, None), (L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1"), (L.ROLLOUT_LDS_TEMPLATE, "1")):
+    # ... and as K1U, K1T's chain with the trace streamed to HBM and histogrammed by a second kernel (CMDP_K1U_G likewise;
+    # a launch longer than 32 768 transitions runs as several segments)
+    TMPL = (L.ROLLOUT_LDS_TEMPLATE, L.ROLLOUT_LDS_TEMPLATE_STREAM)
+    for which, pipe in ((L.ROLLOUT_GLOBAL, None), (L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1"), (L.ROLLOUT_LDS_TEMPLATE, "1"),
+                        (L.ROLLOUT_LDS_TEMPLATE_STREAM, "1")):
         saved = os.environ.pop("CMDP_K1L_PIPE", None)
         if pipe is not None:
             os.environ["CMDP_K1L_PIPE"] = pipe
-        if which == L.ROLLOUT_LDS_TEMPLATE:
+        if which in TMPL:
             os.environ["CMDP_K1T_G"] = str(k1t_g)
+            os.environ["CMDP_K1U_G"] = str(k1t_g)
         try:
             env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX, philox_keys=keys)
         finally:
             os.environ.pop("CMDP_K1L_PIPE", None)
             os.environ.pop("CMDP_K1T_G", None)
+            os.environ.pop("CMDP_K1U_G", None)
             if saved is not None:
                 os.environ["CMDP_K1L_PIPE"] = saved
         env.set_rollout_kernel(which)
@@ -212,12 +220,15 @@ def _check_lds_rollout(B, size, n1, n2, tables=None, models=None, expect_k1t=Non
         try:
             a = env.rollout(n1)  # odd transition count: the next launch starts mid Philox block and mid episode
         except L.CmdpError as e:  # K1T exists for A = 2 and action-permuted copies of one MDP; it must say so otherwise
-            assert which == L.ROLLOUT_LDS_TEMPLATE and e.code == L.ERR_UNSUPPORTED and not expect_k1t, e
+            assert which in TMPL and e.code == L.ERR_UNSUPPORTED and not expect_k1t, e
             env.close()
             continue
         if which == L.ROLLOUT_LDS_TEMPLATE:
             plan = env.lds_plan()
             assert expect_k1t is not False and plan["kernel"] == "k_rollout_tmpl" and plan["instances_per_workgroup"] == min(k1t_g, 128), plan
+        if which == L.ROLLOUT_LDS_TEMPLATE_STREAM:
+            plan = env.lds_plan()
+            assert expect_k1t is not False and plan["kernel"] == "k_rollout_tmpl_stream" and plan["instances_per_workgroup"] == min(k1t_g, 256), plan
         b = env.rollout(n2)
         c = env.rollout(3)   # shorter than one Philox block / one group of 8
         vs, vsa = env.visits()
@@ -225,9 +236,9 @@ def _check_lds_rollout(B, size, n1, n2, tables=None, models=None, expect_k1t=Non
                               c["reward_sum"], vs, vsa, env.state())
         env.close()
     if expect_k1t:
-        assert (L.ROLLOUT_LDS_TEMPLATE, "1") in res
+        assert (L.ROLLOUT_LDS_TEMPLATE, "1") in res and (L.ROLLOUT_LDS_TEMPLATE_STREAM, "1") in res
     g = res[(L.ROLLOUT_GLOBAL, None)]
-    for key in ((L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1"), (L.ROLLOUT_LDS_TEMPLATE, "1")):
+    for key in ((L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1"), (L.ROLLOUT_LDS_TEMPLATE, "1"), (L.ROLLOUT_LDS_TEMPLATE_STREAM, "1")):
         if key not in res:
             continue
         l = res[key]
@@ -266,16 +277,19 @@ def test_lds_rollout_with_per_instance_episode_phase(need_gpu):
     mask = (np.arange(B) % 3 == 0).astype(np.uint8)
     n1, n2 = 13, 6_007
     res = {}
-    for which, pipe in ((L.ROLLOUT_GLOBAL, None), (L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1"), (L.ROLLOUT_LDS_TEMPLATE, "1")):
+    for which, pipe in ((L.ROLLOUT_GLOBAL, None), (L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1"), (L.ROLLOUT_LDS_TEMPLATE, "1"),
+                        (L.ROLLOUT_LDS_TEMPLATE_STREAM, "1")):
         saved = os.environ.pop("CMDP_K1L_PIPE", None)
         if pipe is not None:
             os.environ["CMDP_K1L_PIPE"] = pipe
         os.environ["CMDP_K1T_G"] = "30"
+        os.environ["CMDP_K1U_G"] = "30"
         try:
             env = BatchedMDP(models, rng_mode=L.RNG_PHILOX, philox_keys=keys, with_dp=False)
         finally:
             os.environ.pop("CMDP_K1L_PIPE", None)
             os.environ.pop("CMDP_K1T_G", None)
+            os.environ.pop("CMDP_K1U_G", None)
             if saved is not None:
                 os.environ["CMDP_K1L_PIPE"] = saved
         env.set_rollout_kernel(which)
@@ -288,7 +302,7 @@ def test_lds_rollout_with_per_instance_episode_phase(need_gpu):
         res[(which, pipe)] = (out["last_obs"], out["reward_sum"], vs, vsa) + tuple(env.state())
         env.close()
     g = res[(L.ROLLOUT_GLOBAL, None)]
-    for key in ((L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1"), (L.ROLLOUT_LDS_TEMPLATE, "1")):
+    for key in ((L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1"), (L.ROLLOUT_LDS_TEMPLATE, "1"), (L.ROLLOUT_LDS_TEMPLATE_STREAM, "1")):
         for x, y in zip(g, res[key]):
             np.testing.assert_array_equal(x, y)
     off = np.concatenate([[0], np.cumsum([m.n_states for m in models])])

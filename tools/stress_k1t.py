@@ -15,6 +15,11 @@ from colosseum_amd.batched import BatchedMDP  # noqa: E402
 from colosseum_amd.mdp.fast_batch import deepsea_episodic_tables  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+# second argument "k1u": the streamed-trace form K1U (k_rollout_tmpl_stream + k_trace_hist) instead of K1T
+K1U = len(sys.argv) > 2 and sys.argv[2] == "k1u"
+WHICH = L.ROLLOUT_LDS_TEMPLATE_STREAM if K1U else L.ROLLOUT_LDS_TEMPLATE
+GENV = "CMDP_K1U_G" if K1U else "CMDP_K1T_G"
+KNAME = "k_rollout_tmpl_stream" if K1U else "k_rollout_tmpl"
 rng = np.random.default_rng(7)
 t_end = time.time() + budget
 cases = 0
@@ -23,32 +28,33 @@ while time.time() < t_end:
     B = int(rng.choice([1, 63, 64, 65, 127, 128, 129, 1000, 128 * 256 - 1, 128 * 256 + 1, 40000, 65536]))
     if size >= 30 and B > 40000 and rng.integers(0, 3):
         B = 40000
-    g = int(rng.choice([0, 0, 17, 64, 65, 100, 128]))   # 0: the library's own choice
-    lens = [int(x) for x in rng.choice([1, 2, 3, 31, 32, 33, 63, 64, 65, 255, 257, 3551, 3553, 4097, 9001, 30001], size=int(rng.integers(1, 4)))]
+    g = int(rng.choice([0, 0, 17, 64, 65, 100, 128] + ([129, 200, 255, 256] if K1U else [])))   # 0: the library's own choice
+    lens = [int(x) for x in rng.choice([1, 2, 3, 31, 32, 33, 63, 64, 65, 255, 257, 3551, 3553, 4097, 9001, 30001] + ([32767, 32769, 70001] if K1U else []),
+                                       size=int(rng.integers(1, 4)))]
     seeds = rng.integers(0, 1 << 30, B)
     tables = deepsea_episodic_tables(seeds, size)
     keys = rng.integers(1, 1 << 62, B).astype(np.uint64)
     res = []
-    for which in (L.ROLLOUT_LDS_TEMPLATE, L.ROLLOUT_GLOBAL):
-        if g and which == L.ROLLOUT_LDS_TEMPLATE:
-            os.environ["CMDP_K1T_G"] = str(g)
+    for which in (WHICH, L.ROLLOUT_GLOBAL):
+        if g and which == WHICH:
+            os.environ[GENV] = str(g)
         try:
             env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX, philox_keys=keys)
         finally:
-            os.environ.pop("CMDP_K1T_G", None)
+            os.environ.pop(GENV, None)
         env.set_rollout_kernel(which)
         env.reset()
         try:
             outs = [env.rollout(n) for n in lens]
         except L.CmdpError as ex:   # the handle was planned onto K1L (not the pipeline kernel): K1T is not built for it
-            assert which == L.ROLLOUT_LDS_TEMPLATE and ex.code == L.ERR_UNSUPPORTED, ex
+            assert which == WHICH and ex.code == L.ERR_UNSUPPORTED, ex
             print("stress_k1t: size %d, %d instances: not planned as a pipeline batch, K1T refused" % (size, B), flush=True)
             env.close()
             res = None
             break
         vs, vsa = env.visits()
-        if which == L.ROLLOUT_LDS_TEMPLATE:
-            assert env.lds_plan()["kernel"] == "k_rollout_tmpl", env.lds_plan()
+        if which == WHICH:
+            assert env.lds_plan()["kernel"] == KNAME, env.lds_plan()
         res.append((outs, vs, vsa, env.state()))
         env.close()
     if res is None:
@@ -61,4 +67,4 @@ while time.time() < t_end:
         assert np.array_equal(x, y), (size, B, g, lens)
     cases += 1
     print("stress_k1t: case %d ok (size %d, %d instances, G %s, launches %s)" % (cases, size, B, g or "auto", lens), flush=True)
-print("stress_k1t: %d cases, K1T == K1 in every counter" % cases)
+print("stress_k1t: %d cases, %s == K1 in every counter" % (cases, "K1U" if K1U else "K1T"))
