@@ -183,8 +183,15 @@ struct cmdp {
   bool k1u_ok = false, k1u_auto = false;
   K1uPlan k1u{};
   size_t k1u_lds = 0;
-  DevBuf<uint4> d_k1u_trace;
-  DevBuf<int32_t> d_k1u_resets;
+  DevBuf<uint4> d_k1u_trace[2];
+  DevBuf<int32_t> d_k1u_resets[2];
+  // the histogram of segment k runs on a second stream under the chain kernel of segment k + 1 (two trace buffers)
+  bool k1u_overlap = false, k1u_overlap_fits = false, k1u_pending = false;
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_trace[2] = {nullptr, nullptr}, ev_hist[2] = {nullptr, nullptr};
+  bool ev_hist_used[2] = {false, false}, k1u_last_overlap = false;
+  int64_t k1u_seq = 0;
+  hipEvent_t ev_k1u[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // CMDP_STAT_ROLLOUT_KERNEL_MS / _HIST_KERNEL_MS of the last segment
   DevBuf<float> d_gp_q, d_gp_p;  // cmdp_greedy_policy_episodic workspace
   // K5S workspace (large-instance diameter)
   DevBuf<float> d_dl_v, d_ell_val;
@@ -234,9 +241,19 @@ struct cmdp {
 
 namespace {
 
-int bind(cmdp_t* h) {
+// the main stream waits for the histogram the second stream still owes (K1U): before anything reads or writes the counters
+int k1u_join(cmdp_t* h) {
+  if (h->k1u_pending) {
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_hist[(h->k1u_seq + 1) & 1], 0));
+    h->k1u_pending = false;
+  }
+  return CMDP_OK;
+}
+
+int bind(cmdp_t* h, bool join = true) {
   if (!h) return fail(CMDP_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(h->device));
+  if (join) return k1u_join(h);
   return CMDP_OK;
 }
 
@@ -417,6 +434,16 @@ int cmdp_destroy(cmdp_t* h) {
     (void)hipStreamSynchronize(h->stream);
     (void)hipStreamDestroy(h->stream);
   }
+  if (h->aux_stream) {
+    (void)hipStreamSynchronize(h->aux_stream);
+    (void)hipStreamDestroy(h->aux_stream);
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (h->ev_trace[i]) (void)hipEventDestroy(h->ev_trace[i]);
+    if (h->ev_hist[i]) (void)hipEventDestroy(h->ev_hist[i]);
+  }
+  for (int i = 0; i < 5; ++i)
+    if (h->ev_k1u[i]) (void)hipEventDestroy(h->ev_k1u[i]);
   for (double* c : h->rc_chunks) (void)hipFree(c);
   if (h->rc_stage_h) (void)hipHostFree(h->rc_stage_h);
   if (h->rc_dst_h) (void)hipHostFree(h->rc_dst_h);
@@ -816,11 +843,15 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
                 u.rows = q.rows; u.tmpl_bytes = q.tmpl_bytes; u.mask_bytes = q.mask_bytes;
                 u.slot_bytes = q.mask_bytes + ((((q.mask_bytes / 4) & 1) == 0) ? 4 : 0);
                 u.n_codes = q.n_codes; u.code_shift = q.code_shift;
-                u.ch = 32;
-                if (const char* ce = std::getenv("CMDP_K1U_CH")) u.ch = std::max(8, std::min(256, std::atoi(ce) & ~7));
+                u.pack10 = u.rows <= 1024 ? 1 : 0;
+                if (const char* pe = std::getenv("CMDP_K1U_PACK10")) u.pack10 = (std::atoi(pe) != 0 && u.rows <= 1024) ? 1 : 0;
+                // chunk length: one barrier per chunk (measured at C2: 2.20 ms per launch at 32 transitions, 2.06 ms at 64)
+                u.ch = u.pack10 ? 72 : 64;
+                if (const char* ce = std::getenv("CMDP_K1U_CH")) u.ch = std::max(8, std::min(240, std::atoi(ce)));
+                u.ch = u.pack10 ? std::max(24, u.ch / 24 * 24) : std::max(8, u.ch & ~7);
                 const int per = u.slot_bytes + 2 * K1P_ACT_STRIDE(u.ch) + 2 * K1P_TR_STRIDE(u.ch);
                 const int cap = std::min<int>(256, (kLdsBudget - K1U_FIXED - u.tmpl_bytes) / per);
-                if (cap >= 64 && k1h_lds_bytes(S) <= (size_t)kLdsBudget) {
+                if (cap >= 64 && k1h_lds_bytes(S, 64) <= (size_t)kLdsBudget) {
                   const int64_t wgs = (B + cap - 1) / cap, rounds_u = (wgs + cus - 1) / cus;
                   u.G = (int)std::min<int64_t>(cap, std::max<int64_t>(1, (B + rounds_u * cus - 1) / (rounds_u * cus)));
                   if (const char* ge = std::getenv("CMDP_K1U_G")) u.G = std::max(1, std::min(cap, std::atoi(ge)));
@@ -830,6 +861,12 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
                   h->k1u_lds = k1u_lds_bytes(u, u.G);
                   h->k1u_ok = true;
                   h->k1u_auto = h->tmpl_auto && rounds_u < rounds_t;
+                  // the histogram of one launch under the chain of the next (second stream) was measured at C2 and LOST:
+                  // co-resident, the chain kernel slows from 2.2 to 3.0 ms (the histogram's LDS atomics sit in the same
+                  // in-order LDS pipeline as the chain's dependent reads) -- 3.25 ms per step against 3.00 one after the
+                  // other.  Kept behind CMDP_K1U_OVERLAP=1 for batches where both workgroups fit one CU.
+                  h->k1u_overlap = false;
+                  h->k1u_overlap_fits = h->k1u_lds + k1h_lds_bytes(S, 32) + 1024 <= (size_t)kLdsBudget;
                   if (const char* ue = std::getenv("CMDP_K1U")) h->k1u_auto = std::atoi(ue) != 0;
                 }
               }
@@ -1182,25 +1219,74 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
   if (h->rollout_kernel == 5 && !(lds_eligible && h->k1u_ok))
     return fail(CMDP_ERR_UNSUPPORTED, "the streamed-trace rollout K1U needs a batch eligible for the shared-table rollout K1T (CMDP_OPT_ROLLOUT_KERNEL 4) "
                                       "and room for 64 instances per workgroup");
-  if (lds_eligible && h->k1u_ok && (h->rollout_kernel == 5 || (h->rollout_kernel == 0 && h->k1u_auto && n_steps >= 64))) {
-    // K1U: per segment of <= K1U_SEG transitions the chain kernel (trace -> HBM), then the histogram of that trace
+  const bool take_k1u = lds_eligible && h->k1u_ok && (h->rollout_kernel == 5 || (h->rollout_kernel == 0 && h->k1u_auto && n_steps >= 64));
+  if (!take_k1u) {
+    if (int rc = k1u_join(h)) return rc;   // every other kernel updates the visit counters itself
+  } else {
+    // K1U: per segment of <= K1U_SEG transitions the chain kernel (trace -> HBM), then the histogram of that trace -- on a
+    // second stream, under the chain kernel of the next segment / launch (two trace buffers), unless switched off
+    static const int ov_env = std::getenv("CMDP_K1U_OVERLAP") ? std::atoi(std::getenv("CMDP_K1U_OVERLAP")) : -1;
+    const bool ov = (ov_env < 0 ? h->k1u_overlap : ov_env != 0) && h->k1u_overlap_fits;
+    if (!h->ev_k1u[0])
+      for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&h->ev_k1u[i]));
+    if (ov && !h->aux_stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+      for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_trace[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_hist[i], hipEventDisableTiming));
+      }
+    }
+    if (!ov) { if (int rc = k1u_join(h)) return rc; }
     const int64_t seg_max = std::min<int64_t>(n_steps, K1U_SEG);
-    const size_t need = (size_t)((seg_max + 7) / 8) * (size_t)h->B;
-    if (h->d_k1u_trace.n < need) HIP_TRY(h->d_k1u_trace.alloc(need));
-    if (h->d_k1u_resets.n < (size_t)h->B) HIP_TRY(h->d_k1u_resets.alloc(h->B));
     K1uPlan u = h->k1u;
-    u.trace = h->d_k1u_trace.p;
-    u.seg_resets = h->d_k1u_resets.p;
-    if (int rc = set_lds(k_rollout_tmpl_stream, h->k1u_lds)) return rc;
-    const size_t hist_lds = k1h_lds_bytes(h->max_S);
-    if (int rc = set_lds(k_trace_hist, hist_lds)) return rc;
+    const int epp = K1U_EPP(u.pack10);
+    const size_t need = (size_t)((seg_max + epp - 1) / epp) * (size_t)h->B;
+    const size_t hist_lds = k1h_lds_bytes(h->max_S, ov ? 32 : 64);
+#define K1U_SET_LDS(P10)                                                                             \
+    {                                                                                                \
+      if (int rc = set_lds(k_rollout_tmpl_stream<P10>, h->k1u_lds)) return rc;                       \
+      if (ov) { if (int rc = set_lds(k_trace_hist<32, 512, P10>, hist_lds)) return rc; }             \
+      else { if (int rc = set_lds(k_trace_hist<64, 1024, P10>, hist_lds)) return rc; }               \
+    }
+    if (u.pack10) K1U_SET_LDS(true) else K1U_SET_LDS(false)
+#undef K1U_SET_LDS
     for (int64_t s0 = 0; s0 < n_steps; s0 += K1U_SEG) {
       const int64_t n = std::min<int64_t>(K1U_SEG, n_steps - s0);
-      hipLaunchKernelGGL(k_rollout_tmpl_stream, dim3(grid_for(h->B, u.G)), dim3(K1U_THREADS), h->k1u_lds, st, t, u, n, d_rsum, d_last,
-                         s0 > 0 ? 1 : 0);
-      hipLaunchKernelGGL(k_trace_hist, dim3(grid_for(h->B, K1H_G)), dim3(K1H_THREADS), hist_lds, st, t, u.trace, u.seg_resets, n,
-                         u.code_shift);
+      const int i = ov ? (int)(h->k1u_seq & 1) : 0;
+      if (h->d_k1u_trace[i].n < need) {
+        if (ov && h->aux_stream) HIP_TRY(hipStreamSynchronize(h->aux_stream));   // the buffer may still be read
+        HIP_TRY(h->d_k1u_trace[i].alloc(need));
+      }
+      if (h->d_k1u_resets[i].n < (size_t)h->B) HIP_TRY(h->d_k1u_resets[i].alloc(h->B));
+      u.trace = h->d_k1u_trace[i].p;
+      u.seg_resets = h->d_k1u_resets[i].p;
+      if (ov && h->ev_hist_used[i]) HIP_TRY(hipStreamWaitEvent(st, h->ev_hist[i], 0));   // its last histogram has read the buffer
+      const bool last = s0 + K1U_SEG >= n_steps;
+      if (last) HIP_TRY(hipEventRecord(h->ev_k1u[0], st));
+      const dim3 rgrid(grid_for(h->B, u.G)), rblock(K1U_THREADS);
+      if (u.pack10) hipLaunchKernelGGL(k_rollout_tmpl_stream<true>, rgrid, rblock, h->k1u_lds, st, t, u, n, d_rsum, d_last, s0 > 0 ? 1 : 0);
+      else hipLaunchKernelGGL(k_rollout_tmpl_stream<false>, rgrid, rblock, h->k1u_lds, st, t, u, n, d_rsum, d_last, s0 > 0 ? 1 : 0);
+      if (last) HIP_TRY(hipEventRecord(h->ev_k1u[1], st));
+      if (ov) {
+        HIP_TRY(hipEventRecord(h->ev_trace[i], st));
+        HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_trace[i], 0));
+        if (last) HIP_TRY(hipEventRecord(h->ev_k1u[3], h->aux_stream));
+        const dim3 hgrid(grid_for(h->B, 32)), hblock(512);
+        if (u.pack10) hipLaunchKernelGGL((k_trace_hist<32, 512, true>), hgrid, hblock, hist_lds, h->aux_stream, t, u.trace, u.seg_resets, n, u.code_shift);
+        else hipLaunchKernelGGL((k_trace_hist<32, 512, false>), hgrid, hblock, hist_lds, h->aux_stream, t, u.trace, u.seg_resets, n, u.code_shift);
+        if (last) HIP_TRY(hipEventRecord(h->ev_k1u[4], h->aux_stream));
+        HIP_TRY(hipEventRecord(h->ev_hist[i], h->aux_stream));
+        h->ev_hist_used[i] = true;
+        h->k1u_pending = true;
+        h->k1u_seq++;
+      } else {
+        const dim3 hgrid(grid_for(h->B, 64)), hblock(1024);
+        if (u.pack10) hipLaunchKernelGGL((k_trace_hist<64, 1024, true>), hgrid, hblock, hist_lds, st, t, u.trace, u.seg_resets, n, u.code_shift);
+        else hipLaunchKernelGGL((k_trace_hist<64, 1024, false>), hgrid, hblock, hist_lds, st, t, u.trace, u.seg_resets, n, u.code_shift);
+        if (last) HIP_TRY(hipEventRecord(h->ev_k1u[2], st));
+      }
     }
+    h->k1u_last_overlap = ov;
     HIP_TRY(hipGetLastError());
     return CMDP_OK;
   }
@@ -1310,7 +1396,7 @@ int cmdp_rollout(cmdp_t* h, int policy, const void* policy_arg, int64_t n_steps,
 }
 
 int cmdp_rollout_async(cmdp_t* h, int policy, int64_t n_steps) {
-  if (int rc = bind(h)) return rc;
+  if (int rc = bind(h, false)) return rc;   // K1U's histogram of the previous launch may still run (launch_rollout joins otherwise)
   if (!h->has_env) return fail(CMDP_ERR_INVALID, "handle was created without the sampler half");
   if (policy != CMDP_POLICY_RANDOM) return fail(CMDP_ERR_INVALID, "rollout_async supports CMDP_POLICY_RANDOM only");
   if (n_steps < 0) return fail(CMDP_ERR_INVALID, "n_steps < 0");
@@ -1403,6 +1489,17 @@ int cmdp_stat(cmdp_t* h, int which, double* out) {
   }
   if (which == CMDP_STAT_DP_KERNEL) {
     *out = h->last_dp_kernel;
+    return CMDP_OK;
+  }
+  if (which == CMDP_STAT_ROLLOUT_KERNEL_MS || which == CMDP_STAT_HIST_KERNEL_MS) {
+    if (!h->ev_k1u[0]) return fail(CMDP_ERR_INVALID, "no streamed-trace rollout (K1U) has run on this handle");
+    const bool hist = which == CMDP_STAT_HIST_KERNEL_MS;
+    hipEvent_t e0 = hist ? (h->k1u_last_overlap ? h->ev_k1u[3] : h->ev_k1u[1]) : h->ev_k1u[0];
+    hipEvent_t e1 = hist ? (h->k1u_last_overlap ? h->ev_k1u[4] : h->ev_k1u[2]) : h->ev_k1u[1];
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *out = ms;
     return CMDP_OK;
   }
   if (which == CMDP_STAT_REWARD_FILLS || which == CMDP_STAT_REWARD_ROUNDS) {

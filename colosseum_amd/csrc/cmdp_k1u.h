@@ -25,9 +25,12 @@
 
 #define K1U_THREADS 1024
 #define K1U_FIXED (K1L_NRV * 8 + 16)   // rv2[K1L_NRV] f64 + pad
-#define K1U_SEG 32768                  // transitions per segment (multiple of 8, < 65 536: 16-bit histogram counters)
-#define K1H_THREADS 512
-#define K1H_G 64                       // instances per histogram workgroup
+#define K1U_SEG 32736                  // transitions per segment (multiple of 24, < 65 536: 16-bit histogram counters)
+// Trace pieces of 16 bytes: 8 entries of 16 bits (arrival row byte offset | reward code, as in the LDS ring), or -- PACK10,
+// batches with at most 1024 rows -- 12 arrival ROW INDICES of 10 bits, three per dword: the histogram only needs the row,
+// and it is bound by the bytes it reads (config C2: 2.6 GB instead of 3.9 GB per launch)
+#define K1U_EPP(pack10) ((pack10) ? 12 : 8)
+#define K1H_MLP 4                      // trace pieces in flight per lane
 
 struct K1uPlan {
   int32_t G;             // instances per workgroup (<= 256)
@@ -35,12 +38,13 @@ struct K1uPlan {
   int32_t tmpl_bytes;
   int32_t mask_bytes;    // swap bits per instance in HBM (multiple of 4)
   int32_t slot_bytes;    // LDS bytes per instance: the swap bits, odd dword stride
-  int32_t ch;            // transitions per ring chunk (multiple of 8)
+  int32_t ch;            // transitions per ring chunk (multiple of 8; of 24 with pack10)
+  int32_t pack10;        // trace pieces hold 12 ten-bit row indices instead of 8 sixteen-bit entries
   int32_t n_codes, code_shift;
   const uint16_t* tmpl;
   const uint8_t* swap_bits;
   const double* rvals;
-  uint4* trace;          // [pieces of the segment][B] 8 trace entries each
+  uint4* trace;          // [pieces of the segment][B] 8 trace entries each (one of two buffers when the histogram overlaps)
   int32_t* seg_resets;   // [B] episode resets of the segment (visits of the start state the histogram adds)
 };
 
@@ -48,8 +52,9 @@ __host__ __device__ inline size_t k1u_lds_bytes(const K1uPlan& p, int g) {
   return (size_t)K1U_FIXED + (size_t)p.tmpl_bytes + (size_t)g * (size_t)(p.slot_bytes + 2 * K1P_ACT_STRIDE(p.ch) + 2 * K1P_TR_STRIDE(p.ch));
 }
 __host__ __device__ inline int k1h_stride_dwords(int S) { return S | 1; }   // one dword per state (two 16-bit counters), odd stride
-__host__ __device__ inline size_t k1h_lds_bytes(int S) { return (size_t)K1H_G * 4 * (size_t)k1h_stride_dwords(S); }
+__host__ __device__ inline size_t k1h_lds_bytes(int S, int G) { return (size_t)G * 4 * (size_t)k1h_stride_dwords(S); }
 
+template <bool PACK10>
 __global__ void __launch_bounds__(K1U_THREADS) k_rollout_tmpl_stream(EnvTables t, K1uPlan p, int64_t n_steps,
                                                                     double* __restrict__ reward_sum,
                                                                     int32_t* __restrict__ last_obs, int accumulate) {
@@ -88,6 +93,7 @@ __global__ void __launch_bounds__(K1U_THREADS) k_rollout_tmpl_stream(EnvTables t
   typedef const __attribute__((address_space(3))) uint8_t* lds_u8;
   const lds_u32 tmpl_l = (lds_u32)(__attribute__((address_space(3))) unsigned char*)tmpl;
   const lds_u8 swp_l = (lds_u8)(__attribute__((address_space(3))) unsigned char*)base;
+  const int smask_u = (1 << p.code_shift) - 1;
   const int32_t start_k = t.start_state[t.start_off[b]] * A * 2;
   int32_t cur = t.cur[b] * A * 2, h = t.hstep[b];
   int32_t n_resets = 0;
@@ -198,11 +204,24 @@ __global__ void __launch_bounds__(K1U_THREADS) k_rollout_tmpl_stream(EnvTables t
     if (!owner || plen <= 0) return;
     const uint32_t* trb = reinterpret_cast<const uint32_t*>(trace + ((size_t)tb * p.G + li) * TS);
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    u32x4* dst = reinterpret_cast<u32x4*>(p.trace) + (size_t)(first >> 3) * (size_t)t.B + (size_t)b;
-    const int npiece = (plen + 7) >> 3;   // a ragged last piece carries stale entries past plen: the histogram stops at n_steps
+    constexpr int EPP = K1U_EPP(PACK10);
+    u32x4* dst = reinterpret_cast<u32x4*>(p.trace) + (size_t)(first / EPP) * (size_t)t.B + (size_t)b;
+    const int npiece = (plen + EPP - 1) / EPP;   // a ragged last piece carries stale entries past plen: the histogram stops at n_steps
+    const uint32_t sm = (uint32_t)smask_u;
     for (int j = 0; j < npiece; ++j) {
       u32x4 v;
-      v.x = trb[4 * j]; v.y = trb[4 * j + 1]; v.z = trb[4 * j + 2]; v.w = trb[4 * j + 3];
+      if (PACK10) {
+        uint32_t e[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) e[k] = trb[6 * j + k];
+        auto row = [&](int k) { return ((e[k >> 1] >> (16 * (k & 1))) & sm) >> 1; };
+        v.x = row(0) | (row(1) << 10) | (row(2) << 20);
+        v.y = row(3) | (row(4) << 10) | (row(5) << 20);
+        v.z = row(6) | (row(7) << 10) | (row(8) << 20);
+        v.w = row(9) | (row(10) << 10) | (row(11) << 20);
+      } else {
+        v.x = trb[4 * j]; v.y = trb[4 * j + 1]; v.z = trb[4 * j + 2]; v.w = trb[4 * j + 3];
+      }
       __builtin_nontemporal_store(v, &dst[(size_t)j * t.B]);   // written once, read once by the histogram: no reuse
     }
   };
@@ -252,58 +271,74 @@ __global__ void __launch_bounds__(K1U_THREADS) k_rollout_tmpl_stream(EnvTables t
   if (role == 1 && owner && reward_sum) reward_sum[b] = sum;
 }
 
-// Histogram of a segment's trace: arrival row r = (entry & smask) >> 1 of every transition of the group's 64 instances.
-__global__ void __launch_bounds__(K1H_THREADS) k_trace_hist(EnvTables t, const uint4* __restrict__ trace,
-                                                           const int32_t* __restrict__ seg_resets, int64_t n_steps,
-                                                           int code_shift) {
+// Histogram of a segment's trace: arrival row r = (entry & smask) >> 1 of every transition of the group's G instances.
+// G = 64: lane = instance (119 KB of counters at C2: the kernel has the CU to itself).  G = 32: two lanes per instance on
+// alternating pieces and 60 KB of counters, so that a workgroup fits NEXT TO a resident k_rollout_tmpl_stream workgroup
+// (74 KB at chunk 32) and the histogram of one step runs under the chain of the next (second stream).
+template <int G, int THREADS, bool PACK10>
+__global__ void __launch_bounds__(THREADS) k_trace_hist(EnvTables t, const uint4* __restrict__ trace,
+                                                       const int32_t* __restrict__ seg_resets, int64_t n_steps,
+                                                       int code_shift) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);
-  __shared__ int32_t start_of[K1H_G], resets_of[K1H_G];
+  __shared__ int32_t start_of[G], resets_of[G];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int NW = K1H_THREADS / 64;
-  const int g0 = blockIdx.x * K1H_G;
-  const int nb = min(K1H_G, t.B - g0);
+  constexpr int NW = THREADS / 64, SUB = 64 / G;
+  const int g0 = blockIdx.x * G;
+  const int nb = min(G, t.B - g0);
   const int64_t so0 = t.state_off[g0];
   const int S = (int)(t.state_off[g0 + 1] - so0);
   const int stride = k1h_stride_dwords(S);
-  for (int i = tid; i < K1H_G * stride; i += K1H_THREADS) cnt[i] = 0u;
+  for (int i = tid; i < G * stride; i += THREADS) cnt[i] = 0u;
   if (tid < nb) {
     start_of[tid] = t.start_state[t.start_off[g0 + tid]];
     resets_of[tid] = seg_resets[g0 + tid];
   }
   __syncthreads();
   const uint32_t smask = (1u << code_shift) - 1u;
-  const int64_t npiece = (n_steps + 7) >> 3;
-  if (lane < nb) {
-    uint32_t* mine = cnt + (size_t)lane * stride;
-    const uint4* src = trace + (size_t)g0 + lane;
-    // two pieces in flight per lane (memory-level parallelism: the loads are the kernel)
-    for (int64_t pc = wave; pc < npiece; pc += 2 * NW) {
-      const uint4 v0 = src[(size_t)pc * t.B];
-      const bool two = pc + NW < npiece;
-      const uint4 v1 = two ? src[(size_t)(pc + NW) * t.B] : make_uint4(0, 0, 0, 0);
-      auto add = [&](uint32_t w, int64_t tpos) {   // two entries per dword
-        if (tpos < n_steps) {
-          const uint32_t r = (w & smask) >> 1;
-          atomicAdd(&mine[r >> 1], 1u << (16 * (r & 1)));
+  constexpr int EPP = K1U_EPP(PACK10);
+  const int64_t npiece = (n_steps + EPP - 1) / EPP;
+  const int inst = lane % G, sub = lane / G;
+  if (inst < nb) {
+    uint32_t* mine = cnt + (size_t)inst * stride;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* src = reinterpret_cast<const u32x4*>(trace) + (size_t)g0 + inst;
+    auto bump_row = [&](uint32_t r) { atomicAdd(&mine[r >> 1], 1u << (16 * (r & 1))); };
+    auto add = [&](uint32_t w, int64_t tpos) {   // the two (sixteen-bit) or three (ten-bit) entries of a dword
+      if (PACK10) {
+        if (tpos < n_steps) bump_row(w & 1023u);
+        if (tpos + 1 < n_steps) bump_row((w >> 10) & 1023u);
+        if (tpos + 2 < n_steps) bump_row((w >> 20) & 1023u);
+      } else {
+        if (tpos < n_steps) bump_row((w & smask) >> 1);
+        if (tpos + 1 < n_steps) bump_row(((w >> 16) & smask) >> 1);
+      }
+    };
+    // K1H_MLP pieces in flight per lane: the loads ARE the kernel (up to 1 KB per wave load; without several loads
+    // outstanding per wave the launch is bound by HBM latency, not bandwidth)
+    constexpr int STEP = NW * SUB;
+    for (int64_t pc = wave * SUB + sub; pc < npiece; pc += (int64_t)K1H_MLP * STEP) {
+      u32x4 v[K1H_MLP];
+#pragma unroll
+      for (int k = 0; k < K1H_MLP; ++k) {
+        const int64_t q = pc + (int64_t)k * STEP;
+        v[k] = q < npiece ? __builtin_nontemporal_load(&src[(size_t)q * t.B]) : u32x4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int k = 0; k < K1H_MLP; ++k) {
+        const int64_t q = pc + (int64_t)k * STEP;
+        if (q < npiece) {
+          constexpr int EPD = EPP / 4;   // entries per dword
+          const int64_t t0 = q * EPP;
+          add(v[k].x, t0); add(v[k].y, t0 + EPD); add(v[k].z, t0 + 2 * EPD); add(v[k].w, t0 + 3 * EPD);
         }
-        if (tpos + 1 < n_steps) {
-          const uint32_t r = ((w >> 16) & smask) >> 1;
-          atomicAdd(&mine[r >> 1], 1u << (16 * (r & 1)));
-        }
-      };
-      const int64_t t0 = pc * 8;
-      add(v0.x, t0); add(v0.y, t0 + 2); add(v0.z, t0 + 4); add(v0.w, t0 + 6);
-      if (two) {
-        const int64_t t1 = (pc + NW) * 8;
-        add(v1.x, t1); add(v1.y, t1 + 2); add(v1.z, t1 + 4); add(v1.w, t1 + 6);
       }
     }
   }
   __syncthreads();
   // flush: dword j of instance i = counts of rows (2 j, 2 j + 1) = the two actions of state j
   const int total = nb * S;
-  for (int k = tid; k < total; k += K1H_THREADS) {
+  for (int k = tid; k < total; k += THREADS) {
     const int i = k / S, j = k - i * S;
     const uint32_t c = cnt[(size_t)i * stride + j];
     const uint32_t c0 = c & 0xffffu, c1 = c >> 16;

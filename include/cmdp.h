@@ -205,7 +205,9 @@ int cmdp_synchronize(cmdp_t* h);
    CMDP_STAT_DP_KERNEL: which kernel that was -- 1 K2 (workgroup, CSR in LDS/HBM), 2 K2R, 5 K2U, 7 K2W, 6 K3 (Gauss-Seidel). */
 enum { CMDP_STAT_DP_KERNEL_MS = 1, CMDP_STAT_DP_KERNEL = 2,
        CMDP_STAT_REWARD_FILLS = 3,   /* CMDP_FLAG_REWARD_CACHE: blocks of 5000 samples drawn so far                */
-       CMDP_STAT_REWARD_ROUNDS = 4   /* ... and park / fill / relaunch rounds                                        */ };
+       CMDP_STAT_REWARD_ROUNDS = 4,  /* ... and park / fill / relaunch rounds                                        */
+       CMDP_STAT_ROLLOUT_KERNEL_MS = 5, /* K1U: HIP-event time of k_rollout_tmpl_stream in the last launch (last segment) */
+       CMDP_STAT_HIST_KERNEL_MS = 6     /* K1U: ... and of its k_trace_hist (on the second stream when overlapped)          */ };
 int cmdp_stat(cmdp_t* h, int which, double* out);
 /* Latency floor of the LDS-resident rollout kernels, measured on the current device: one wavefront per CU follows
    per-lane uint16 tables in LDS for n_steps dependent reads.  CMDP_CALIB_LDS_READ: the bare dependent ds_read_u16
