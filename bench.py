@@ -375,9 +375,28 @@ def main():
         # the latency of the dependent LDS read chain of one transition.  The chain latency is measured in this run.
         ns_read, ns_chain = C.c_double(), C.c_double()
         L.check(lib.cmdp_calibrate(L.CALIB_LDS_READ, 200000, C.byref(ns_read)))
-        shared_table = plan.get("kernel") == "k_rollout_tmpl"   # K1T's chain reads the word pair and the swap bit
+        streamed = plan.get("kernel") == "k_rollout_tmpl_stream"   # K1U: K1T's chain, visit counts histogrammed from an HBM trace
+        shared_table = plan.get("kernel") == "k_rollout_tmpl" or streamed   # the chain reads the word pair and the swap bit
         L.check(lib.cmdp_calibrate(L.CALIB_LDS_CHAIN_SHARED if shared_table else L.CALIB_LDS_CHAIN, 200000, C.byref(ns_chain)))
-        if shared_table:
+        kernel_ms = {}
+        if streamed:
+            # K1U: ONE successor table per CU and per instance only the swap bits in LDS, so LDS capacity (and the 32 wavefronts
+            # of a CU) would hold ~2 000 chains: what caps the resident chains is the BATCH -- B / 256 CUs
+            min_footprint = (S + 7) // 8
+            chains_per_cu = min((LDS_BYTES - 2 * S * A) // min_footprint, 32 * 64, -(-B // N_CUS))
+            footprint_txt = "swap bits per instance beside one shared %d-B table; capped by the 32 wavefronts of a CU and by the batch (B / %d CUs)" % (2 * S * A, N_CUS)
+            # per-kernel times of a step (HIP events inside the library, on the stream the kernels run on): three more
+            # launches outside the timed region, each read back
+            acc = {"k_rollout_tmpl_stream": [], "k_trace_hist": []}
+            for _ in range(3):
+                env.rollout_async(args.launch_steps)
+                env.synchronize()
+                for name, which in (("k_rollout_tmpl_stream", L.STAT_ROLLOUT_KERNEL_MS), ("k_trace_hist", L.STAT_HIST_KERNEL_MS)):
+                    v = C.c_double()
+                    L.check(lib.cmdp_stat(env.handle, which, C.byref(v)))
+                    acc[name].append(v.value)
+            kernel_ms = {k: float(np.mean(v)) for k, v in acc.items()}
+        elif shared_table:
             # K1T: ONE uint16 successor table per CU; a chain needs its 8-bit visit-count deltas and one swap bit per state
             min_footprint = S * A + (S + 7) // 8
             chains_per_cu = (LDS_BYTES - 2 * S * A) // min_footprint
@@ -390,17 +409,34 @@ def main():
         hv = hbm_view(8 + 8 * 1 + 28, "SURVEY 8(d) CSR figure (8 + 8*nnz + 28 = 44 B/transition); the tables are LDS-resident, so "
                       "these bytes never cross HBM -- reported as an equivalent rate, NOT a roofline fraction",
                       lds_kernel if args.rollout_kernel != 1 else "k_rollout<", units_per_launch, avg_launch_s)
+        dom_rate = units_per_launch / (kernel_ms["k_rollout_tmpl_stream"] * 1e-3) if streamed else kernel_rate
         roofline = {
             "bound": "lds_latency",
             "kernel": lds_kernel if args.rollout_kernel != 1 else "k_rollout<0,false>",
-            "achieved": kernel_rate / 1e9, "peak": peak / 1e9, "unit": "G transitions/s (one dependent LDS read each)",
-            "frac": kernel_rate / peak,
+            "achieved": dom_rate / 1e9, "peak": peak / 1e9, "unit": "G transitions/s (one dependent LDS read each)",
+            "frac": dom_rate / peak,
+            "frac_against_bare_lds_read": dom_rate / (N_CUS * chains_per_cu / (ns_read.value * 1e-9)),
             "model": "peak = %d CUs x floor(160 KiB / %d B of %s) = %d resident chains per CU / "
                      "calibrated dependent-read chain latency" % (N_CUS, min_footprint, footprint_txt, chains_per_cu),
             "calibrated_chain_ns": ns_chain.value, "calibrated_bare_lds_read_ns": ns_read.value,
             "resident_chains_per_cu": plan.get("instances_per_workgroup"), "lds_plan": plan,
             "traffic": hv["traffic"], "hbm": hv,
         }
+        if streamed:
+            epp = 12 if S * A <= 1024 else 8   # trace entries per 16-byte piece (ten-bit rows when they fit)
+            hist_bytes = units_per_launch * 16 / epp + 8 * B * S * A + 8 * B * S
+            roofline["kernel_ms"] = kernel_ms
+            roofline["step"] = {
+                "what": "a step = k_rollout_tmpl_stream (the chains; 16-bit trace -> HBM) followed by k_trace_hist (visit counts from "
+                        "the trace): `achieved` / `frac` above are the dominant kernel's over ITS duration, these are the whole step's",
+                "achieved": kernel_rate / 1e9, "frac": kernel_rate / peak,
+                "frac_against_bare_lds_read": kernel_rate / (N_CUS * chains_per_cu / (ns_read.value * 1e-9)),
+                "hist_roofline": {"bound": "hbm", "kernel": "k_trace_hist",
+                                  "algorithmic_bytes_per_launch": hist_bytes,
+                                  "accounting": "trace read (16 B per %d transitions) + read-modify-write of visits_sa and visits_s" % epp,
+                                  "achieved": (hist_bytes) / (kernel_ms["k_trace_hist"] * 1e-3) / 1e9,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": (hist_bytes) / (kernel_ms["k_trace_hist"] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
     roofline["launch_ms_avg"] = avg_launch_s * 1e3
     roofline["launch_ms_min"] = float(np.min(launch_ms))
 
