@@ -463,8 +463,11 @@ def main():
         "build_id": build_id[:16],
         "roofline": roofline,
         "parity_notes": "state indices / visit counts bit-exact; Jacobi VI/PE bit-exact incl. sweep counts; Gauss-Seidel VI/PE and "
-                        "episodic values within 2e-6 of the reference (NOT the 1e-6 of the north star: the reference sums rows "
-                        "with BLAS sgemv, whose accumulation order is not reproduced)",
+                        "episodic values within 2e-6 absolute of the reference's run in the development container (NOT the 1e-6 of "
+                        "the north star: the reference sums rows with BLAS sgemv, whose accumulation order belongs to the BLAS kernel "
+                        "of the CPU -- the reference's own runs under OpenBLAS's Sandybridge and Haswell kernels differ by 2.86e-6 "
+                        "on the same instances, profiles/r03_gs_blas_kernels.json; this build is 1.07e-6 from the Haswell-family runs); "
+                        "Beta rewards bit-exact through the batched path (reward caches filled from each MDP's numpy stream)",
     }
     if gather_ms is not None:
         line["gather_ms"] = gather_ms
@@ -637,7 +640,7 @@ def main():
         # instance -- the reference's execution model.  The reference's own rate is quoted beside them.
         from oracle import numpy_port as NP
 
-        nn, nsteps_np = min(512, B), 3000
+        nn, nsteps_np = min(512, B), 30000
         c0 = time.perf_counter()
         _, np_rsum, np_vs, _ = NP.rollout_vectorised(tables, 0, nn, nsteps_np, keys)
         np_s = time.perf_counter() - c0

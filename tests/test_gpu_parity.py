@@ -347,8 +347,14 @@ def test_vi_frozenlake20_vs_reference(need_gpu):
             np.testing.assert_array_equal(dp.split_rows(Q)[i].reshape(-1, 4), z[k + f"jac_{tag}_Q"])
             np.testing.assert_array_equal(dp.split_states(V)[i], z[k + f"disp_{tag}_V"])
             assert sw[i] == c[f"jac_{tag}_sweeps"]
-            np.testing.assert_allclose(dp.split_states(Vg)[i], z[k + f"gs_{tag}_V"], rtol=2e-6, atol=2e-6)
-            np.testing.assert_allclose(dp.split_rows(Qg)[i].reshape(-1, 4), z[k + f"gs_{tag}_Q"], rtol=2e-6, atol=2e-6)
+            # Gauss-Seidel: the reference's `T[s] @ V` is BLAS sgemv, whose accumulation order belongs to the BLAS KERNEL of
+            # the CPU it runs on.  oracle/gs_blas_experiment.py ran the reference's own function on these very instances
+            # under six OpenBLAS kernel families (profiles/r03_gs_blas_kernels.json): two runs of the REFERENCE differ by up
+            # to 2.86e-6 (Sandybridge vs Haswell / Zen / SkylakeX), this build's in-order restatement is 1.07e-6 from the
+            # Haswell-family runs (the golden's) and 2.74e-6 from the Nehalem / Sandybridge ones -- inside the reference's
+            # own spread, which is why the bound here is not the north star's 1e-6
+            np.testing.assert_allclose(dp.split_states(Vg)[i], z[k + f"gs_{tag}_V"], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(dp.split_rows(Qg)[i].reshape(-1, 4), z[k + f"gs_{tag}_Q"], rtol=0, atol=2e-6)
             assert abs(int(swg[i]) - c[f"gs_{tag}_sweeps"]) <= 1
             m = models[i]
             oQ, oV, oit, _ = O.vi_discounted(m.n_states, 4, m.csr(), m.reward_matrix(), 0.99, eps, 2)
