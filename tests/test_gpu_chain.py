@@ -123,6 +123,50 @@ def test_mixing_time_against_dense_float64_powers(need_gpu):
         env.close()
 
 
+def test_mixing_time_large_chain_path_at_scale(need_gpu):
+    """Config C5's second half -- the mixing time of a chain too large for the row-in-LDS stepping path -- in the driver's
+    GPU suite at reduced size (the full S = 50 272 run takes 103 s: tools/run_c5.py --mixing, profiles/).
+    (i) MiniGridRooms 14 x 14 x 4 rooms (S = 3 152, above the 1 024-state switch to dense float64 matrix powers in HBM):
+    t_mix and the total variation at t_mix against a plain numpy float64 evaluation by repeated squaring + binary search.
+    (ii) room size 28 as in C5, 4 rooms (S = 12 560, 1.26 GB per power): properties the definition implies -- the total
+    variation at t_mix is at most the threshold, and t_mix does not grow when the threshold is relaxed."""
+    from colosseum_amd.hardness import mixing_time
+    from colosseum_amd.markov_chain import gth_batch
+
+    m = make_model("MiniGridRoomsContinuous", seed=0, room_size=14, n_rooms=4, n_starting_states=2, p_lazy=0.1)
+    assert m.n_states == 3152
+    t, tv = mixing_time([m], threshold=0.25, max_steps=1 << 20)
+    T, _ = m.dense()
+    P = T.astype(np.float64).mean(1)
+    P /= P.sum(1, keepdims=True)
+    sd = gth_batch([P])[0]
+
+    def tvd(X):
+        return 0.5 * np.abs(X - sd).sum(1).max()
+
+    powers = [P]
+    while tvd(powers[-1]) > 0.25:          # A_k = P^(2^k) until 2^K steps are mixed
+        powers.append(powers[-1] @ powers[-1])
+    K = len(powers) - 1
+    assert K >= 8
+    X, steps = None, 0                     # largest t (bit by bit) whose power is NOT yet mixed; t_mix = t + 1
+    for k in range(K - 1, -1, -1):
+        Y = powers[k] if X is None else X @ powers[k]
+        if tvd(Y) > 0.25:
+            X, steps = Y, steps + (1 << k)
+    want_t = steps + 1
+    want_tv = tvd(P if X is None else X @ P)
+    assert int(t[0]) == want_t, (t, want_t)
+    assert tv[0] == pytest.approx(want_tv, rel=1e-8)
+
+    big = make_model("MiniGridRoomsContinuous", seed=0, room_size=28, n_rooms=4, n_starting_states=2, p_lazy=0.1)
+    assert big.n_states == 12560
+    t25, tv25 = mixing_time([big], threshold=0.25, max_steps=1 << 22)
+    t40, tv40 = mixing_time([big], threshold=0.40, max_steps=1 << 22)
+    assert 0 < tv25[0] <= 0.25 and 0 < tv40[0] <= 0.40
+    assert 1000 < t40[0] <= t25[0]
+
+
 def test_chain_api_argument_checks(need_gpu):
     """Error paths of the new entry points: they fail loudly with a library error, never with a GPU fault."""
     m = make_model("FrozenLakeContinuous", seed=3, size=5, p_frozen=0.8)

@@ -78,3 +78,27 @@ def test_run_c5_two_ranks_give_the_single_process_diameter(need_gpu):
     two = json.loads(_run(_torchrun(2, 29733) + args + ["--share-gpu", "--dist-backend", "gloo"]).strip().splitlines()[-1])
     assert two["world"] == 2 and two["targets_this_rank"] * 2 >= one["n_states"] - 1
     assert one["diameter"] == two["diameter"] and one["diameter"] > 0
+
+
+def test_c4_at_its_real_length(need_gpu, tmp_path):
+    """Config C4 as the reference defines it (benchmark/experiment_config.yml): the four default suites, 1 000 instances x
+    500 000 steps, a log row every 100 steps -- 5 000 rows per instance, the reference's CSV files on disk.  Run in the
+    throughput mode of the Beta rewards (device-sampled; the reference-exact mode is checked setting by setting in
+    tests/test_gpu_benchmark.py and costs ~90 s here): the summary of that mode is deterministic and pinned."""
+    import glob
+
+    args = ["tools/run_benchmark.py", "--configs-json", os.path.join(GOLDEN, "G11_benchmark_configs.json"),
+            "--benchmark", "benchmark_episodic_ergodic", "--benchmark", "benchmark_episodic_communicating",
+            "--benchmark", "benchmark_continuous_ergodic", "--benchmark", "benchmark_continuous_communicating",
+            "--out", str(tmp_path / "c4"), "--concurrent-groups", "12", "--beta-rewards", "philox"]
+    s = json.loads(_run([sys.executable] + args, timeout=500).strip().splitlines()[-1])
+    assert s["instances"] == s["run"] == 1000 and s["steps_each"] == 500000 and s["skipped_existing"] == 0
+    assert s["mean_normalized_cumulative_regret"] == pytest.approx(380972.0156768999, rel=1e-12)
+    files = glob.glob(str(tmp_path / "c4" / "logs" / "*" / "seed*_logs.csv"))
+    assert len(files) == 1000
+    for f in files[::97]:
+        lines = open(f).read().split("\r\n")
+        assert len(lines) == 5002 and lines[-1] == "" and lines[0].startswith("cumulative_expected_reward,")
+        assert lines[1].split(",")[lines[0].split(",").index("steps")] == "100"
+        assert lines[5000].split(",")[lines[0].split(",").index("steps")] == "499999"
+    print("C4 at full length: %.1f s wall, %.3g agent steps/s" % (s["wall_s"], s["agent_steps_per_s"]))
