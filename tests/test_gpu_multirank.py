@@ -97,7 +97,7 @@ def test_c4_at_its_real_length(need_gpu, tmp_path):
     files = glob.glob(str(tmp_path / "c4" / "logs" / "*" / "seed*_logs.csv"))
     assert len(files) == 1000
     for f in files[::97]:
-        lines = open(f).read().split("\r\n")
+        lines = open(f, newline="").read().split("\r\n")
         assert len(lines) == 5002 and lines[-1] == "" and lines[0].startswith("cumulative_expected_reward,")
         assert lines[1].split(",")[lines[0].split(",").index("steps")] == "100"
         assert lines[5000].split(",")[lines[0].split(",").index("steps")] == "499999"
