@@ -162,9 +162,9 @@ struct cmdp {
   bool k1s_ok = false;
   K1sPlan k1s{};
   size_t k1s_bytes = 0;
-  DevBuf<unsigned long long> d_k1s_codes;
+  DevBuf<uint4> d_k1s_dict;
   DevBuf<uint8_t> d_k1s_pat, d_k1s_rc;
-  DevBuf<uint16_t> d_k1s_sets;
+  DevBuf<uint16_t> d_k1s_sets, d_k1s_shape16;
   DevBuf<double> d_k1s_patterns, d_k1s_rvals;
   // LDS-resident rollout (K1L)
   bool lds_ok = false;
@@ -287,8 +287,9 @@ static int build_k1s(cmdp_t* h, const cmdp_desc* d) {
     for (int64_t e = 0; e < h->n_entries; ++e)
       if (d->sp_rkind[e] != 0) return CMDP_OK;   // reward means of Beta entries: K1 reports them
   const int64_t R = h->n_rows, NS = h->n_states;
-  std::vector<unsigned long long> codes((size_t)R, 0);
-  std::vector<uint8_t> pat((size_t)R, 0);
+  std::vector<uint16_t> shape((size_t)R, 0);
+  std::vector<uint4> dict;
+  std::map<std::pair<int, unsigned long long>, int> shape_of;
   std::vector<double> patterns;
   std::map<std::vector<uint64_t>, int> pat_of;
   std::map<uint64_t, int> code_of;
@@ -329,7 +330,7 @@ static int build_k1s(cmdp_t* h, const cmdp_desc* d) {
             patterns.push_back(k < n - 1 ? d->sp_cum[lo + k] : std::numeric_limits<double>::infinity());
           patterns.push_back(d->sp_cum[hi - 1]);
         }
-        pat[(size_t)r] = (uint8_t)it->second;
+        const int pat_id = it->second;
         unsigned long long word = 0;
         for (int k = 0; k < n; ++k) {
           const int32_t nx = d->sp_next[lo + k];
@@ -348,7 +349,13 @@ static int build_k1s(cmdp_t* h, const cmdp_desc* d) {
           if (rc_row[(size_t)r] < 0) rc_row[(size_t)r] = c;
           else if (rc_row[(size_t)r] != c) by_row = false;
         }
-        codes[(size_t)r] = word;
+        auto sh = shape_of.find({pat_id, word});
+        if (sh == shape_of.end()) {
+          if (dict.size() == 65535) return CMDP_OK;
+          sh = shape_of.emplace(std::make_pair(pat_id, word), (int)dict.size()).first;
+          dict.push_back(make_uint4((uint32_t)word, (uint32_t)(word >> 32), (uint32_t)pat_id, 0u));
+        }
+        shape[(size_t)r] = (uint16_t)sh->second;
       }
       U = std::max(U, (int)set.size());
     }
@@ -359,39 +366,59 @@ static int build_k1s(cmdp_t* h, const cmdp_desc* d) {
   p.S = (int)S0; p.rows = (int)S0 * A; p.U = U; p.n_pat = (int)pat_of.size(); p.n_codes = (int)rvals.size();
   p.reward_mode = by_state ? 0 : 1;
   p.ch = 32;
+  p.n_shapes = (int)dict.size();
+  p.shape_bytes = p.n_shapes <= 256 ? 1 : 2;
   auto up8 = [](int x) { return (x + 7) & ~7; };
-  p.off_pat = p.rows * 8;
-  p.off_cnt = up8(p.off_pat + p.rows);
+  p.off_cnt = up8(p.rows * p.shape_bytes);
   p.off_ovf = up8(p.off_cnt + p.rows);
   p.off_sets = up8(p.off_ovf + 2 * (K1S_OVF + 2));
   p.off_rc = up8(p.off_sets + 2 * p.S * U);
   p.off_start = up8(p.off_rc + (by_state ? p.S : p.rows));
   p.slot_bytes = up8(p.off_start + 48 + 8 * K1S_MAXSTART + 4 * K1S_MAXSTART);
-  const size_t fixed = k1s_fixed_bytes(p.n_pat) + 64;
+  const size_t fixed = k1s_fixed_bytes(p.n_pat, p.n_shapes) + 64;
   const size_t per = (size_t)p.slot_bytes + k1s_ring_bytes(p.ch);
   if (fixed + 4 * per > (size_t)kLdsBudget) return CMDP_OK;   // fewer than four instances per CU: not worth it
   const int cap = (int)std::min<size_t>(64, ((size_t)kLdsBudget - fixed) / per);
   // the fewest instances per workgroup that keep the number of rounds (as for K1L)
   const int64_t wgs = (B + cap - 1) / cap, rounds = (wgs + h->cus - 1) / h->cus;
   p.G = (int)std::min<int64_t>(cap, std::max<int64_t>(1, (B + rounds * h->cus - 1) / (rounds * h->cus)));
-  // lanes per instance in the walker wavefront.  Measured (FrozenLake-20 / MiniGrid-8 / DeepSea-20 with p_rand, G = 8 /
-  // 11 / 22): teams of 8 (two entries per lane, two ballots) +19 %; teams of 4 (four ballots) -3 %; of 2 -31 % against
-  // a lane per instance counting its 16 entries itself -- so teams only where a lane gets at most two entries
-  p.team = p.G <= 4 ? 16 : (p.G <= 8 ? 8 : 1);
+  // walker wavefronts and lanes per instance in them.  Round 2 (ONE walker wavefront; FrozenLake-20 / MiniGrid-8 /
+  // DeepSea-20 with p_rand, G = 8 / 11 / 22): teams of 8 (two entries per lane, two ballots) +19 %; teams of 4 (four
+  // ballots) -3 %; of 2 -31 % against a lane per instance counting its 16 entries itself -- so teams only where a lane
+  // gets at most two entries.  With up to four walker wavefronts a wavefront has a quarter of the instances and its teams
+  // are larger.  CMDP_K1S_NW / CMDP_K1S_TEAM override (tuning aids, read per handle).
+  p.nw = p.G >= 4 ? 4 : (p.G >= 2 ? 2 : 1);
+  if (const char* e = std::getenv("CMDP_K1S_NW")) p.nw = std::max(1, std::min(4, std::atoi(e)));
+  p.nw = std::min(p.nw, p.G);
+  p.gw = (p.G + p.nw - 1) / p.nw;
+  p.team = p.gw <= 4 ? 16 : (p.gw <= 8 ? 8 : 1);
+  if (const char* e = std::getenv("CMDP_K1S_TEAM")) {
+    const int tm = std::atoi(e);
+    if ((tm == 1 || tm == 2 || tm == 4 || tm == 8 || tm == 16) && tm * p.gw <= 64) p.team = tm;
+  }
   hipStream_t st = h->stream;
   std::vector<uint16_t> sets_flat((size_t)NS * U, 0);
   for (int64_t s = 0; s < NS; ++s)
     for (size_t j = 0; j < sets[(size_t)s].size(); ++j) sets_flat[(size_t)s * U + j] = (uint16_t)sets[(size_t)s][j];
   std::vector<uint8_t> rc(by_state ? (size_t)NS : (size_t)R, 0);
   for (size_t i = 0; i < rc.size(); ++i) rc[i] = (uint8_t)std::max(0, by_state ? rc_state[i] : rc_row[i]);
-  HIP_TRY(h->d_k1s_codes.upload(codes.data(), codes.size(), st));
-  HIP_TRY(h->d_k1s_pat.upload(pat.data(), pat.size(), st));
+  if (p.shape_bytes == 1) {
+    std::vector<uint8_t> s8((size_t)R);
+    for (int64_t r = 0; r < R; ++r) s8[(size_t)r] = (uint8_t)shape[(size_t)r];
+    HIP_TRY(h->d_k1s_pat.upload(s8.data(), s8.size(), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    p.shape = h->d_k1s_pat.p;
+  } else {
+    HIP_TRY(h->d_k1s_shape16.upload(shape.data(), shape.size(), st));
+    p.shape = h->d_k1s_shape16.p;
+  }
+  HIP_TRY(h->d_k1s_dict.upload(dict.data(), dict.size(), st));
   HIP_TRY(h->d_k1s_sets.upload(sets_flat.data(), sets_flat.size(), st));
   HIP_TRY(h->d_k1s_rc.upload(rc.data(), rc.size(), st));
   HIP_TRY(h->d_k1s_patterns.upload(patterns.data(), patterns.size(), st));
   HIP_TRY(h->d_k1s_rvals.upload(rvals.data(), rvals.size(), st));
   HIP_TRY(hipStreamSynchronize(st));
-  p.codes = h->d_k1s_codes.p; p.pat = h->d_k1s_pat.p; p.sets = h->d_k1s_sets.p; p.rcode = h->d_k1s_rc.p;
+  p.dict = h->d_k1s_dict.p; p.sets = h->d_k1s_sets.p; p.rcode = h->d_k1s_rc.p;
   p.patterns = h->d_k1s_patterns.p; p.rvals = h->d_k1s_rvals.p;
   h->k1s = p;
   h->k1s_bytes = fixed + (size_t)p.G * per + 16;

@@ -7,20 +7,25 @@
 //   * the cumulative-probability vector of a row takes one of a handful of values in the whole batch (it is a function of
 //     p_lazy, p_rand, the number of actions and the shape of the nominal outcome lists): PATTERNS, shared by the batch;
 //   * the rows of a state draw their successors from the same few states (a cell's neighbours and itself): a per-state
-//     SUCCESSOR SET of U <= 16 states, and every row entry is a 4-bit index into it -- one 64-bit word per row.
-// With that, an instance is ~10 bytes per row + 2 U bytes per state (FrozenLake 20x20: 18 KB instead of 67 KB of
-// float64 / int32 tables) and G instances fit a CU's LDS.  One workgroup runs G instances: a TEAM of lanes of wavefront 0
-// walks each instance entirely on chip, wavefronts 1-3 produce the random-policy action bytes and the 53-bit transition uniforms
-// of the NEXT chunk (Philox domains 2 and 0, the same streams as K1 and the CPU oracle) into double-buffered LDS rings.
+//     SUCCESSOR SET of U <= 16 states, and every row entry is a 4-bit index into it -- one 64-bit word per row;
+//   * (round 3) those words, paired with the row's pattern, take few distinct values in the whole batch as well (FrozenLake
+//     20x20: ~100 ROW SHAPES, MiniGrid: 12, DeepSea: 3): a shared dictionary of shapes, and ONE BYTE per row naming its
+//     shape (two when the batch has more than 256).
+// With that, an instance is 2 bytes per row (shape, visit-count delta) + 2 U bytes per state (FrozenLake 20x20: 7 KB
+// instead of 18 KB in round 2 and 67 KB of float64 / int32 tables) and G instances fit a CU's LDS.  One workgroup runs G
+// instances: wavefronts 0 .. nw-1 are WALKERS, each walks gw = G / nw of the instances entirely on chip, a TEAM of lanes
+// per instance (round 2 had ONE walker wavefront: the LDS pipeline was 2 % busy and the workgroup was bound by that one
+// wavefront's instruction issue); the other wavefronts produce the random-policy action bytes and the 53-bit transition
+// uniforms of the NEXT chunk (Philox domains 2 and 0, the same streams as K1 and the CPU oracle) into double-buffered LDS rings.
 //
-// Per transition the walker does: action + uniform from the ring; row word + pattern id (two independent ds_reads);
+// Per transition the walker does: action + uniform from the ring; the row's shape byte, then the shape's word + pattern id (one 16-byte read);
 // the pattern's 16 padded cumulative values (independent ds_reads) and the count #{k < n-1 : cum_k <= u * total} ==
 // bisect_right of `random.choices` (custom_samplers.py:59-72, identical arithmetic to choose_index); the 4-bit code;
 // the successor from the state's set; the arrival row's 8-bit visit counter (overflow list as in K1L); the reward code
 // (per successor state or per row) and the sequential float64 reward sum.  Results are bit-equal to K1 and the oracle.
 #pragma once
 
-#define K1S_THREADS 256
+#define K1S_THREADS 512      // up to four walker wavefronts + four producers
 #define K1S_MAXE 16          // entries per row (4-bit codes in a 64-bit word)
 #define K1S_OVF 30           // wrap events of the 8-bit counters an instance can record between two flushes
 #define K1S_MAXSTART 8
@@ -34,20 +39,22 @@ struct K1sPlan {
   int32_t n_codes;       // distinct reward values
   int32_t reward_mode;   // 0: code per successor state, 1: code per row
   int32_t ch;            // transitions per ring chunk
-  int32_t team;          // lanes of wavefront 0 per instance: 16 or 8 when G <= 4 / 8 (one or two entries per lane), else 1
+  int32_t team;          // lanes of a walker wavefront per instance (power of two <= 16: 16 / team entries per lane)
+  int32_t nw, gw;        // walker wavefronts, instances per walker wavefront (nw * gw >= G, gw * team <= 64)
+  int32_t n_shapes, shape_bytes;   // row shapes of the batch; bytes per row naming its shape (1 or 2)
   int32_t slot_bytes;    // LDS bytes per instance
-  int32_t off_pat, off_cnt, off_ovf, off_sets, off_rc, off_start;   // byte offsets inside a slot
-  const unsigned long long* codes;  // [R] 4-bit successor-set indices of the row's entries
-  const uint8_t* pat;               // [R] pattern of the row
+  int32_t off_cnt, off_ovf, off_sets, off_rc, off_start;   // byte offsets inside a slot (the shape ids start the slot)
+  const void* shape;                // [R] uint8 / uint16 shape of the row
+  const uint4* dict;                // [n_shapes] {word lo, word hi, pattern, 0}: the 4-bit successor-set indices of the row's entries
   const uint16_t* sets;             // [NS][U] successor sets
   const uint8_t* rcode;             // [NS] or [R] reward codes
   const double* patterns;           // [n_pat][K1S_PAT_STRIDE]
   const double* rvals;              // [n_codes]
 };
 
-__host__ __device__ inline size_t k1s_fixed_bytes(int n_pat) {
-  // patterns, reward values (after the range rescale), per-instance keys / counters
-  return (size_t)n_pat * K1S_PAT_STRIDE * 8 + 256 * 8 + 64 * 8 + 64 * 8 + 64 * 8;
+__host__ __device__ inline size_t k1s_fixed_bytes(int n_pat, int n_shapes) {
+  // patterns, reward values (after the range rescale), per-instance keys / counters, the shape dictionary
+  return (size_t)n_pat * K1S_PAT_STRIDE * 8 + 256 * 8 + 64 * 8 + 64 * 8 + 64 * 8 + (size_t)n_shapes * 16;
 }
 __host__ __device__ inline size_t k1s_ring_bytes(int ch) { return (size_t)2 * (8 * ch + ch); }  // per instance: uniforms + actions, 2 buffers
 
@@ -58,7 +65,8 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
   const int g0 = blockIdx.x * p.G;
   const int nb = min(p.G, t.B - g0);
   const int A = t.A, H = t.H, S = p.S, rows = p.rows, U = p.U, CH = p.ch;
-  double* pats = reinterpret_cast<double*>(k1s_smem);
+  uint4* dict = reinterpret_cast<uint4*>(k1s_smem);                               // [n_shapes], 16-byte aligned
+  double* pats = reinterpret_cast<double*>(dict + p.n_shapes);
   double* rv2 = pats + (size_t)p.n_pat * K1S_PAT_STRIDE;                         // [256]
   uint2* keys = reinterpret_cast<uint2*>(rv2 + 256);                              // [64]
   unsigned long long* ntr = reinterpret_cast<unsigned long long*>(keys + 64);     // [64] transition counters at launch
@@ -70,6 +78,8 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
   //      for the largest, S = p.S) ------------------------------------------------------------------------------------
   for (int i = tid; i < p.n_pat * K1S_PAT_STRIDE; i += K1S_THREADS) pats[i] = p.patterns[i];
   for (int i = tid; i < p.n_codes; i += K1S_THREADS) rv2[i] = p.rvals[i] * t.rscale - t.rmin;   // r * (max - min) - min, once per value
+  for (int i = tid; i < p.n_shapes; i += K1S_THREADS) dict[i] = p.dict[i];
+  const int SBY = p.shape_bytes;
   if (tid < nb) { keys[tid] = t.philox_key[g0 + tid]; ntr[tid] = t.n_trans[g0 + tid]; nrs[tid] = t.n_reset[g0 + tid]; }
   for (int i = tid; i < nb * rows; i += K1S_THREADS) {
     const int slot = i / rows, r = i - slot * rows;
@@ -77,8 +87,8 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
     unsigned char* sb = slots + (size_t)slot * p.slot_bytes;
     sb[p.off_cnt + r] = 0;
     if (r < (int)(t.state_off[g0 + slot + 1] - so) * A) {
-      reinterpret_cast<unsigned long long*>(sb)[r] = p.codes[so * A + r];
-      sb[p.off_pat + r] = p.pat[so * A + r];
+      if (SBY == 1) sb[r] = reinterpret_cast<const uint8_t*>(p.shape)[so * A + r];
+      else reinterpret_cast<uint16_t*>(sb)[r] = reinterpret_cast<const uint16_t*>(p.shape)[so * A + r];
       if (p.reward_mode == 1) sb[p.off_rc + r] = p.rcode[so * A + r];
     }
   }
@@ -102,24 +112,27 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
     }
     for (int k = 0; k < K1S_MAXSTART; ++k) reinterpret_cast<int32_t*>(sb + 48 + 8 * K1S_MAXSTART)[k] = 0;  // resets per start state
   }
-  // Wavefront 0 walks the instances in TEAMS of T lanes: the lanes of a team hold the same state and split the one part
+  // A walker wavefront walks its instances in TEAMS of T lanes: the lanes of a team hold the same state and split the one part
   // of a transition that is wide -- the comparison of u * total with the row's (padded) 16 cumulative probabilities:
   // every lane compares 16 / T of them, one wave-wide ballot per entry collects the results and the popcount of the
   // team's bits is bisect_right's index (the north star's "wavefront CDF lookup").  Lane 0 of a team owns its instance's
   // counters; teams beyond the group's instances shadow instance 0 without writing.
   const int T = p.team, E = K1S_MAXE / T;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NW = p.nw;
   const int team = (tid & 63) / T, sub = (tid & 63) - team * T;
-  const bool walker = tid < 64 && team < nb;
+  const int myslot = wave * p.gw + team;
+  const bool walker = wave < NW && team < p.gw && myslot < nb;
   const bool writer = walker && sub == 0;
-  const int wslot = walker ? team : 0;
+  const int wslot = walker ? myslot : 0;
   const int b = g0 + wslot;
   int32_t cur = t.cur[b], h = t.hstep[b];
   int32_t last_s = t.last_start[b], prev_s = t.prev_start[b];
   unsigned long long nr = t.n_reset[b];
   double sum = 0.0;
   unsigned char* base = slots + (size_t)wslot * p.slot_bytes;
-  const unsigned long long* codes = reinterpret_cast<const unsigned long long*>(base);
-  const uint8_t* pat = base + p.off_pat;
+  const uint8_t* shp8 = base;
+  const uint16_t* shp16 = reinterpret_cast<const uint16_t*>(base);
   uint8_t* c8 = base + p.off_cnt;
   uint16_t* ovf = reinterpret_cast<uint16_t*>(base + p.off_ovf);
   const uint16_t* sets = reinterpret_cast<const uint16_t*>(base + p.off_sets);
@@ -132,8 +145,8 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
 
   // producers: action byte and transition uniform of transitions [first, first + len) of every instance
   auto produce = [&](int buf, int64_t first, int len) {
-    const int ptid = tid - 64;
-    for (int item = ptid; item < nb * len; item += K1S_THREADS - 64) {
+    const int ptid = tid - 64 * NW;
+    for (int item = ptid; item < nb * len; item += K1S_THREADS - 64 * NW) {
       const int slot = item / len, j = item - slot * len;
       const unsigned long long n = ntr[slot] + (unsigned long long)(first + j);
       const uint2 key = keys[slot];
@@ -162,16 +175,16 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
 
   int64_t done = 0;
   int buf = 0;
-  if (n_steps > 0 && tid >= 64) produce(0, 0, (int)min((int64_t)CH, n_steps));
+  if (n_steps > 0 && wave >= NW) produce(0, 0, (int)min((int64_t)CH, n_steps));
   __syncthreads();
   int since_flush = 0;
   const bool episodic = H > 0;
   while (done < n_steps) {
     const int len = (int)min((int64_t)CH, n_steps - done);
-    if (tid >= 64) {
+    if (wave >= NW) {
       const int64_t nfirst = done + len;
       if (nfirst < n_steps) produce(buf ^ 1, nfirst, (int)min((int64_t)CH, n_steps - nfirst));
-    } else {   // wavefront 0, every lane (the ballots need the whole wave in step)
+    } else {   // a walker wavefront, every lane (the ballots need the whole wave in step)
       const double* us = reinterpret_cast<const double*>(ring_u) + ((size_t)buf * p.G + wslot) * CH;
       const unsigned char* as = ring_a + ((size_t)buf * p.G + wslot) * CH;
       const unsigned long long tmask = (T == 64) ? ~0ull : ((1ull << T) - 1ull);
@@ -179,8 +192,9 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
         const int a = as[s];
         const double u = us[s];
         const int row = cur * A + a;
-        const unsigned long long w = codes[row];
-        const double* pc = pats + (size_t)pat[row] * K1S_PAT_STRIDE;
+        const uint4 de = dict[SBY == 1 ? (uint32_t)shp8[row] : (uint32_t)shp16[row]];
+        const unsigned long long w = (unsigned long long)de.x | ((unsigned long long)de.y << 32);
+        const double* pc = pats + (size_t)de.z * K1S_PAT_STRIDE;
         const double x = u * (pc[16] + 0.0);
         int idx = 0;
         if (T == 1) {
