@@ -289,7 +289,9 @@ static int build_k1s(cmdp_t* h, const cmdp_desc* d) {
   const int64_t R = h->n_rows, NS = h->n_states;
   std::vector<uint16_t> shape((size_t)R, 0);
   std::vector<uint4> dict;
-  std::map<std::pair<int, unsigned long long>, int> shape_of;
+  std::map<std::tuple<int, unsigned long long, int>, int> shape_of;
+  std::vector<unsigned long long> words((size_t)R, 0);
+  std::vector<uint8_t> pat_ids((size_t)R, 0);
   std::vector<double> patterns;
   std::map<std::vector<uint64_t>, int> pat_of;
   std::map<uint64_t, int> code_of;
@@ -349,19 +351,27 @@ static int build_k1s(cmdp_t* h, const cmdp_desc* d) {
           if (rc_row[(size_t)r] < 0) rc_row[(size_t)r] = c;
           else if (rc_row[(size_t)r] != c) by_row = false;
         }
-        auto sh = shape_of.find({pat_id, word});
-        if (sh == shape_of.end()) {
-          if (dict.size() == 65535) return CMDP_OK;
-          sh = shape_of.emplace(std::make_pair(pat_id, word), (int)dict.size()).first;
-          dict.push_back(make_uint4((uint32_t)word, (uint32_t)(word >> 32), (uint32_t)pat_id, 0u));
-        }
-        shape[(size_t)r] = (uint16_t)sh->second;
+        words[(size_t)r] = word;
+        pat_ids[(size_t)r] = (uint8_t)pat_id;
       }
       U = std::max(U, (int)set.size());
     }
     if (d->start_off[b + 1] - d->start_off[b] > K1S_MAXSTART) return CMDP_OK;
   }
   if (!by_state && !by_row) return CMDP_OK;
+  // row shapes: (pattern, word) -- and, when the reward is a function of the row rather than of the successor state, the
+  // row's reward code, so that the shape's dictionary entry carries it
+  for (int64_t r = 0; r < R; ++r) {
+    const int rcd = by_state ? 0 : std::max(0, rc_row[(size_t)r]);
+    const auto key = std::make_tuple((int)pat_ids[(size_t)r], words[(size_t)r], rcd);
+    auto sh = shape_of.find(key);
+    if (sh == shape_of.end()) {
+      if (dict.size() == 65535) return CMDP_OK;
+      sh = shape_of.emplace(key, (int)dict.size()).first;
+      dict.push_back(make_uint4((uint32_t)words[(size_t)r], (uint32_t)(words[(size_t)r] >> 32), (uint32_t)pat_ids[(size_t)r], (uint32_t)rcd));
+    }
+    shape[(size_t)r] = (uint16_t)sh->second;
+  }
   K1sPlan p{};
   p.S = (int)S0; p.rows = (int)S0 * A; p.U = U; p.n_pat = (int)pat_of.size(); p.n_codes = (int)rvals.size();
   p.reward_mode = by_state ? 0 : 1;
@@ -372,8 +382,11 @@ static int build_k1s(cmdp_t* h, const cmdp_desc* d) {
   p.off_cnt = up8(p.rows * p.shape_bytes);
   p.off_ovf = up8(p.off_cnt + p.rows);
   p.off_sets = up8(p.off_ovf + 2 * (K1S_OVF + 2));
+  // reward code of the arrival state in the top four bits of its successor-set entries (no separate look-up on the walk)
+  // when both fit sixteen bits; per-row codes travel in the shape's dictionary entry: no per-instance code table then
+  p.rc_packed = (by_state && S0 <= 4096 && rvals.size() <= 16) ? 1 : 0;
   p.off_rc = up8(p.off_sets + 2 * p.S * U);
-  p.off_start = up8(p.off_rc + (by_state ? p.S : p.rows));
+  p.off_start = up8(p.off_rc + ((by_state && !p.rc_packed) ? p.S : 0));
   p.slot_bytes = up8(p.off_start + 48 + 8 * K1S_MAXSTART + 4 * K1S_MAXSTART);
   const size_t fixed = k1s_fixed_bytes(p.n_pat, p.n_shapes) + 64;
   const size_t per = (size_t)p.slot_bytes + k1s_ring_bytes(p.ch);
@@ -398,8 +411,15 @@ static int build_k1s(cmdp_t* h, const cmdp_desc* d) {
   }
   hipStream_t st = h->stream;
   std::vector<uint16_t> sets_flat((size_t)NS * U, 0);
-  for (int64_t s = 0; s < NS; ++s)
-    for (size_t j = 0; j < sets[(size_t)s].size(); ++j) sets_flat[(size_t)s * U + j] = (uint16_t)sets[(size_t)s][j];
+  for (int b = 0; b < B; ++b) {
+    const int64_t so = h->state_off[b];
+    for (int64_t s = so; s < h->state_off[b + 1]; ++s)
+      for (size_t j = 0; j < sets[(size_t)s].size(); ++j) {
+        const int32_t nx = sets[(size_t)s][j];
+        const int code = p.rc_packed ? std::max(0, rc_state[(size_t)(so + nx)]) : 0;
+        sets_flat[(size_t)s * U + j] = (uint16_t)(nx | (code << 12));
+      }
+  }
   std::vector<uint8_t> rc(by_state ? (size_t)NS : (size_t)R, 0);
   for (size_t i = 0; i < rc.size(); ++i) rc[i] = (uint8_t)std::max(0, by_state ? rc_state[i] : rc_row[i]);
   if (p.shape_bytes == 1) {

@@ -37,7 +37,8 @@ struct K1sPlan {
   int32_t U;             // successor-set slots per state
   int32_t n_pat;         // patterns
   int32_t n_codes;       // distinct reward values
-  int32_t reward_mode;   // 0: code per successor state, 1: code per row
+  int32_t reward_mode;   // 0: code per successor state, 1: code per row (carried by the row's shape)
+  int32_t rc_packed;     // mode 0: the successor-set entries hold state | code << 12 (no per-instance code table)
   int32_t ch;            // transitions per ring chunk
   int32_t team;          // lanes of a walker wavefront per instance (power of two <= 16: 16 / team entries per lane)
   int32_t nw, gw;        // walker wavefronts, instances per walker wavefront (nw * gw >= G, gw * team <= 64)
@@ -89,7 +90,6 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
     if (r < (int)(t.state_off[g0 + slot + 1] - so) * A) {
       if (SBY == 1) sb[r] = reinterpret_cast<const uint8_t*>(p.shape)[so * A + r];
       else reinterpret_cast<uint16_t*>(sb)[r] = reinterpret_cast<const uint16_t*>(p.shape)[so * A + r];
-      if (p.reward_mode == 1) sb[p.off_rc + r] = p.rcode[so * A + r];
     }
   }
   for (int i = tid; i < nb * S; i += K1S_THREADS) {
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
     if (s < (int)(t.state_off[g0 + slot + 1] - so)) {
       unsigned char* sb = slots + (size_t)slot * p.slot_bytes;
       for (int u = 0; u < U; ++u) reinterpret_cast<uint16_t*>(sb + p.off_sets)[s * U + u] = p.sets[(so + s) * U + u];
-      if (p.reward_mode == 0) sb[p.off_rc + s] = p.rcode[so + s];
+      if (p.reward_mode == 0 && !p.rc_packed) sb[p.off_rc + s] = p.rcode[so + s];
     }
   }
   if (tid < nb) {  // start sampler of the instance: states and accumulated probabilities
@@ -188,13 +188,35 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
       const double* us = reinterpret_cast<const double*>(ring_u) + ((size_t)buf * p.G + wslot) * CH;
       const unsigned char* as = ring_a + ((size_t)buf * p.G + wslot) * CH;
       const unsigned long long tmask = (T == 64) ? ~0ull : ((1ull << T) - 1ull);
+      // Software-pipelined by hand: per transition the STATE depends on three LDS round trips in a row (shape byte ->
+      // dictionary entry -> successor-set entry; the cumulative values come with the dictionary entry's pattern, or at once
+      // when the batch has a single pattern).  Everything else is taken off that chain: the action byte and the uniform
+      // of transition s + 1 are fetched a transition ahead, and the bookkeeping of transition s - 1 (8-bit visit counter,
+      // reward value, float64 sum in transition order) is issued right behind transition s's first read, so that its
+      // round trips ride in that read's shadow (LDS returns a wavefront's reads in order).
+      const bool one_pat = p.n_pat == 1;
+      const bool packed = p.rc_packed != 0;
+      const int mode = p.reward_mode;
+      int a_n = as[0];
+      double u_n = us[0];
+      int prev_arow = -1;
+      double rv_prev = 0.0;
       for (int s = 0; s < len; ++s) {
-        const int a = as[s];
-        const double u = us[s];
+        const int a = a_n;
+        const double u = u_n;
         const int row = cur * A + a;
-        const uint4 de = dict[SBY == 1 ? (uint32_t)shp8[row] : (uint32_t)shp16[row]];
+        const uint32_t sh = SBY == 1 ? (uint32_t)shp8[row] : (uint32_t)shp16[row];
+        if (s + 1 < len) { a_n = as[s + 1]; u_n = us[s + 1]; }
+        if (writer && prev_arow >= 0) {
+          const int c1 = (int)c8[prev_arow] + 1;
+          ovf[n_ovf] = (uint16_t)prev_arow;                 // kept only on a wrap
+          n_ovf += c1 >> 8;
+          c8[prev_arow] = (uint8_t)c1;
+        }
+        sum += rv_prev;
+        const uint4 de = dict[sh];
         const unsigned long long w = (unsigned long long)de.x | ((unsigned long long)de.y << 32);
-        const double* pc = pats + (size_t)de.z * K1S_PAT_STRIDE;
+        const double* pc = one_pat ? pats : pats + (size_t)de.z * K1S_PAT_STRIDE;
         const double x = u * (pc[16] + 0.0);
         int idx = 0;
         if (T == 1) {
@@ -207,15 +229,11 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
           }
         }
         const int code = (int)((w >> (4 * idx)) & 15ull);
-        const int nxt = sets[cur * U + code];
-        const int arow = nxt * A + a;                       // arrival node under the action taken (base.py:1302-1303)
-        if (writer) {
-          const int c1 = (int)c8[arow] + 1;
-          ovf[n_ovf] = (uint16_t)arow;                      // kept only on a wrap
-          n_ovf += c1 >> 8;
-          c8[arow] = (uint8_t)c1;
-        }
-        sum += rv2[p.reward_mode == 0 ? rc[nxt] : rc[row]];
+        const int se = sets[cur * U + code];
+        const int nxt = packed ? (se & 0xfff) : se;
+        const int rcode = packed ? (se >> 12) : (mode == 0 ? (int)rc[nxt] : (int)de.w);
+        rv_prev = rv2[rcode];                               // consumed a transition later
+        prev_arow = nxt * A + a;                            // arrival node under the action taken (base.py:1302-1303)
         ++h;
         cur = nxt;
         if (episodic && h >= H) {                           // episodic termination followed at once by reset()
@@ -236,6 +254,13 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
           last_s = cur;
         }
       }
+      if (writer && prev_arow >= 0) {                       // the last transition's bookkeeping
+        const int c1 = (int)c8[prev_arow] + 1;
+        ovf[n_ovf] = (uint16_t)prev_arow;
+        n_ovf += c1 >> 8;
+        c8[prev_arow] = (uint8_t)c1;
+      }
+      sum += rv_prev;
     }
     done += len;
     since_flush += len;
