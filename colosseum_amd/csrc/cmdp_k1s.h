@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
   // every lane compares 16 / T of them, one wave-wide ballot per entry collects the results and the popcount of the
   // team's bits is bisect_right's index (the north star's "wavefront CDF lookup").  Lane 0 of a team owns its instance's
   // counters; teams beyond the group's instances shadow instance 0 without writing.
-  const int T = p.team, E = K1S_MAXE / T;
+  const int T = p.team;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NW = p.nw;
   const int team = (tid & 63) / T, sub = (tid & 63) - team * T;
@@ -187,80 +187,118 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
     } else {   // a walker wavefront, every lane (the ballots need the whole wave in step)
       const double* us = reinterpret_cast<const double*>(ring_u) + ((size_t)buf * p.G + wslot) * CH;
       const unsigned char* as = ring_a + ((size_t)buf * p.G + wslot) * CH;
-      const unsigned long long tmask = (T == 64) ? ~0ull : ((1ull << T) - 1ull);
       // Software-pipelined by hand: per transition the STATE depends on three LDS round trips in a row (shape byte ->
-      // dictionary entry -> successor-set entry; the cumulative values come with the dictionary entry's pattern, or at once
-      // when the batch has a single pattern).  Everything else is taken off that chain: the action byte and the uniform
+      // dictionary entry -> successor-set entry).  Everything else is taken off that chain: the action byte and the uniform
       // of transition s + 1 are fetched a transition ahead, and the bookkeeping of transition s - 1 (8-bit visit counter,
       // reward value, float64 sum in transition order) is issued right behind transition s's first read, so that its
       // round trips ride in that read's shadow (LDS returns a wavefront's reads in order).
-      const bool one_pat = p.n_pat == 1;
-      const bool packed = p.rc_packed != 0;
-      const int mode = p.reward_mode;
-      int a_n = as[0];
-      double u_n = us[0];
-      int prev_arow = -1;
-      double rv_prev = 0.0;
-      for (int s = 0; s < len; ++s) {
-        const int a = a_n;
-        const double u = u_n;
-        const int row = cur * A + a;
-        const uint32_t sh = SBY == 1 ? (uint32_t)shp8[row] : (uint32_t)shp16[row];
-        if (s + 1 < len) { a_n = as[s + 1]; u_n = us[s + 1]; }
-        if (writer && prev_arow >= 0) {
+      // The loop exists in SPECIALISED forms -- team size, single pattern (the cumulative values of the lane's entries and
+      // the total then live in registers for the whole chunk), one shape byte, where the reward code comes from -- all
+      // compile-time: the generic form below them carries a dozen uniform branches and a full LDS wait behind each, which
+      // made a transition cost ~440 ns whatever the team size.  TT = 0 / OP = -1 / RM = -1: read from the plan at run time.
+      auto walk = [&](auto tt_tag, auto op_tag, auto rm_tag) {
+        constexpr int TT = decltype(tt_tag)::value, OPc = decltype(op_tag)::value, RMc = decltype(rm_tag)::value;
+        constexpr int EC = K1S_MAXE / (TT ? TT : K1S_MAXE);   // entries per lane, compile time (1 when TT is not given)
+        const int Tn = TT ? TT : T;
+        const int En = K1S_MAXE / Tn;
+        const bool one_pat = OPc < 0 ? (p.n_pat == 1) : (OPc != 0);
+        const int rmode = RMc < 0 ? (p.rc_packed ? 0 : (p.reward_mode == 0 ? 1 : 2)) : RMc;   // 0 packed, 1 per state, 2 per row
+        const int sby = (TT && OPc >= 0) ? 1 : SBY;   // the specialised forms are instantiated for one shape byte
+        const unsigned long long tmask = (Tn == 64) ? ~0ull : ((1ull << Tn) - 1ull);
+        const int tshift = team * Tn;
+        double total0 = 0.0, cum0[K1S_MAXE];
+        if (one_pat) {
+          total0 = pats[16] + 0.0;
+          if (TT) {
+#pragma unroll
+            for (int e = 0; e < EC; ++e) cum0[e] = pats[sub * En + e];
+          }
+        }
+        int a_n = as[0];
+        double u_n = us[0];
+        int prev_arow = -1;
+        double rv_prev = 0.0;
+        for (int s = 0; s < len; ++s) {
+          const int a = a_n;
+          const double u = u_n;
+          const int row = cur * A + a;
+          const uint32_t sh = sby == 1 ? (uint32_t)shp8[row] : (uint32_t)shp16[row];
+          if (s + 1 < len) { a_n = as[s + 1]; u_n = us[s + 1]; }
+          if (writer && prev_arow >= 0) {
+            const int c1 = (int)c8[prev_arow] + 1;
+            ovf[n_ovf] = (uint16_t)prev_arow;                 // kept only on a wrap
+            n_ovf += c1 >> 8;
+            c8[prev_arow] = (uint8_t)c1;
+          }
+          sum += rv_prev;
+          const uint4 de = dict[sh];
+          const unsigned long long w = (unsigned long long)de.x | ((unsigned long long)de.y << 32);
+          const double* pc = one_pat ? pats : pats + (size_t)de.z * K1S_PAT_STRIDE;
+          const double x = u * (one_pat ? total0 : (pc[16] + 0.0));
+          int idx = 0;
+          if (Tn == 1) {
+#pragma unroll
+            for (int k = 0; k < K1S_MAXE; ++k) idx += ((TT && one_pat ? cum0[k] : pc[k]) <= x) ? 1 : 0;   // padded with +inf beyond n - 1
+          } else if (TT) {
+#pragma unroll
+            for (int e = 0; e < EC; ++e) {
+              const unsigned long long bal = __ballot((one_pat ? cum0[e] : pc[sub * En + e]) <= x);
+              idx += __popcll((bal >> tshift) & tmask);
+            }
+          } else {
+            for (int e = 0; e < En; ++e) {
+              const unsigned long long bal = __ballot(pc[sub * En + e] <= x);
+              idx += __popcll((bal >> tshift) & tmask);
+            }
+          }
+          const int code = (int)((w >> (4 * idx)) & 15ull);
+          const int se = sets[cur * U + code];
+          const int nxt = rmode == 0 ? (se & 0xfff) : se;
+          const int rcode = rmode == 0 ? (se >> 12) : (rmode == 1 ? (int)rc[nxt] : (int)de.w);
+          rv_prev = rv2[rcode];                               // consumed a transition later
+          prev_arow = nxt * A + a;                            // arrival node under the action taken (base.py:1302-1303)
+          ++h;
+          cur = nxt;
+          if (episodic && h >= H) {                           // episodic termination followed at once by reset()
+            h = 0;
+            int k = 0;
+            const int ns = st_n[0];
+            if (ns > 1) {
+              uint32_t ww[4];
+              const uint2 key = keys[wslot];
+              philox4x32_10((uint32_t)nr, (uint32_t)(nr >> 32), 1u, 0u, key.x, key.y, ww);
+              const double xs = u53(ww[0], ww[1]) * (st_cum[ns - 1] + 0.0);
+              for (int i = 0; i < ns - 1; ++i) k += (st_cum[i] <= xs) ? 1 : 0;
+            }
+            ++nr;
+            cur = st_n[1 + k];
+            if (writer) st_res[k] += 1;
+            prev_s = last_s;
+            last_s = cur;
+          }
+        }
+        if (writer && prev_arow >= 0) {                       // the last transition's bookkeeping
           const int c1 = (int)c8[prev_arow] + 1;
-          ovf[n_ovf] = (uint16_t)prev_arow;                 // kept only on a wrap
+          ovf[n_ovf] = (uint16_t)prev_arow;
           n_ovf += c1 >> 8;
           c8[prev_arow] = (uint8_t)c1;
         }
         sum += rv_prev;
-        const uint4 de = dict[sh];
-        const unsigned long long w = (unsigned long long)de.x | ((unsigned long long)de.y << 32);
-        const double* pc = one_pat ? pats : pats + (size_t)de.z * K1S_PAT_STRIDE;
-        const double x = u * (pc[16] + 0.0);
-        int idx = 0;
-        if (T == 1) {
-#pragma unroll
-          for (int k = 0; k < K1S_MAXE; ++k) idx += (pc[k] <= x) ? 1 : 0;   // padded with +inf beyond n - 1: those never count
-        } else {
-          for (int e = 0; e < E; ++e) {
-            const unsigned long long bal = __ballot(pc[sub * E + e] <= x);
-            idx += __popcll((bal >> (team * T)) & tmask);
-          }
-        }
-        const int code = (int)((w >> (4 * idx)) & 15ull);
-        const int se = sets[cur * U + code];
-        const int nxt = packed ? (se & 0xfff) : se;
-        const int rcode = packed ? (se >> 12) : (mode == 0 ? (int)rc[nxt] : (int)de.w);
-        rv_prev = rv2[rcode];                               // consumed a transition later
-        prev_arow = nxt * A + a;                            // arrival node under the action taken (base.py:1302-1303)
-        ++h;
-        cur = nxt;
-        if (episodic && h >= H) {                           // episodic termination followed at once by reset()
-          h = 0;
-          int k = 0;
-          const int ns = st_n[0];
-          if (ns > 1) {
-            uint32_t ww[4];
-            const uint2 key = keys[wslot];
-            philox4x32_10((uint32_t)nr, (uint32_t)(nr >> 32), 1u, 0u, key.x, key.y, ww);
-            const double xs = u53(ww[0], ww[1]) * (st_cum[ns - 1] + 0.0);
-            for (int i = 0; i < ns - 1; ++i) k += (st_cum[i] <= xs) ? 1 : 0;
-          }
-          ++nr;
-          cur = st_n[1 + k];
-          if (writer) st_res[k] += 1;
-          prev_s = last_s;
-          last_s = cur;
-        }
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      using I8 = std::integral_constant<int, 8>;
+      using I16 = std::integral_constant<int, 16>;
+      using IR = std::integral_constant<int, -1>;
+      const int rm = p.rc_packed ? 0 : (p.reward_mode == 0 ? 1 : 2);
+      if (p.n_pat == 1 && SBY == 1 && (T == 16 || T == 8 || T == 1)) {
+        if (T == 16) { if (rm == 0) walk(I16{}, I1{}, I0{}); else if (rm == 1) walk(I16{}, I1{}, I1{}); else walk(I16{}, I1{}, I2{}); }
+        else if (T == 8) { if (rm == 0) walk(I8{}, I1{}, I0{}); else if (rm == 1) walk(I8{}, I1{}, I1{}); else walk(I8{}, I1{}, I2{}); }
+        else { if (rm == 0) walk(I1{}, I1{}, I0{}); else if (rm == 1) walk(I1{}, I1{}, I1{}); else walk(I1{}, I1{}, I2{}); }
+      } else {
+        walk(I0{}, IR{}, IR{});
       }
-      if (writer && prev_arow >= 0) {                       // the last transition's bookkeeping
-        const int c1 = (int)c8[prev_arow] + 1;
-        ovf[n_ovf] = (uint16_t)prev_arow;
-        n_ovf += c1 >> 8;
-        c8[prev_arow] = (uint8_t)c1;
-      }
-      sum += rv_prev;
     }
     done += len;
     since_flush += len;
