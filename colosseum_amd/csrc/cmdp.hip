@@ -1366,11 +1366,13 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
                                       "cumulative-probability patterns, deterministic rewards that depend on the successor or on "
                                       "the row alone, and room for four instances in LDS");
   // K1S runs G instances per CU at a time however large the batch is (LDS capacity), K1's rate grows with the batch (more
-  // wavefronts cover its HBM latency) until bandwidth caps it: measured (tools/exp_k1s_batch.py, profiles/
-  // r02_k1_vs_k1s_batch.json) K1 ~ B x 2.5e5 / (1 + B / 40 000) transitions/s, K1S ~ CUs x G / 480 ns.  FrozenLake-20
-  // (G = 8): K1S up to ~35 000 instances, K1 beyond (131 072 instances: 6.7e9 against 4.5e9).
+  // wavefronts cover its HBM latency) until bandwidth caps it: K1 ~ B x 2.5e5 / (1 + B / 40 000) transitions/s (measured,
+  // profiles/r02_k1_vs_k1s_batch.json).  Round 3 (row-shape dictionary: 2-3 x the instances per CU; four walker
+  // wavefronts; specialised, hand-pipelined walker): K1S ~ CUs x G / 320-470 ns -- FrozenLake-20 1.44e10 at 4 096 instances
+  // and 1.85e10 at 131 072 (K1: 0.8e9 / 6.6e9), so K1S stays ahead at every batch size measured
+  // (profiles/r03_k1s_walkers.txt); the model is kept for batches where few instances fit a CU.
   const double k1_rate = (double)h->B * 2.5e5 / (1.0 + (double)h->B / 4.0e4);
-  const double k1s_rate = (double)h->cus * (double)h->k1s.G / 480e-9;
+  const double k1s_rate = (double)h->cus * (double)h->k1s.G / 450e-9;
   const bool k1s_pays = k1_rate < 1.1 * k1s_rate;
   if (k1s_eligible && (h->rollout_kernel == 3 || (h->rollout_kernel == 0 && n_steps >= 64 && k1s_pays))) {
     if (int rc = set_lds(k_rollout_stoch, h->k1s_bytes)) return rc;

@@ -113,7 +113,7 @@ def check_one():
         env.close()
         # the other rollout kernels on the same streams: HBM tables (K1), the LDS kernels where the batch is eligible
         # (K1L / K1P, the shared-table K1T, the stochastic-dynamics K1S)
-        for which in (L.ROLLOUT_GLOBAL, L.ROLLOUT_LDS, L.ROLLOUT_LDS_TEMPLATE, L.ROLLOUT_LDS_STOCHASTIC):
+        for which in (L.ROLLOUT_GLOBAL, L.ROLLOUT_LDS, L.ROLLOUT_LDS_TEMPLATE, L.ROLLOUT_LDS_TEMPLATE_STREAM, L.ROLLOUT_LDS_STOCHASTIC):
             env = BatchedMDP([m] * 3, rng_mode=L.RNG_PHILOX, philox_keys=keys, with_dp=False)
             env.set_rollout_kernel(which)
             env.reset()
