@@ -51,7 +51,7 @@ N_CUS = 256
 CLOCK_HZ = 2.4e9        # MI355X peak engine clock
 VALU_CYCLES = 2         # MI355X_MICROARCH.md, per-instruction constants: wave64 v_fma_f32 = 2 cycles per SIMD
 LDS_BYTES = 160 * 1024  # per CU
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
 
 
 class HipEvents:
@@ -174,7 +174,7 @@ def pmc_entry(kernel_prefix, units_per_launch, build_id):
     except Exception:
         return None
     for k in j.get("kernels", []):
-        if k["kernel"].startswith(kernel_prefix) and k.get("units_per_launch") == units_per_launch:
+        if k["kernel"].split("<")[0] == kernel_prefix.split("<")[0] and k.get("units_per_launch") == units_per_launch:
             return dict(bytes=k["hbm_bytes_per_launch"], read=k["hbm_read_bytes_per_launch"], write=k["hbm_write_bytes_per_launch"],
                         current=j.get("build_id") == build_id, source="profiles/" + os.path.basename(PMC_FILE),
                         collected_on_build=j.get("build_id", "")[:16])
@@ -426,16 +426,19 @@ def main():
             epp = 12 if S * A <= 1024 else 8   # trace entries per 16-byte piece (ten-bit rows when they fit)
             hist_bytes = units_per_launch * 16 / epp + 8 * B * S * A + 8 * B * S
             roofline["kernel_ms"] = kernel_ms
+            pm_h = pmc_entry("k_trace_hist", units_per_launch, build_id)
             roofline["step"] = {
                 "what": "a step = k_rollout_tmpl_stream (the chains; 16-bit trace -> HBM) followed by k_trace_hist (visit counts from "
                         "the trace): `achieved` / `frac` above are the dominant kernel's over ITS duration, these are the whole step's",
                 "achieved": kernel_rate / 1e9, "frac": kernel_rate / peak,
+                "hbm_traffic_bytes": (hv["traffic"] + pm_h["bytes"]) if (hv["traffic"] and pm_h) else None,
                 "frac_against_bare_lds_read": kernel_rate / (N_CUS * chains_per_cu / (ns_read.value * 1e-9)),
                 "hist_roofline": {"bound": "hbm", "kernel": "k_trace_hist",
                                   "algorithmic_bytes_per_launch": hist_bytes,
                                   "accounting": "trace read (16 B per %d transitions) + read-modify-write of visits_sa and visits_s" % epp,
                                   "achieved": (hist_bytes) / (kernel_ms["k_trace_hist"] * 1e-3) / 1e9,
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": pm_h["bytes"] if pm_h else None,
+                                  "traffic_frac": pm_h["bytes"] / (kernel_ms["k_trace_hist"] * 1e-3) / 1e9 / HBM_PEAK_GBS if pm_h else None,
                                   "frac": (hist_bytes) / (kernel_ms["k_trace_hist"] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
     roofline["launch_ms_avg"] = avg_launch_s * 1e3
     roofline["launch_ms_min"] = float(np.min(launch_ms))

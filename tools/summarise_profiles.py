@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copies what tools/collect_profiles.sh left under gpurun_out/TAG_* into profiles/ and writes profiles/r02_pmc.json,
+"""Copies what tools/collect_profiles.sh left under gpurun_out/TAG_* into profiles/ and writes profiles/r03_pmc.json,
 the summary bench.py reads for `roofline.traffic` (HBM bytes per launch: FETCH_SIZE x2 per the gfx950 correction for
 wide coalesced reads + WRITE_SIZE, separate --pmc passes) and for the VI leg's instruction counts (SQ_INSTS_VALU etc. per
 sweep).  The summary carries the build id of the library the passes ran on; bench.py reports whether that is the build
@@ -50,6 +50,8 @@ for leg, ks_ in legs.items():
 
 cfg = line["config"]
 units = {"k_rollout_pipe": cfg["instances_per_gpu"] * cfg["transitions_per_instance_per_step"],
+         "k_rollout_tmpl_stream": cfg["instances_per_gpu"] * cfg["transitions_per_instance_per_step"],
+         "k_trace_hist": cfg["instances_per_gpu"] * cfg["transitions_per_instance_per_step"],
          "k_rollout_tmpl": cfg["instances_per_gpu"] * cfg["transitions_per_instance_per_step"],
          "k_rollout_lds": cfg["instances_per_gpu"] * cfg["transitions_per_instance_per_step"],
          "k_rollout_dense": 65536 * 200}
@@ -64,7 +66,7 @@ for k in sorted(names):
         e.update(FETCH_SIZE_KB_reported=f[0], WRITE_SIZE_KB_reported=wr[0], hbm_read_bytes_per_launch=f[0] * 2048,
                  hbm_write_bytes_per_launch=wr[0] * 1024, hbm_bytes_per_launch=f[0] * 2048 + wr[0] * 1024)
     for pre, u in units.items():
-        if short.startswith(pre):
+        if short.split("<")[0] == pre:
             e["units_per_launch"] = u
     s1, s2 = legs["sq1"].get(k, {}), legs["sq2"].get(k, {})
     for c, (v, n) in list(s1.items()) + list(s2.items()):
@@ -82,7 +84,7 @@ for k in sorted(names):
         e["kernel_cycles"] = cyc
         e["lds_idx_active_frac"] = e["SQ_LDS_IDX_ACTIVE"] / (256 * cyc)                     # LDS pipe busy, per CU
         e["valu_issue_frac_at_2_cycles"] = e["SQ_INSTS_VALU"] * 2 / (1024 * cyc)            # 1024 SIMDs, wave64 fp32 op = 2 cycles
-    if len(e) > 1 and ("rollout" in short or "dp_reg" in short):
+    if len(e) > 1 and ("rollout" in short or "dp_reg" in short or "trace_hist" in short):
         kernels.append(e)
 j = dict(build_id=None, tag=tag, kernels=kernels,
          correction="gfx950: FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced streaming reads -> x2 "
@@ -96,6 +98,6 @@ try:
     assert j["build_id"][:16] == under["build_id"], (j["build_id"][:16], under["build_id"])
 except ImportError:
     pass
-json.dump(j, open(f"{prof}/r02_pmc.json", "w"), indent=1)
+json.dump(j, open(f"{prof}/r03_pmc.json", "w"), indent=1)
 for e in kernels:
     print(e["kernel"], {k: (round(v, 3) if isinstance(v, float) else v) for k, v in e.items() if k != "kernel"})
