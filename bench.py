@@ -165,10 +165,58 @@ def sustained_leg(env, ev, launch_steps, seconds, B):
     }
 
 
+LIVE_PMC = None   # {kernel base name: {"read": bytes, "write": bytes, "launches": n}} measured by child runs under rocprofv3
+
+
+def live_pmc(child_args, timeout=170):
+    """HBM traffic per launch MEASURED IN THIS RUN: two child runs of this script's headline and dense legs under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes: the two counters do not fit the TCC slots
+    together; --kernel-trace is the only other option on the command line, the program comes directly after `--`), per-kernel
+    means of the collected values.  FETCH_SIZE x 2 per the gfx950 correction for wide coalesced reads, both counters in
+    KiB.  Returns None when rocprofv3 is missing or a pass fails (the committed summary is used then)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    out = {}
+    for counter, scale, key in (("FETCH_SIZE", 2048.0, "read"), ("WRITE_SIZE", 1024.0, "write")):
+        d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "--output-format", "csv", "--", sys.executable,
+               os.path.abspath(__file__), "--pmc-child"] + child_args
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None
+            acc = {}
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == counter:
+                    acc.setdefault(row["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0], []).append(float(row["Counter_Value"]))
+            for k, v in acc.items():
+                out.setdefault(k, {})[key] = scale * sum(v) / len(v)
+                out[k]["launches"] = len(v)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {k: v for k, v in out.items() if "read" in v and "write" in v}
+
+
 def pmc_entry(kernel_prefix, units_per_launch, build_id):
     """HBM bytes per launch of a kernel from the committed summary of this round's `--pmc FETCH_SIZE` / `--pmc
     WRITE_SIZE` passes (their own rocprofv3 runs, tools/collect_profiles.sh).  Returned only when the summary was
     collected on the same workload; `current` says whether it was collected on THIS build of the library."""
+    base = kernel_prefix.split("<")[0]
+    if LIVE_PMC and base in LIVE_PMC:   # measured in this run (child passes under rocprofv3)
+        v = LIVE_PMC[base]
+        return dict(bytes=v["read"] + v["write"], read=v["read"], write=v["write"], current=True,
+                    source="this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of bench.py, %d launches" % v["launches"],
+                    collected_on_build=build_id[:16])
     try:
         j = json.load(open(PMC_FILE))
     except Exception:
@@ -205,10 +253,16 @@ def main():
                          "[r*B/N, (r+1)*B/N) of SURVEY 8(e)")
     ap.add_argument("--sustained-seconds", type=float, default=10.0, help="length of the sustained leg (0: skip)")
     ap.add_argument("--strong-share", type=int, default=8, help="rehearse one rank's share of a strong split over this many GPUs (0: skip)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from the committed PMC summary instead of "
+                    "measuring it in child runs under rocprofv3 (about 40 s)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the child run live_pmc() profiles
     ap.add_argument("--layout", default="csr", choices=["csr", "dense"],
                     help="layout of the HEADLINE leg: csr (default, fastest) or dense (then --launch-steps applies to K1D)")
     args = ap.parse_args()
 
+    if args.pmc_child:   # a few launches of the headline and dense kernels, nothing else, nothing printed
+        args.steps, args.warmup, args.dense_steps = 3, 1, 2
+        args.no_cpu, args.no_live_pmc, args.vi_instances, args.sustained_seconds, args.strong_share = True, True, 0, 0.0, 0
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
@@ -344,6 +398,15 @@ def main():
     if args.sustained_seconds > 0 and world == 1 and not dense_headline:
         sustained = sustained_leg(env, ev, args.launch_steps, args.sustained_seconds, B)
 
+    # ---- HBM traffic of the headline and dense kernels, measured now (child runs under rocprofv3 --pmc; N = 1 only) ------
+    global LIVE_PMC
+    if world == 1 and not args.no_live_pmc and not dense_headline:
+        t_pmc = time.time()
+        LIVE_PMC = live_pmc(["--instances", str(B), "--size", str(args.size), "--launch-steps", str(args.launch_steps),
+                             "--dense-instances", str(args.dense_instances), "--dense-launch-steps", str(args.dense_launch_steps),
+                             "--rollout-kernel", str(args.rollout_kernel)])
+        t_pmc = time.time() - t_pmc
+
     units_per_launch = B * args.launch_steps
     total_steps = world * units_per_launch * args.steps
     value = total_steps / elapsed
@@ -362,6 +425,7 @@ def main():
             "traffic_frac": pm["bytes"] / launch_s / 1e9 / HBM_PEAK_GBS if pm else None,
             "traffic_source": ("%s (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate --pmc passes; collected on "
                                "build %s = %s build)" % (pm["source"], pm["collected_on_build"], "this" if pm["current"] else "ANOTHER")) if pm else None,
+            "traffic_measured_in_this_run": bool(LIVE_PMC) and pm is not None and pm["source"].startswith("this run"),
             "traffic_current": pm["current"] if pm else None,
         }
 
