@@ -218,6 +218,12 @@ struct cmdp {
   DevBuf<int64_t> d_ch_off;
   DevBuf<int32_t> d_ch_kind, d_ch_ncls, d_ch_act, d_ch_start, d_ch_idx;
   DevBuf<uint8_t> d_ch_mask;
+  // K9F: fill-reducing elimination plan of every instance (build_chain_plan), built at the first average-reward call
+  bool chain_plan_built = false, chain_plan_any = false;
+  DevBuf<int32_t> d_cf_rank, d_cf_cptr, d_cf_nrounds, d_cf_rptr, d_cf_piv;
+  DevBuf<int64_t> d_cf_cbase, d_cf_rbase;
+  DevBuf<uint16_t> d_cf_cand;
+  DevBuf<uint8_t> d_cf_slow;
   DevBuf<float> d_dense;  // CMDP_LAYOUT_DENSE: [R][dense_spad]
   int dense_spad = 0;
   DevBuf<uint16_t> d_next16;
@@ -1551,6 +1557,16 @@ int cmdp_stat(cmdp_t* h, int which, double* out) {
     *out = ms;
     return CMDP_OK;
   }
+  if (which == CMDP_STAT_CHAIN_FAST_INSTANCES) {
+    if (!h->chain_plan_any) { *out = 0.0; return CMDP_OK; }
+    std::vector<uint8_t> slow((size_t)h->B);
+    HIP_TRY(hipMemcpyAsync(slow.data(), h->d_cf_slow.p, (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    int n = 0;
+    for (uint8_t x : slow) n += x == 0;
+    *out = (double)n;
+    return CMDP_OK;
+  }
   if (which == CMDP_STAT_REWARD_FILLS || which == CMDP_STAT_REWARD_ROUNDS) {
     *out = (double)(which == CMDP_STAT_REWARD_FILLS ? h->rc_fills : h->rc_rounds);
     return CMDP_OK;
@@ -2675,6 +2691,142 @@ int cmdp_qlearning_policy(cmdp_agent_t* a, float* pi) {
   return CMDP_OK;
 }
 
+// K9F's host side (cmdp_chain.h): per instance a minimum-degree elimination order of the MDP's transition graph (union over
+// the actions, symmetrised), every pivot's candidate list in the filled graph, and a schedule of rounds of up to 16 pivots
+// that are pairwise non-adjacent and share at most one candidate.  Instances without a plan (a pivot with more than 64
+// candidates, more than 65 535 states) keep K9.
+static int build_chain_plan(cmdp_t* h) {
+  h->chain_plan_built = true;
+  const int B = h->B, A = h->A;
+  hipStream_t st = h->stream;
+  std::vector<int64_t> ptr((size_t)h->n_rows + 1);
+  std::vector<int32_t> col((size_t)h->n_csr);
+  std::vector<float> val((size_t)h->n_csr);
+  HIP_TRY(hipMemcpyAsync(ptr.data(), h->d_csr_ptr.p, sizeof(int64_t) * ptr.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(col.data(), h->d_csr_col.p, sizeof(int32_t) * col.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(val.data(), h->d_csr_val.p, sizeof(float) * val.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  constexpr int W = 16, NARROW = 64;
+  std::vector<int32_t> rank((size_t)h->n_states, -1), cptr((size_t)h->n_states + B, 0), nrounds((size_t)B, -1), rptr, piv((size_t)h->n_states, 0);
+  std::vector<int64_t> cbase((size_t)B, 0), rbase((size_t)B, 0);
+  std::vector<uint16_t> cand;
+  std::vector<std::vector<int>> plans;
+  for (int b = 0; b < B; ++b) {
+    const int64_t so = h->state_off[b];
+    const int S = (int)(h->state_off[b + 1] - so);
+    cbase[(size_t)b] = (int64_t)cand.size();
+    rbase[(size_t)b] = (int64_t)rptr.size();
+    if (S < 2 || S > 65535) continue;
+    const int NWD = (S + 63) / 64;
+    std::vector<uint64_t> g((size_t)S * NWD, 0);   // adjacency bitsets of the elimination graph
+    auto setbit = [&](int u, int v) { g[(size_t)u * NWD + (v >> 6)] |= 1ull << (v & 63); };
+    for (int s2 = 0; s2 < S; ++s2)
+      for (int a = 0; a < A; ++a) {
+        const int64_t r = (so + s2) * A + a;
+        for (int64_t k = ptr[(size_t)r]; k < ptr[(size_t)r + 1]; ++k)
+          if (val[(size_t)k] > 0.0f && col[(size_t)k] != s2) { setbit(s2, col[(size_t)k]); setbit(col[(size_t)k], s2); }
+      }
+    std::vector<int> degree((size_t)S, 0), order((size_t)S), rk((size_t)S, -1);
+    std::vector<char> alive((size_t)S, 1);
+    for (int u = 0; u < S; ++u)
+      for (int w = 0; w < NWD; ++w) degree[(size_t)u] += __builtin_popcountll(g[(size_t)u * NWD + w]);
+    std::vector<std::vector<int>> cands((size_t)S);
+    bool ok = true;
+    for (int step = 0; step < S; ++step) {
+      int v = -1;
+      for (int u = 0; u < S; ++u)
+        if (alive[(size_t)u] && (v < 0 || degree[(size_t)u] < degree[(size_t)v])) v = u;   // ties: the smallest state
+      order[(size_t)step] = v;
+      rk[(size_t)v] = step;
+      alive[(size_t)v] = 0;
+      std::vector<int>& nb = cands[(size_t)step];
+      for (int w = 0; w < NWD; ++w) {
+        uint64_t x = g[(size_t)v * NWD + w];
+        while (x) { nb.push_back(64 * w + __builtin_ctzll(x)); x &= x - 1; }
+      }
+      if (step < S - 1 && (int)nb.size() > NARROW) { ok = false; break; }
+      for (int u : nb) {   // the neighbours become a clique; v leaves the graph
+        uint64_t* gu = &g[(size_t)u * NWD];
+        const uint64_t* gv = &g[(size_t)v * NWD];
+        int d = 0;
+        for (int w = 0; w < NWD; ++w) { gu[w] |= gv[w]; }
+        gu[u >> 6] &= ~(1ull << (u & 63));
+        gu[v >> 6] &= ~(1ull << (v & 63));
+        for (int w = 0; w < NWD; ++w) d += __builtin_popcountll(gu[w]);
+        degree[(size_t)u] = d;
+      }
+    }
+    if (!ok) continue;
+    // candidate lists as positions, ascending; bitsets of them for the conflict test of the schedule
+    std::vector<uint64_t> cb((size_t)S * NWD, 0);
+    for (int i = 0; i < S; ++i) {
+      std::vector<int>& nb = cands[(size_t)i];
+      for (int& x : nb) x = rk[(size_t)x];
+      std::sort(nb.begin(), nb.end());
+      for (int x : nb) cb[(size_t)i * NWD + (x >> 6)] |= 1ull << (x & 63);
+    }
+    // rounds: pivots whose lower-ranked neighbours are all done, pairwise sharing at most one candidate
+    std::vector<int> pending((size_t)S, 0);
+    for (int i = 0; i < S; ++i)
+      for (int x : cands[(size_t)i]) pending[(size_t)x]++;
+    std::vector<char> done((size_t)S, 0);
+    std::vector<int> ready;
+    for (int i = 0; i < S - 1; ++i)
+      if (!pending[(size_t)i]) ready.push_back(i);
+    int remaining = S - 1, nr = 0;
+    int32_t* pv = piv.data() + so;
+    int filled = 0;
+    while (remaining > 0) {
+      std::sort(ready.begin(), ready.end());
+      std::vector<int> rnd, rest;
+      for (int pidx : ready) {
+        bool fits = (int)rnd.size() < W;
+        for (size_t q = 0; fits && q < rnd.size(); ++q) {
+          int common = 0;
+          for (int w = 0; w < NWD; ++w) common += __builtin_popcountll(cb[(size_t)pidx * NWD + w] & cb[(size_t)rnd[q] * NWD + w]);
+          fits = common <= 1;
+        }
+        if (fits) rnd.push_back(pidx); else rest.push_back(pidx);
+      }
+      if (rnd.empty()) { ok = false; break; }
+      rptr.push_back(filled);
+      for (int pidx : rnd) {
+        pv[filled++] = pidx;
+        --remaining;
+        for (int x : cands[(size_t)pidx])
+          if (--pending[(size_t)x] == 0 && x < S - 1) rest.push_back(x);
+      }
+      ready.swap(rest);
+      ++nr;
+    }
+    if (!ok) { rptr.resize((size_t)rbase[(size_t)b]); continue; }
+    rptr.push_back(filled);
+    nrounds[(size_t)b] = nr;
+    for (int s2 = 0; s2 < S; ++s2) rank[(size_t)(so + s2)] = rk[(size_t)s2];
+    int32_t* cp = cptr.data() + so + b;
+    cp[0] = 0;
+    for (int i = 0; i < S; ++i) {
+      for (int x : cands[(size_t)i]) cand.push_back((uint16_t)x);
+      cp[i + 1] = cp[i] + (int)cands[(size_t)i].size();
+    }
+    h->chain_plan_any = true;
+  }
+  if (!h->chain_plan_any) return CMDP_OK;
+  if (cand.empty()) cand.push_back(0);
+  if (rptr.empty()) rptr.push_back(0);
+  HIP_TRY(h->d_cf_rank.upload(rank.data(), rank.size(), st));
+  HIP_TRY(h->d_cf_cptr.upload(cptr.data(), cptr.size(), st));
+  HIP_TRY(h->d_cf_nrounds.upload(nrounds.data(), nrounds.size(), st));
+  HIP_TRY(h->d_cf_rptr.upload(rptr.data(), rptr.size(), st));
+  HIP_TRY(h->d_cf_piv.upload(piv.data(), piv.size(), st));
+  HIP_TRY(h->d_cf_cbase.upload(cbase.data(), cbase.size(), st));
+  HIP_TRY(h->d_cf_rbase.upload(rbase.data(), rbase.size(), st));
+  HIP_TRY(h->d_cf_cand.upload(cand.data(), cand.size(), st));
+  HIP_TRY(h->d_cf_slow.alloc(B));
+  HIP_TRY(hipStreamSynchronize(st));
+  return CMDP_OK;
+}
+
 // K9 launch shared by cmdp_average_reward / cmdp_qlearning_average_reward: policy either as device one-hot rows
 // (`d_pi`) or device actions (`d_act`); start states on the device.
 // `mask_on_device`: `mask` is already a device pointer (the logged loop keeps its need-mask there)
@@ -2728,6 +2880,23 @@ static int chain_launch(cmdp_t* h, const float* d_pi, const int32_t* d_act, cons
     HIP_TRY(d_dbg.alloc((size_t)B * 8));
     HIP_TRY(d_dbg.zero(st));
     c.dbg = d_dbg.p;
+  }
+  // K9F first (irreducible chains, fill-reducing elimination order, rounds of independent pivots); it flags the instances
+  // it leaves to K9.  The reference's summation order (CMDP_OPT_CHAIN_EXACT_ORDER) keeps K9 alone.
+  static const int fast_env = std::getenv("CMDP_CHAIN_FAST") ? std::atoi(std::getenv("CMDP_CHAIN_FAST")) : 1;
+  if (!h->chain_exact && fast_env) {
+    if (!h->chain_plan_built)
+      if (int rc = build_chain_plan(h)) return rc;
+    const size_t flds = chain_fast_lds_bytes(h->max_S, h->max_row_nnz, 16);
+    if (h->chain_plan_any && flds <= (size_t)kLdsBudget) {
+      ChainFast f{};
+      f.rank = h->d_cf_rank.p; f.cptr = h->d_cf_cptr.p; f.cbase = h->d_cf_cbase.p; f.cand = h->d_cf_cand.p;
+      f.nrounds = h->d_cf_nrounds.p; f.rbase = h->d_cf_rbase.p; f.rptr = h->d_cf_rptr.p; f.piv = h->d_cf_piv.p;
+      f.slow = h->d_cf_slow.p;
+      if (int rc = set_lds(k_chain_fast<16>, flds)) return rc;
+      hipLaunchKernelGGL((k_chain_fast<16>), dim3(B), dim3(1024), flds, st, c, f);
+      c.mask = h->d_cf_slow.p;
+    }
   }
   if (h->chain_exact) hipLaunchKernelGGL((k_chain_average_reward<16, true>), dim3(B), dim3(1024), lds, st, c);
   else hipLaunchKernelGGL((k_chain_average_reward<16, false>), dim3(B), dim3(1024), lds, st, c);

@@ -484,6 +484,280 @@ __global__ void __launch_bounds__(NW * 64) k_chain_average_reward(ChainArgs c) {
 
 
 // ===================================================================================================
+// K9F k_chain_fast: the average reward of IRREDUCIBLE policy chains by GTH elimination in a FILL-REDUCING ORDER, several
+// independent pivots per round (round 3).
+//
+// K9 above spends its time in 783 dependent pivot steps (S = 784: 4.1 us each -- two scans of a dense row / column of the
+// work matrix in L2, three barriers) after a one-lane Tarjan search (1.2 ms), 5.1 ms per log row, and the continuous
+// MiniGrid batches of the benchmark (config C4) are bound by it.  GTH censors one state at a time and ANY order gives the
+// same stationary distribution up to rounding (the SURVEY's tolerance for this row is 1e-6 on the average reward; K9's
+// default already replaces the reference's index-ordered sums by wave butterflies).  The policy's chain is a sub-graph of
+// the MDP's transition graph (union over the actions), which is fixed per instance, so the host computes ONCE per instance
+// (cmdp.hip: build_chain_plan):
+//   * a minimum-degree elimination order of that graph (symmetrised) -- S = 784: 10 332 candidate entries in the filled
+//     graph instead of ~75 000 in state order, at most 59 per pivot;
+//   * per pivot its CANDIDATE list (the higher-ranked neighbours in the filled graph: a superset of the non-zeros of its
+//     row and column under any policy), so a pivot's scan is one gather of <= 64 values instead of a walk over the row;
+//   * a schedule of ROUNDS: up to 16 pivots per round that are pairwise non-adjacent in the filled graph and share at most
+//     one candidate -- their rank-1 updates then touch disjoint off-diagonal entries (the diagonal is never read), so a
+//     round's pivots are scanned, scaled and applied concurrently with no atomics and a result that does not depend on
+//     the interleaving.  S = 784: 197 rounds instead of 783 pivot steps.
+// The kernel first checks that the chain is irreducible (forward and backward reachability from state 0 by frontier
+// relaxation over the adjacency in LDS, all threads; an irreducible chain is ONE recurrent class == the whole chain, the
+// reference's float64 branch) -- otherwise, or without a plan, it flags the instance for K9 (which then runs unchanged).
+// One wavefront per pivot of a round: gather the candidates' row / column values, ballot-compact the non-zeros, butterfly
+// sum = the scale; scale the column and store it packed in the dead part of the pivot's row (as K9 does); one barrier;
+// all threads apply the round's updates; one barrier.  Back-substitution walks the rounds in reverse, one wavefront per
+// pivot.  Not bit-equal to K9 (other elimination order): CMDP_OPT_CHAIN_EXACT_ORDER = 1 keeps K9 alone.
+// ===================================================================================================
+struct ChainFast {
+  const int32_t* rank;      // [NSTATES] elimination position of every state (instance-relative positions)
+  const int32_t* cptr;      // [NSTATES + B] per instance S_b + 1 offsets into its candidate block, at state_off[b] + b
+  const int64_t* cbase;     // [B] start of the instance's candidate block
+  const uint16_t* cand;     // candidate positions (> the pivot's), ascending
+  const int32_t* nrounds;   // [B] rounds of the instance, -1 = no plan
+  const int64_t* rbase;     // [B] start of the instance's round offsets (nrounds + 1 entries)
+  const int32_t* rptr;      // round -> first pivot slot
+  const int32_t* piv;       // [NSTATES] pivots in schedule order, at state_off[b]
+  uint8_t* slow;            // [B] out: 1 = evaluate this instance with K9
+};
+
+__host__ __device__ inline size_t chain_fast_lds_bytes(int S, int max_deg, int nw) {
+  return sizeof(double) * (2 * (size_t)S + 2 * (size_t)nw * 64 + nw) +
+         sizeof(int) * ((size_t)7 * S + 2 + (size_t)S * max_deg + 2 * (size_t)nw * 64 + 2 * nw + 16);
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) k_chain_fast(ChainArgs c, ChainFast f) {
+  extern __shared__ unsigned char chain_smem[];
+  __shared__ int s_f[4];
+  constexpr int NT = NW * 64;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (c.mask && !c.mask[b]) { if (tid == 0) f.slow[b] = 0; return; }
+  const int R = f.nrounds[b];
+  if (R < 0) { if (tid == 0) f.slow[b] = 1; return; }
+  const int64_t soff = c.state_off[b];
+  const int S = (int)(c.state_off[b + 1] - soff);
+  const int A = c.A;
+  const int64_t row0 = soff * A;
+  double* xs = reinterpret_cast<double*>(chain_smem);
+  double* ev = xs + S;
+  double* wrowv = ev + S;                 // [NW][64]
+  double* wcolv = wrowv + NW * 64;        // [NW][64]
+  double* wscale = wcolv + NW * 64;       // [NW]
+  int* act = reinterpret_cast<int*>(wscale + NW);
+  int* adjp = act + S;                    // [S + 1]
+  int* fwd = adjp + S + 1;
+  int* bwd = fwd + S;
+  int* rk = bwd + S;                      // rank of every state
+  int* lcnt = rk + S;                     // entries of every packed column
+  int* deg = lcnt + S;
+  int* wrowk = deg + S;                   // [NW][64]
+  int* wcolj = wrowk + NW * 64;           // [NW][64]
+  int* wcnt = wcolj + NW * 64;            // [NW][2]
+  int* wpre = wcnt + 2 * NW;              // [16] prefix of the round's update counts
+  int* adj = wpre + 16;                   // [<= S * max_deg]
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  if (c.dbg && tid == 0) c.dbg[(int64_t)b * 8 + 0] = (long long)wall_clock64();
+  // ---- A: actions, out-degrees, adjacency (as K9) --------------------------------------------------------------------
+  for (int s = tid; s < S; s += NT) {
+    int a = 0;
+    if (c.act) {
+      a = c.act[soff + s];
+    } else {
+      const float* p = c.pi + row0 + (int64_t)s * A;
+      for (int k = 0; k < A; ++k) a = (p[k] == 1.0f) ? k : a;
+    }
+    act[s] = a;
+    const int64_t r = row0 + (int64_t)s * A + a;
+    int d = 0;
+    for (int64_t k = c.csr_ptr[r]; k < c.csr_ptr[r + 1]; ++k) d += (c.csr_val[k] > 0.0f) ? 1 : 0;
+    deg[s] = d;
+    rk[s] = f.rank[soff + s];
+    fwd[s] = (s == 0) ? 1 : 0;
+    bwd[s] = (s == 0) ? 1 : 0;
+  }
+  __syncthreads();
+  if (wave == 0) {  // exclusive scan of the degrees
+    int carry = 0;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+      const int s = s0 + lane;
+      int v = (s < S) ? deg[s] : 0;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+      }
+      if (s < S) adjp[s + 1] = carry + v;
+      carry += __shfl(v, 63, 64);
+    }
+    if (lane == 0) adjp[0] = 0;
+  }
+  __syncthreads();
+  for (int s = tid; s < S; s += NT) {
+    const int64_t r = row0 + (int64_t)s * A + act[s];
+    int o = adjp[s];
+    for (int64_t k = c.csr_ptr[r]; k < c.csr_ptr[r + 1]; ++k)
+      if (c.csr_val[k] > 0.0f) adj[o++] = c.csr_col[k];
+  }
+  __syncthreads();
+  // ---- R: irreducible?  every state reachable from state 0 and state 0 reachable from every state -----------------------
+  for (;;) {
+    if (tid == 0) s_f[0] = 0;
+    __syncthreads();
+    bool ch = false;
+    for (int s = tid; s < S; s += NT) {
+      const bool fs = fwd[s] != 0;
+      bool bs = bwd[s] != 0;
+      for (int e = adjp[s]; e < adjp[s + 1]; ++e) {
+        const int w = adj[e];
+        if (fs && !fwd[w]) { fwd[w] = 1; ch = true; }
+        if (!bs && bwd[w]) { bs = true; bwd[s] = 1; ch = true; }
+      }
+    }
+    if (ch) s_f[0] = 1;
+    __syncthreads();
+    const int again = s_f[0];
+    __syncthreads();
+    if (!again) break;
+  }
+  if (tid == 0) s_f[1] = 1;
+  __syncthreads();
+  for (int s = tid; s < S; s += NT)
+    if (!fwd[s] || !bwd[s]) s_f[1] = 0;
+  __syncthreads();
+  if (!s_f[1]) { if (tid == 0) f.slow[b] = 1; return; }   // several classes or transient states: K9's job
+  if (c.dbg && tid == 0) c.dbg[(int64_t)b * 8 + 1] = c.dbg[(int64_t)b * 8 + 2] = c.dbg[(int64_t)b * 8 + 3] = (long long)wall_clock64();
+  // ---- D: the chain as a dense matrix in ELIMINATION positions ------------------------------------------------------
+  const int m = S;
+  double* a = c.work + c.work_off[b];
+  int32_t* aj = c.work_idx + c.work_off[b];
+  for (int64_t e = tid; e < (int64_t)m * m; e += NT) a[e] = 0.0;
+  __syncthreads();
+  for (int s = tid; s < S; s += NT) {
+    const int64_t r = row0 + (int64_t)s * A + act[s];
+    const int64_t base = (int64_t)rk[s] * m;
+    for (int64_t k = c.csr_ptr[r]; k < c.csr_ptr[r + 1]; ++k) {
+      const float v = c.csr_val[k];
+      if (v > 0.0f) a[base + rk[c.csr_col[k]]] = (double)fminf(1.0f, v);
+    }
+  }
+  if (tid == 0) s_f[2] = 0;
+  __syncthreads();
+  if (c.dbg && tid == 0) c.dbg[(int64_t)b * 8 + 4] = (long long)wall_clock64();
+  // ---- E: GTH elimination, a round of independent pivots at a time ------------------------------------------------------
+  const int32_t* cptr = f.cptr + soff + b;
+  const uint16_t* cand = f.cand + f.cbase[b];
+  const int32_t* rptr = f.rptr + f.rbase[b];
+  const int32_t* piv = f.piv + soff;
+  double* myrowv = wrowv + wave * 64;
+  double* mycolv = wcolv + wave * 64;
+  int* myrowk = wrowk + wave * 64;
+  int* mycolj = wcolj + wave * 64;
+  for (int r = 0; r < R; ++r) {
+    const int p0 = rptr[r], np = rptr[r + 1] - p0;
+    if (wave < np) {
+      const int i = piv[p0 + wave];
+      const int c0 = cptr[i], cnt = cptr[i + 1] - c0;
+      const int k = (lane < cnt) ? (int)cand[c0 + lane] : 0;
+      const double rv = (lane < cnt) ? a[(int64_t)i * m + k] : 0.0;
+      const double cv = (lane < cnt) ? a[(int64_t)k * m + i] : 0.0;
+      const unsigned long long bmr = __ballot(rv != 0.0), bmc = __ballot(cv != 0.0);
+      if (rv != 0.0) {
+        const int q = __popcll(bmr & lt);
+        myrowk[q] = k;
+        myrowv[q] = rv;
+      }
+      if (cv != 0.0) {
+        const int q = __popcll(bmc & lt);
+        mycolj[q] = k;
+        mycolv[q] = cv;
+      }
+      const double sc = lanes_add<false>(0.0, rv, bmr);
+      const int nrow = __popcll(bmr), ncol = __popcll(bmc);
+      __builtin_amdgcn_wave_barrier();
+      if (sc <= 0.0) {
+        if (lane == 0) s_f[2] = 1;   // cannot happen on an irreducible chain; K9 takes the instance
+      } else if (lane < ncol) {
+        // a[j, i] /= scale; the scaled column is what back-substitution needs: stored packed (value, position) in the
+        // part of row i right of the diagonal, dead from here on
+        const double l = mycolv[lane] / sc;
+        mycolv[lane] = l;
+        a[(int64_t)i * m + i + 1 + lane] = l;
+        aj[(int64_t)i * m + i + 1 + lane] = mycolj[lane];
+      }
+      if (lane == 0) {
+        lcnt[i] = ncol;
+        wcnt[2 * wave] = nrow;
+        wcnt[2 * wave + 1] = ncol;
+      }
+    }
+    __syncthreads();
+    if (s_f[2]) break;
+    if (tid == 0) {
+      int acc = 0;
+      for (int w = 0; w < np; ++w) { wpre[w] = acc; acc += wcnt[2 * w] * wcnt[2 * w + 1]; }
+      wpre[np] = acc;
+    }
+    __syncthreads();
+    const int total = wpre[np];
+    for (int e = tid; e < total; e += NT) {
+      int w = 0;
+      while (w + 1 < np && wpre[w + 1] <= e) ++w;
+      const int le = e - wpre[w], nrow = wcnt[2 * w];
+      const int pj = le / nrow, pk = le - pj * nrow;
+      const int64_t at = (int64_t)wcolj[w * 64 + pj] * m + wrowk[w * 64 + pk];
+      a[at] = __dadd_rn(a[at], __dmul_rn(wcolv[w * 64 + pj], wrowv[w * 64 + pk]));
+    }
+    __syncthreads();
+  }
+  if (s_f[2]) { if (tid == 0) f.slow[b] = 1; return; }
+  if (c.dbg && tid == 0) c.dbg[(int64_t)b * 8 + 5] = (long long)wall_clock64();
+  // ---- F: back-substitution, the rounds in reverse ---------------------------------------------------------------------
+  for (int i = tid; i < m; i += NT) xs[i] = 0.0;
+  __syncthreads();
+  if (tid == 0) xs[m - 1] = 1.0;   // the one position that is never eliminated
+  __syncthreads();
+  for (int r = R - 1; r >= 0; --r) {
+    const int p0 = rptr[r], np = rptr[r + 1] - p0;
+    if (wave < np) {
+      const int i = piv[p0 + wave];
+      const int cnt = lcnt[i];
+      const int64_t base = (int64_t)i * m + i + 1;
+      const double l = (lane < cnt) ? a[base + lane] : 0.0;
+      const int j = (lane < cnt) ? aj[base + lane] : 0;
+      const double pr = (lane < cnt) ? __dmul_rn(xs[j], l) : 0.0;
+      const double acc = lanes_add<false>(0.0, pr, ~0ull);
+      if (lane == 0) xs[i] = acc;
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    double tot = 0.0;
+    for (int i0 = 0; i0 < m; i0 += 64) {
+      const int i = i0 + lane;
+      const double v = (i < m) ? xs[i] : 0.0;
+      tot = lanes_add<false>(tot, v, ~0ull);
+    }
+    if (lane == 0) wscale[0] = tot;
+  }
+  __syncthreads();
+  const double tot = wscale[0];
+  if (c.dbg && tid == 0) c.dbg[(int64_t)b * 8 + 6] = (long long)wall_clock64();
+  for (int s = tid; s < S; s += NT) {
+    const float ar = c.R[row0 + (int64_t)s * A + act[s]];
+    ev[s] = __dmul_rn((double)ar, xs[rk[s]] / tot);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    c.avg[b] = __dadd_rn(0.0, np_pairwise<double, 12>(ev, S));
+    c.kind[b] = CHAIN_F64;   // one recurrent class == the whole chain: the reference's float64 branch
+    if (c.n_classes) c.n_classes[b] = 1;
+    f.slow[b] = 0;
+    if (c.dbg) { c.dbg[(int64_t)b * 8 + 7] = (long long)wall_clock64(); }
+  }
+}
+
+// ===================================================================================================
 // K10: mixing time of the chain of a stationary policy (BUILD-DEFINED: the reference has no mixing time; SURVEY
 // section 8 f2 defines it as the smallest t with max_s TV(P^t(s, .), pi) <= threshold, threshold 1/4).
 // X_t[s, :] = distribution after t steps from state s (X_0 = I), float64, one workgroup per (instance, start state):

@@ -207,7 +207,9 @@ enum { CMDP_STAT_DP_KERNEL_MS = 1, CMDP_STAT_DP_KERNEL = 2,
        CMDP_STAT_REWARD_FILLS = 3,   /* CMDP_FLAG_REWARD_CACHE: blocks of 5000 samples drawn so far                */
        CMDP_STAT_REWARD_ROUNDS = 4,  /* ... and park / fill / relaunch rounds                                        */
        CMDP_STAT_ROLLOUT_KERNEL_MS = 5, /* K1U: HIP-event time of k_rollout_tmpl_stream in the last launch (last segment) */
-       CMDP_STAT_HIST_KERNEL_MS = 6     /* K1U: ... and of its k_trace_hist (on the second stream when overlapped)          */ };
+       CMDP_STAT_HIST_KERNEL_MS = 6,    /* K1U: ... and of its k_trace_hist (on the second stream when overlapped)          */
+       CMDP_STAT_CHAIN_FAST_INSTANCES = 7 /* instances (evaluated or masked out) the last average-reward call did NOT hand to K9:
+                                             those K9F solved (irreducible chain, fill-reducing elimination order)          */ };
 int cmdp_stat(cmdp_t* h, int which, double* out);
 /* Latency floor of the LDS-resident rollout kernels, measured on the current device: one wavefront per CU follows
    per-lane uint16 tables in LDS for n_steps dependent reads.  CMDP_CALIB_LDS_READ: the bare dependent ds_read_u16
@@ -244,9 +246,12 @@ int cmdp_calibrate(int what, int64_t n_steps, double* ns_per_step);
    sweep (taken by default for 257..448 states, <= 5 distinct successors per state, <= 4 non-zeros per row; 5 keeps K2U).
    All forms return identical bits.
    CMDP_OPT_CHAIN_EXACT_ORDER (cmdp_average_reward / cmdp_qlearning_average_reward): 1 = every float64 sum of the GTH
-   elimination in the reference's index order (bit-equal to cmdp_gth and the oracle, one serial chain per sum);
-   0 (default) = wave butterfly sums, deterministic, within ~1e-15 relative of the former, several times faster on
-   chains with hundreds of states.
+   elimination in the reference's index order and the states eliminated in the reference's order (bit-equal to cmdp_gth
+   and the oracle, one serial chain per sum);
+   0 (default) = wave butterfly sums and -- for irreducible chains -- a fill-reducing elimination order computed once per
+   instance from the MDP's transition graph, several independent pivots per step (kernel K9F): deterministic, within
+   ~1e-13 relative of the former (GTH is subtraction-free: any elimination order gives the stationary distribution to
+   rounding), 5-8 x faster on chains with hundreds of states.
    CMDP_OPT_DIAMETER_WORKSPACE_MB: HBM the value arrays of K5S may take per launch (default 24576; 512 bytes per
    state per group of 64 targets; more groups in flight = more of the GPU busy).
    CMDP_OPT_DIAMETER_RELABEL_MIN_STATES: K5S stores the rows of instances with at least this many states (default 8192)

@@ -68,6 +68,45 @@ def test_average_reward_kernel_matches_host_restatement(need_gpu, cls, kw):
         assert multi >= 4
 
 
+def test_fast_chain_kernel_on_irreducible_chains(need_gpu):
+    """K9F (fill-reducing elimination order, rounds of independent pivots) on the chains it exists for -- the benchmark's
+    continuous MiniGrid settings under greedy-like policies, where p_rand makes every policy's chain irreducible --
+    against K9 in the reference's order (itself bit-equal to the host restatement, test above): same numpy type (float64:
+    one class == the whole chain), same class count, values within 1e-11 relative (the SURVEY's tolerance for this row is
+    1e-6; GTH is subtraction-free, so another elimination order moves the result by a few ulp only).  The statistic says
+    the fast kernel really took them; a reducible chain in the same batch goes to K9."""
+    import ctypes as C
+    import json
+
+    from conftest import GOLDEN
+
+    cfg = json.load(open(os.path.join(GOLDEN, "G11_benchmark_configs.json")))["benchmark_continuous_ergodic"]["mdp_configs"]
+    for cls, scope in (("MiniGridEmptyContinuous", "prms_3"), ("MiniGridEmptyContinuous", "prms_0"), ("MiniGridRoomsContinuous", "prms_0"),
+                       ("FrozenLakeContinuous", "prms_0"), ("DeepSeaContinuous", "prms_0")):
+        ms = [make_model(cls, seed=s, **cfg[cls][scope]) for s in range(3)]
+        S, A = ms[0].n_states, ms[0].n_actions
+        rng = np.random.default_rng(S)
+        acts = [rng.integers(0, A, m.n_states).astype(np.int32) for m in ms]
+        acts += [np.full(m.n_states, k % A, np.int32) for k, m in enumerate(ms)]
+        starts = [int(rng.integers(0, m.n_states)) for m in ms] * 2
+        env = BatchedMDP(ms + ms, rng_mode=L.RNG_PHILOX, with_env=False)
+        fast, ncls_fast = env.average_reward(acts, starts)
+        n_fast = C.c_double()
+        L.check(L.load().cmdp_stat(env.handle, L.STAT_CHAIN_FAST_INSTANCES, C.byref(n_fast)))
+        env.set_option(L.OPT_CHAIN_EXACT_ORDER, 1)
+        vals, ncls = env.average_reward(acts, starts)
+        np.testing.assert_array_equal(ncls_fast, ncls)
+        assert int(n_fast.value) == int((ncls == 1).sum()) >= 3, (cls, scope, n_fast.value, ncls)
+        for x, y in zip(fast, vals):
+            assert type(x) is type(y) and x == pytest.approx(y, rel=1e-11, abs=1e-15), (cls, scope, x, y)
+        # masked calls leave the others alone
+        mask = np.array([1, 0, 1, 0, 1, 0], bool)
+        env.set_option(L.OPT_CHAIN_EXACT_ORDER, 0)
+        part, _ = env.average_reward(acts, starts, mask=mask)
+        assert [part[i] for i in (0, 2, 4)] == [fast[i] for i in (0, 2, 4)]
+        env.close()
+
+
 def test_mixing_time_against_dense_float64_powers(need_gpu):
     """Build-defined measure (no reference counterpart): both device paths -- one sparse step at a time with the row in
     LDS, and matrix powers with the binary search on t (what config C5 runs) -- must give the t and the total variation
