@@ -2706,7 +2706,7 @@ static int build_chain_plan(cmdp_t* h) {
   HIP_TRY(hipMemcpyAsync(col.data(), h->d_csr_col.p, sizeof(int32_t) * col.size(), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(val.data(), h->d_csr_val.p, sizeof(float) * val.size(), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  constexpr int W = 16, NARROW = 64;
+  constexpr int W = 16, NARROW = K9F_MAXC;
   std::vector<int32_t> rank((size_t)h->n_states, -1), cptr((size_t)h->n_states + B, 0), nrounds((size_t)B, -1), rptr, piv((size_t)h->n_states, 0);
   std::vector<int64_t> cbase((size_t)B, 0), rbase((size_t)B, 0);
   std::vector<uint16_t> cand;

@@ -522,9 +522,11 @@ struct ChainFast {
   uint8_t* slow;            // [B] out: 1 = evaluate this instance with K9
 };
 
+#define K9F_KC 2                      // candidate chunks of 64 a pivot's wavefront handles
+#define K9F_MAXC (64 * K9F_KC)        // candidates per pivot the plan may hold (more: the instance keeps K9)
 __host__ __device__ inline size_t chain_fast_lds_bytes(int S, int max_deg, int nw) {
-  return sizeof(double) * (2 * (size_t)S + 2 * (size_t)nw * 64 + nw) +
-         sizeof(int) * ((size_t)7 * S + 2 + (size_t)S * max_deg + 2 * (size_t)nw * 64 + 2 * nw + 16);
+  return sizeof(double) * (2 * (size_t)S + 2 * (size_t)nw * K9F_MAXC + nw) +
+         sizeof(int) * ((size_t)7 * S + 2 + (size_t)S * max_deg + 2 * (size_t)nw * K9F_MAXC + 2 * nw + 16);
 }
 
 template <int NW>
@@ -542,9 +544,10 @@ __global__ void __launch_bounds__(NW * 64) k_chain_fast(ChainArgs c, ChainFast f
   const int64_t row0 = soff * A;
   double* xs = reinterpret_cast<double*>(chain_smem);
   double* ev = xs + S;
-  double* wrowv = ev + S;                 // [NW][64]
-  double* wcolv = wrowv + NW * 64;        // [NW][64]
-  double* wscale = wcolv + NW * 64;       // [NW]
+  constexpr int MC = K9F_MAXC;
+  double* wrowv = ev + S;                 // [NW][MC]
+  double* wcolv = wrowv + NW * MC;        // [NW][MC]
+  double* wscale = wcolv + NW * MC;       // [NW]
   int* act = reinterpret_cast<int*>(wscale + NW);
   int* adjp = act + S;                    // [S + 1]
   int* fwd = adjp + S + 1;
@@ -552,9 +555,9 @@ __global__ void __launch_bounds__(NW * 64) k_chain_fast(ChainArgs c, ChainFast f
   int* rk = bwd + S;                      // rank of every state
   int* lcnt = rk + S;                     // entries of every packed column
   int* deg = lcnt + S;
-  int* wrowk = deg + S;                   // [NW][64]
-  int* wcolj = wrowk + NW * 64;           // [NW][64]
-  int* wcnt = wcolj + NW * 64;            // [NW][2]
+  int* wrowk = deg + S;                   // [NW][MC]
+  int* wcolj = wrowk + NW * MC;           // [NW][MC]
+  int* wcnt = wcolj + NW * MC;            // [NW][2]
   int* wpre = wcnt + 2 * NW;              // [16] prefix of the round's update counts
   int* adj = wpre + 16;                   // [<= S * max_deg]
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -649,41 +652,57 @@ __global__ void __launch_bounds__(NW * 64) k_chain_fast(ChainArgs c, ChainFast f
   const uint16_t* cand = f.cand + f.cbase[b];
   const int32_t* rptr = f.rptr + f.rbase[b];
   const int32_t* piv = f.piv + soff;
-  double* myrowv = wrowv + wave * 64;
-  double* mycolv = wcolv + wave * 64;
-  int* myrowk = wrowk + wave * 64;
-  int* mycolj = wcolj + wave * 64;
+  double* myrowv = wrowv + wave * MC;
+  double* mycolv = wcolv + wave * MC;
+  int* myrowk = wrowk + wave * MC;
+  int* mycolj = wcolj + wave * MC;
   for (int r = 0; r < R; ++r) {
     const int p0 = rptr[r], np = rptr[r + 1] - p0;
     if (wave < np) {
       const int i = piv[p0 + wave];
       const int c0 = cptr[i], cnt = cptr[i + 1] - c0;
-      const int k = (lane < cnt) ? (int)cand[c0 + lane] : 0;
-      const double rv = (lane < cnt) ? a[(int64_t)i * m + k] : 0.0;
-      const double cv = (lane < cnt) ? a[(int64_t)k * m + i] : 0.0;
-      const unsigned long long bmr = __ballot(rv != 0.0), bmc = __ballot(cv != 0.0);
-      if (rv != 0.0) {
-        const int q = __popcll(bmr & lt);
-        myrowk[q] = k;
-        myrowv[q] = rv;
+      // the candidates' row and column values (all gathers in flight together), non-zeros compacted in candidate order
+      int kk[K9F_KC];
+      double rv[K9F_KC], cv[K9F_KC];
+#pragma unroll
+      for (int u = 0; u < K9F_KC; ++u) {
+        const int l = 64 * u + lane;
+        kk[u] = (l < cnt) ? (int)cand[c0 + l] : 0;
+        rv[u] = (l < cnt) ? a[(int64_t)i * m + kk[u]] : 0.0;
+        cv[u] = (l < cnt) ? a[(int64_t)kk[u] * m + i] : 0.0;
       }
-      if (cv != 0.0) {
-        const int q = __popcll(bmc & lt);
-        mycolj[q] = k;
-        mycolv[q] = cv;
+      int nrow = 0, ncol = 0;
+      double sc = 0.0;
+#pragma unroll
+      for (int u = 0; u < K9F_KC; ++u) {
+        if (64 * u >= cnt) break;
+        const unsigned long long bmr = __ballot(rv[u] != 0.0), bmc = __ballot(cv[u] != 0.0);
+        if (rv[u] != 0.0) {
+          const int q = nrow + __popcll(bmr & lt);
+          myrowk[q] = kk[u];
+          myrowv[q] = rv[u];
+        }
+        if (cv[u] != 0.0) {
+          const int q = ncol + __popcll(bmc & lt);
+          mycolj[q] = kk[u];
+          mycolv[q] = cv[u];
+        }
+        sc = lanes_add<false>(sc, rv[u], bmr);
+        nrow += __popcll(bmr);
+        ncol += __popcll(bmc);
       }
-      const double sc = lanes_add<false>(0.0, rv, bmr);
-      const int nrow = __popcll(bmr), ncol = __popcll(bmc);
       __builtin_amdgcn_wave_barrier();
       if (sc <= 0.0) {
         if (lane == 0) s_f[2] = 1;   // cannot happen on an irreducible chain; K9 takes the instance
-      } else if (lane < ncol) {
+      } else {
         // a[j, i] /= scale; the scaled column is what back-substitution needs: stored packed (value, position) in the
         // part of row i right of the diagonal, dead from here on
-        const double l = mycolv[lane] / sc;
-        mycolv[lane] = l;
-        a[(int64_t)i * m + i + 1 + lane] = l;
-        aj[(int64_t)i * m + i + 1 + lane] = mycolj[lane];
+        for (int l = lane; l < ncol; l += 64) {
+          const double lv = mycolv[l] / sc;
+          mycolv[l] = lv;
+          a[(int64_t)i * m + i + 1 + l] = lv;
+          aj[(int64_t)i * m + i + 1 + l] = mycolj[l];
+        }
       }
       if (lane == 0) {
         lcnt[i] = ncol;
@@ -705,8 +724,8 @@ __global__ void __launch_bounds__(NW * 64) k_chain_fast(ChainArgs c, ChainFast f
       while (w + 1 < np && wpre[w + 1] <= e) ++w;
       const int le = e - wpre[w], nrow = wcnt[2 * w];
       const int pj = le / nrow, pk = le - pj * nrow;
-      const int64_t at = (int64_t)wcolj[w * 64 + pj] * m + wrowk[w * 64 + pk];
-      a[at] = __dadd_rn(a[at], __dmul_rn(wcolv[w * 64 + pj], wrowv[w * 64 + pk]));
+      const int64_t at = (int64_t)wcolj[w * MC + pj] * m + wrowk[w * MC + pk];
+      a[at] = __dadd_rn(a[at], __dmul_rn(wcolv[w * MC + pj], wrowv[w * MC + pk]));
     }
     __syncthreads();
   }
@@ -723,10 +742,16 @@ __global__ void __launch_bounds__(NW * 64) k_chain_fast(ChainArgs c, ChainFast f
       const int i = piv[p0 + wave];
       const int cnt = lcnt[i];
       const int64_t base = (int64_t)i * m + i + 1;
-      const double l = (lane < cnt) ? a[base + lane] : 0.0;
-      const int j = (lane < cnt) ? aj[base + lane] : 0;
-      const double pr = (lane < cnt) ? __dmul_rn(xs[j], l) : 0.0;
-      const double acc = lanes_add<false>(0.0, pr, ~0ull);
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < K9F_KC; ++u) {
+        if (64 * u >= cnt) break;
+        const int l = 64 * u + lane;
+        const double lv = (l < cnt) ? a[base + l] : 0.0;
+        const int j = (l < cnt) ? aj[base + l] : 0;
+        const double pr = (l < cnt) ? __dmul_rn(xs[j], lv) : 0.0;
+        acc = lanes_add<false>(acc, pr, ~0ull);
+      }
       if (lane == 0) xs[i] = acc;
     }
     __syncthreads();
