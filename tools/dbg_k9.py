@@ -24,3 +24,11 @@ rows = bm._run_group(models, list(range(n)), "QLearningContinuous", bm.DEFAULT_A
                      L.RNG_MT_COMPAT, 0, beta_rewards="philox")
 dt = time.time() - t0
 print(f"{cls} {scope}: {n} instances, S={models[0].n_states}, {steps} steps, {len(rows[0])} rows in {dt:.2f} s = {dt / len(rows[0]) * 1e3:.2f} ms per row")
+# a second, longer run on fresh copies: (t2 - t1) / extra rows = the steady-state cost of a log row
+if len(sys.argv) > 6:
+    steps2 = int(sys.argv[6])
+    t0 = time.time()
+    rows2 = bm._run_group(models, list(range(n)), "QLearningContinuous", bm.DEFAULT_AGENT_CONFIGS["QLearningContinuous"], steps2, 100,
+                          L.RNG_MT_COMPAT, 0, beta_rewards="philox")
+    dt2 = time.time() - t0
+    print(f"steady state: {(dt2 - dt) / (len(rows2[0]) - len(rows[0])) * 1e3:.3f} ms per row ({steps2} steps in {dt2:.2f} s)")
