@@ -90,7 +90,7 @@ def test_c4_at_its_real_length(need_gpu, tmp_path):
     args = ["tools/run_benchmark.py", "--configs-json", os.path.join(GOLDEN, "G11_benchmark_configs.json"),
             "--benchmark", "benchmark_episodic_ergodic", "--benchmark", "benchmark_episodic_communicating",
             "--benchmark", "benchmark_continuous_ergodic", "--benchmark", "benchmark_continuous_communicating",
-            "--out", str(tmp_path / "c4"), "--concurrent-groups", "12", "--beta-rewards", "philox"]
+            "--out", str(tmp_path / "c4"), "--beta-rewards", "philox"]
     s = json.loads(_run([sys.executable] + args, timeout=500).strip().splitlines()[-1])
     assert s["instances"] == s["run"] == 1000 and s["steps_each"] == 500000 and s["skipped_existing"] == 0
     assert s["mean_normalized_cumulative_regret"] == pytest.approx(380972.0156768999, rel=1e-12)

@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--steps", type=int)
     ap.add_argument("--seeds", type=int)
     ap.add_argument("--log-every", type=int)
-    ap.add_argument("--concurrent-groups", type=int, default=12, help="device batches driven concurrently (host threads, one stream each)")
+    ap.add_argument("--concurrent-groups", type=int, default=16, help="device batches driven concurrently (host threads, one stream each)")
     ap.add_argument("--max-batch", type=int, default=128, help="instances per device batch (larger groups are split)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0")
@@ -71,6 +71,7 @@ def main():
     # generous timeout, so that no rank waits in rendezvous while another is still running its shard, and a rank that
     # dies mid-run is noticed at the gather -- (3) only then the first HIP call of this process
     models = bm.build_shard_models(instances, rank, world, workers=max(1, min(16, (os.cpu_count() or 1) // world)), skip=skip)
+    print(f"[rank {rank}] {len(models)} models built in {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
     if world > 1:
         import datetime
 

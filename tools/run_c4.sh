@@ -8,7 +8,7 @@ MODE=${1:-reference}; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
 mkdir -p $OUT
-for CG in "${@:-12}"; do
+for CG in "${@:-16}"; do
   rm -rf /tmp/c4_$CG
   python3 $R/tools/run_benchmark.py --configs-json $R/tests/golden/G11_benchmark_configs.json \
     --benchmark benchmark_episodic_ergodic --benchmark benchmark_episodic_communicating \
