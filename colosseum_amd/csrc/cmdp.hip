@@ -2830,6 +2830,8 @@ static int build_chain_plan(cmdp_t* h) {
 // K9 launch shared by cmdp_average_reward / cmdp_qlearning_average_reward: policy either as device one-hot rows
 // (`d_pi`) or device actions (`d_act`); start states on the device.
 // `mask_on_device`: `mask` is already a device pointer (the logged loop keeps its need-mask there)
+// `copy_back` false: `avg` / `kind` (when given) are DEVICE-ACCESSIBLE buffers (page-locked host memory in the logged loop) the
+// kernels write directly -- no copy kernel per row; nothing is synchronised.
 static int chain_launch(cmdp_t* h, const float* d_pi, const int32_t* d_act, const int32_t* d_start, const uint8_t* mask,
                         double* avg, int32_t* kind, int32_t* n_classes, bool mask_on_device = false, bool copy_back = true) {
   if (!h->has_dp) return fail(CMDP_ERR_INVALID, "the handle was created without the DP half (CSR transition matrices)");
@@ -2865,7 +2867,9 @@ static int chain_launch(cmdp_t* h, const float* d_pi, const int32_t* d_act, cons
   c.B = B; c.A = h->A; c.max_deg = h->max_row_nnz;
   c.state_off = h->d_state_off.p; c.csr_ptr = h->d_csr_ptr.p; c.csr_col = h->d_csr_col.p; c.csr_val = h->d_csr_val.p;
   c.R = h->d_R.p; c.pi = d_pi; c.act = d_act; c.start = d_start; c.mask = dmask;
-  c.work_off = h->d_ch_off.p; c.work = h->d_ch_work.p; c.work_idx = h->d_ch_idx.p; c.avg = h->d_ch_avg.p; c.kind = h->d_ch_kind.p;
+  c.work_off = h->d_ch_off.p; c.work = h->d_ch_work.p; c.work_idx = h->d_ch_idx.p;
+  c.avg = (!copy_back && avg) ? avg : h->d_ch_avg.p;
+  c.kind = (!copy_back && kind) ? kind : h->d_ch_kind.p;
   c.n_classes = h->d_ch_ncls.p;
   if (lds > 64 * 1024)
   {
@@ -3262,12 +3266,12 @@ int cmdp_qlearning_destroy(cmdp_agent_t* a) {
 }
 
 // the interaction kernel of `n_steps` steps on the handle's stream (no synchronisation, no copies)
-static int ql_launch(cmdp_agent_t* a, int64_t n_steps, const uint8_t* dmask, int8_t* d_actions, int resume) {
+static int ql_launch(cmdp_agent_t* a, int64_t n_steps, const uint8_t* dmask, int8_t* d_actions, int resume, double* cum_host) {
   cmdp_t* h = a->env;
   hipStream_t st = h->stream;
   const dim3 grid(grid_for(h->B, 256)), block(256);
   const RewardCache rc = h->rcache();
-#define QL_LAUNCH(K, ARGS) hipLaunchKernelGGL(K, grid, block, 0, st, h->env(), ARGS, n_steps, dmask, d_actions, a->d_rsum.p, rc, resume)
+#define QL_LAUNCH(K, ARGS) hipLaunchKernelGGL(K, grid, block, 0, st, h->env(), ARGS, n_steps, dmask, d_actions, a->d_rsum.p, rc, resume, cum_host)
   if (h->reward_cache) {
     if (a->continuous) QL_LAUNCH(k_qlearn_continuous<true>, a->cargs);
     else if (a->args.ucb == 0) QL_LAUNCH((k_qlearn_episodic<0, true>), a->args);
@@ -3283,9 +3287,11 @@ static int ql_launch(cmdp_agent_t* a, int64_t n_steps, const uint8_t* dmask, int
 }
 // With reference-exact reward caches the call returns with the stream idle (instances park, the host fills their blocks,
 // the kernel is relaunched); otherwise nothing is synchronised.
-static int ql_enqueue_run(cmdp_agent_t* a, int64_t n_steps, const uint8_t* dmask, int8_t* d_actions) {
-  if (a->env->reward_cache) return rc_drive(a->env, [&](int resume) -> int { return ql_launch(a, n_steps, dmask, d_actions, resume); });
-  return ql_launch(a, n_steps, dmask, d_actions, 0);
+// `cum_host` (nullable): page-locked host array that receives the running reward sums at the end of the launch.
+static int ql_enqueue_run(cmdp_agent_t* a, int64_t n_steps, const uint8_t* dmask, int8_t* d_actions, double* cum_host = nullptr) {
+  if (a->env->reward_cache)
+    return rc_drive(a->env, [&](int resume) -> int { return ql_launch(a, n_steps, dmask, d_actions, resume, cum_host); });
+  return ql_launch(a, n_steps, dmask, d_actions, 0, cum_host);
 }
 
 int cmdp_qlearning_run(cmdp_agent_t* a, int64_t n_steps, const uint8_t* train_mask, int8_t* actions_trace,
@@ -3313,7 +3319,7 @@ int cmdp_qlearning_run(cmdp_agent_t* a, int64_t n_steps, const uint8_t* train_ma
 }
 
 // greedy policy of the agents' Q tables -> episodic policy evaluation -> V[0, :] packed into a->d_v0 (no synchronisation)
-static int ql_enqueue_evaluate(cmdp_agent_t* a) {
+static int ql_enqueue_evaluate(cmdp_agent_t* a, float* v0_out = nullptr, int32_t* snap = nullptr) {
   cmdp_t* h = a->env;
   if (a->continuous) return fail(CMDP_ERR_INVALID, "cmdp_qlearning_evaluate is for the episodic agent; use cmdp_qlearning_policy");
   if (!h->has_dp) return fail(CMDP_ERR_INVALID, "the environment handle was created without the DP half");
@@ -3336,7 +3342,8 @@ static int ql_enqueue_evaluate(cmdp_agent_t* a) {
   HIP_TRY(hipGetLastError());
   // V[0, :] of instance b sits at (H+1)*state_off[b]: pack
   if (a->d_v0.n < (size_t)h->n_states) HIP_TRY(a->d_v0.alloc(h->n_states));
-  hipLaunchKernelGGL(k_gather_v0, dim3(h->B), dim3(256), 0, st, h->B, H, h->d_state_off.p, h->d_V.p, a->d_v0.p);
+  hipLaunchKernelGGL(k_gather_v0, dim3(h->B), dim3(256), 0, st, h->B, H, h->d_state_off.p, h->d_V.p, v0_out ? v0_out : a->d_v0.p,
+                     h->d_last_start.p, h->d_prev_start.p, h->d_h.p, snap);
   HIP_TRY(hipGetLastError());
   return CMDP_OK;
 }
@@ -3386,14 +3393,12 @@ int cmdp_qlearning_run_logged(cmdp_agent_t* a, const cmdp_loop_desc* d, int64_t 
   EpisodicInputs ein{h->H, d->opt0, d->worst0, d->start_pos, d->start_prob, d->kmax};
   PinnedBuf<double> cum, avg;
   PinnedBuf<float> v0;
-  PinnedBuf<int32_t> last, prev, hstep, akind;
+  PinnedBuf<int32_t> snap, akind;
   PinnedBuf<uint8_t> mask, need;
   if (int rc = cum.alloc(B)) return rc;
   if (int rc = avg.alloc(B)) return rc;
   if (int rc = v0.alloc((size_t)NS)) return rc;
-  if (int rc = last.alloc(B)) return rc;
-  if (int rc = prev.alloc(B)) return rc;
-  if (int rc = hstep.alloc(B)) return rc;
+  if (int rc = snap.alloc((size_t)3 * B)) return rc;
   if (int rc = akind.alloc(B)) return rc;
   if (int rc = mask.alloc(B)) return rc;
   if (int rc = need.alloc(B)) return rc;
@@ -3410,26 +3415,22 @@ int cmdp_qlearning_run_logged(cmdp_agent_t* a, const cmdp_loop_desc* d, int64_t 
 
   auto log_row = [&](int64_t i, int64_t t, int64_t n_since, bool in_loop) -> int {
     // evaluation of the agents' current greedy policies, then one synchronisation for everything this row reads
+    // Everything a row reads comes back WITHOUT copy kernels: the kernels write into page-locked host memory directly
+    // (V[0, :], the start states and in-episode times, the average rewards and their kinds, the reward sums), and read the
+    // evaluation mask from it -- a C4 run issued 580 000 copies of a few hundred bytes, 32 us each under load.
     if (episodic) {
-      if (int rc = ql_enqueue_evaluate(a)) return rc;
-      HIP_TRY(hipMemcpyAsync(v0.p, a->d_v0.p, sizeof(float) * (size_t)NS, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(last.p, h->d_last_start.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(prev.p, h->d_prev_start.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(hstep.p, h->d_h.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+      if (int rc = ql_enqueue_evaluate(a, v0.p, snap.p)) return rc;
     } else {
       continuous_need(tr, need.p);
       bool any = false;
       for (int b = 0; b < B; ++b) any = any || need.p[b];
       if (any) {
-        HIP_TRY(hipMemcpyAsync(h->d_ch_mask.p, need.p, B, hipMemcpyHostToDevice, st));
         if (a->d_pi.n < (size_t)a->n_q) HIP_TRY(a->d_pi.alloc(a->n_q));
         hipLaunchKernelGGL(k_greedy_policy_episodic<double>, dim3(B), dim3(64), 0, st, B, h->A, 1, 1, h->d_state_off.p,
                            a->d_Qc.p, a->d_pi.p);
         HIP_TRY(hipGetLastError());
-        if (int rc = chain_launch(h, a->d_pi.p, nullptr, h->d_cur.p, h->d_ch_mask.p, nullptr, nullptr, nullptr, true, false))
+        if (int rc = chain_launch(h, a->d_pi.p, nullptr, h->d_cur.p, need.p, avg.p, akind.p, nullptr, true, false))
           return rc;
-        HIP_TRY(hipMemcpyAsync(avg.p, h->d_ch_avg.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(akind.p, h->d_ch_kind.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
       }
     }
     HIP_TRY(hipStreamSynchronize(st));
@@ -3440,8 +3441,8 @@ int cmdp_qlearning_run_logged(cmdp_agent_t* a, const cmdp_loop_desc* d, int64_t 
     if (episodic) {
       // the reference logs step t before the reset that follows a termination: if step t ended an episode (in-episode
       // time back at 0), its `last_starting_node` is still the start of the episode that ended
-      for (int b = 0; b < B; ++b)
-        start_abs[(size_t)b] = h->state_off[b] + ((hstep.p[b] == 0 && in_loop) ? prev.p[b] : last.p[b]);
+      for (int b = 0; b < B; ++b)   // snap: last_start | prev_start | hstep
+        start_abs[(size_t)b] = h->state_off[b] + ((snap.p[2 * B + b] == 0 && in_loop) ? snap.p[B + b] : snap.p[b]);
       episodic_update(tr, ein, t, T, v0.p, start_abs.data(), cum.p, n_since, in_loop, sps, val, knd);
     } else {
       continuous_update(tr, t, T, need.p, avg.p, akind.p, cum.p, n_since, in_loop, sps, val, knd);
@@ -3454,12 +3455,13 @@ int cmdp_qlearning_run_logged(cmdp_agent_t* a, const cmdp_loop_desc* d, int64_t 
     const int64_t tl = log_ts[i];
     // the reference reads `_cumulative_reward` at step tl BEFORE adding that step's reward: the sum is copied after step
     // tl-1, then step tl runs (whose update the logged policy already contains)
-    if (tl - done > 0) {
-      if (int rc = ql_enqueue_run(a, tl - done, a->d_mask.p, nullptr)) return rc;
+    if (tl - done > 0) {   // the kernel leaves the sums in `cum` (page-locked) itself
+      if (int rc = ql_enqueue_run(a, tl - done, a->d_mask.p, nullptr, cum.p)) return rc;
       n_since += tl - done;
+    } else {
+      // no step lies between two rows (log_every == 1): the sum through step tl-1, not the one of an earlier row
+      HIP_TRY(hipMemcpyAsync(cum.p, a->d_rsum.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
     }
-    // also when no step lies between two rows (log_every == 1): the sum through step tl-1, not the one of an earlier row
-    HIP_TRY(hipMemcpyAsync(cum.p, a->d_rsum.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
     if (int rc = ql_enqueue_run(a, 1, a->d_mask.p, nullptr)) return rc;
     done = tl + 1;
     if (int rc = log_row((int64_t)i, tl, n_since, true)) return rc;
@@ -3479,9 +3481,10 @@ int cmdp_qlearning_run_logged(cmdp_agent_t* a, const cmdp_loop_desc* d, int64_t 
   }
   if (T - done > 0) {
     n_since += T - done;
-    if (int rc = ql_enqueue_run(a, T - done, a->d_mask.p, nullptr)) return rc;
+    if (int rc = ql_enqueue_run(a, T - done, a->d_mask.p, nullptr, cum.p)) return rc;
+  } else {
+    HIP_TRY(hipMemcpyAsync(cum.p, a->d_rsum.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
   }
-  HIP_TRY(hipMemcpyAsync(cum.p, a->d_rsum.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
   if (int rc = log_row((int64_t)log_ts.size(), T - 1, n_since, false)) return rc;
   if (is_training)
     for (int b = 0; b < B; ++b) is_training[b] = tr.inst[(size_t)b].training ? 1 : 0;

@@ -50,7 +50,7 @@ template <int UCB, bool RC>
 __global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, int64_t n_steps,
                                                          const uint8_t* __restrict__ train_mask,
                                                          int8_t* __restrict__ act_trace, double* __restrict__ cum_reward,
-                                                         RewardCache rc, int resume) {
+                                                         RewardCache rc, int resume, double* __restrict__ cum_host) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= t.B) return;
   int64_t step0 = 0;
@@ -187,6 +187,7 @@ __global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, 
   t.n_trans[b] = nt;
   t.n_reset[b] = nr;
   cum_reward[b] = sum;
+  if (cum_host) cum_host[b] = sum;   // page-locked host memory: the logged loop reads the sum without a copy
   if (RC) {
     rc.left[b] = parked ? (long long)(n_steps - step) : 0;
     if (!parked) rc.pend_e[b] = -1;
@@ -369,12 +370,21 @@ __global__ void __launch_bounds__(64) k_greedy_policy_episodic(int B, int A, int
 }
 
 // V[0, :] of every instance (row 0 of its [H+1][S_b] block) packed contiguously for one device-to-host copy
+// `V0` may be page-locked host memory (the logged loop: no copy kernel per row); `snap` (nullable, host memory as well)
+// receives last_start / prev_start / hstep of every instance, [3][B]
 __global__ void __launch_bounds__(256) k_gather_v0(int B, int H, const int64_t* __restrict__ state_off,
-                                                   const float* __restrict__ V, float* __restrict__ V0) {
+                                                   const float* __restrict__ V, float* __restrict__ V0,
+                                                   const int32_t* __restrict__ last_start, const int32_t* __restrict__ prev_start,
+                                                   const int32_t* __restrict__ hstep, int32_t* __restrict__ snap) {
   const int b = blockIdx.x;
   const int64_t so = state_off[b];
   const int S = (int)(state_off[b + 1] - so);
   for (int s = threadIdx.x; s < S; s += blockDim.x) V0[so + s] = V[(int64_t)(H + 1) * so + s];
+  if (snap && threadIdx.x == 0) {
+    snap[b] = last_start[b];
+    snap[B + b] = prev_start[b];
+    snap[2 * B + b] = hstep[b];
+  }
 }
 
 
@@ -404,7 +414,7 @@ template <bool RC>
 __global__ void __launch_bounds__(256) k_qlearn_continuous(EnvTables t, QlcArgs q, int64_t n_steps,
                                                            const uint8_t* __restrict__ train_mask,
                                                            int8_t* __restrict__ act_trace, double* __restrict__ cum_reward,
-                                                           RewardCache rc, int resume) {
+                                                           RewardCache rc, int resume, double* __restrict__ cum_host) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= t.B) return;
   int64_t step0 = 0;
@@ -497,6 +507,7 @@ __global__ void __launch_bounds__(256) k_qlearn_continuous(EnvTables t, QlcArgs 
   t.hstep[b] = h;
   t.n_trans[b] = nt;
   cum_reward[b] = sum;
+  if (cum_host) cum_host[b] = sum;
   if (RC) {
     rc.left[b] = parked ? (long long)(n_steps - step) : 0;
     if (!parked) rc.pend_e[b] = -1;
