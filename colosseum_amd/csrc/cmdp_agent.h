@@ -81,6 +81,16 @@ __global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, 
   double sum = cum_reward[b];
   int64_t step = step0;
   for (; step < n_steps; ++step) {
+    // One lane walks one instance and every table lives in HBM / L2, so a step costs its DEPENDENT memory round trips
+    // (~1 us each; 9 of them in the straightforward order).  Where the action count allows (A <= 4) the loads are issued as
+    // early as their addresses are known: the row descriptors of ALL actions next to the Q row (before the action is
+    // chosen), the update's table entries right after the action (before the transition), both MT19937 words of the draw
+    // together, and the row's maximum after the update from registers -- 6 round trips.  Same values, same order of
+    // arithmetic.
+    constexpr int AM = 4;
+    const bool fastA = A <= AM;
+    float qv[AM];
+    RowDesc rd[AM];
     int action = 0;
     int32_t s_t, time, obs;
     double reward;
@@ -91,13 +101,34 @@ __global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, 
       time = h - 1;
       ty = (h >= H) ? 2 : 1;
       obs = (ty == 2) ? -1 : cur;
+      if (fastA) {
+#pragma unroll
+        for (int a = 0; a < AM; ++a) qv[a] = (a < A) ? Q[((int64_t)time * S + s_t) * A + a] : -INFINITY;
+      }
     } else {
       // ---- QValuesActor.select_action: greedy with uniform tie-break --------------------------------------
       const float* qrow = Q + ((int64_t)h * S + cur) * A;
-      float qmax = qrow[0];
-      for (int a = 1; a < A; ++a) qmax = fmaxf(qmax, qrow[a]);
+      if (fastA) {
+        const RowDesc* rp = t.row + (soff + cur) * A;
+#pragma unroll
+        for (int a = 0; a < AM; ++a) {
+          qv[a] = (a < A) ? qrow[a] : -INFINITY;
+          if (a < A) rd[a] = rp[a];
+        }
+      }
+      float qmax;
       int n_tie = 0;
-      for (int a = 0; a < A; ++a) n_tie += (qrow[a] == qmax) ? 1 : 0;
+      if (fastA) {   // fully unrolled over registers (a dynamic index would send the arrays to scratch)
+        qmax = qv[0];
+#pragma unroll
+        for (int a = 1; a < AM; ++a) qmax = fmaxf(qmax, qv[a]);
+#pragma unroll
+        for (int a = 0; a < AM; ++a) n_tie += (a < A && qv[a] == qmax) ? 1 : 0;
+      } else {
+        qmax = qrow[0];
+        for (int a = 1; a < A; ++a) qmax = fmaxf(qmax, qrow[a]);
+        for (int a = 0; a < A; ++a) n_tie += (qrow[a] == qmax) ? 1 : 0;
+      }
       int pick = 0;
       if (n_tie > 1) {  // RandomState.choice(ties) == ties[randint(0, n)]: masked rejection on 32-bit draws
         const uint32_t mx = (uint32_t)(n_tie - 1);
@@ -109,23 +140,55 @@ __global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, 
         *mtp = pos;
         pick = (int)v;
       }
-      for (int a = 0, k = 0; a < A; ++a)
-        if (qrow[a] == qmax) { if (k == pick) action = a; ++k; }
+      if (fastA) {
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < AM; ++a)
+          if (a < A && qv[a] == qmax) { if (k == pick) action = a; ++k; }
+      } else {
+        for (int a = 0, k = 0; a < A; ++a)
+          if (qrow[a] == qmax) { if (k == pick) action = a; ++k; }
+      }
       if (act_trace) act_trace[step * t.B + b] = (int8_t)action;
       s_t = cur;
       time = h;
     }
+    // the update's table entries: their addresses are known now, their loads ride under the transition's round trips
+    const int64_t idx = ((int64_t)time * S + s_t) * A + action;
+    int32_t n_pre = 0;
+    float mu_pre = 0.0f, sg_pre = 0.0f, bt_pre = 0.0f;
+    if (train) {
+      n_pre = N[idx];
+      if (UCB == 1) { mu_pre = MU[idx]; sg_pre = SG[idx]; bt_pre = BT[idx]; }
+    }
     // ---- BaseMDP.step -------------------------------------------------------------------------------------------
+    const bool was_pending = RC && pending;
+    RowDesc dsel;
+    if (fastA && !was_pending) {
+      dsel = rd[0];
+#pragma unroll
+      for (int a = 1; a < AM; ++a)
+        if (a == action) dsel = rd[a];
+    }
     if (RC) {
       double rraw = 0.0;
       int64_t e;
       if (pending) { e = rc.pend_e[b]; pending = false; }
+      else if (fastA) { ty = env_transition_desc<true>(t, soff, ebase, key, cur, h, nt, action, obs, rraw, e, dsel); ++nt; }
       else ty = env_transition(t, soff, ebase, key, cur, h, nt, action, obs, rraw, e);
       if (!rc_fetch(t.sp_rkind, rc, e, rraw)) {
         rc_park(rc, b, e, s_t, action);
         parked = true;
         break;
       }
+      reward = rraw * t.rscale - t.rmin;
+    } else if (fastA) {
+      const unsigned long long n0 = nt;
+      double rraw;
+      int64_t e;
+      ty = env_transition_desc<true>(t, soff, ebase, key, cur, h, n0, action, obs, rraw, e, dsel);
+      ++nt;
+      if (t.sp_rkind && t.sp_rkind[e] == 1) rraw = philox_beta(t.sp_rp0[e], t.sp_rp1[e], n0, key);  // throughput mode only
       reward = rraw * t.rscale - t.rmin;
     } else {
       ty = env_step(t, soff, ebase, key, cur, h, nt, action, obs, reward);
@@ -135,13 +198,20 @@ __global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, 
     if (train) {
       // s_tp1 = -1 at termination indexes the LAST state of row time+1 == H, which is never written (0)
       const float vnext = V[(int64_t)(time + 1) * S + (ty == 2 ? S - 1 : obs)];
-      const int64_t idx = ((int64_t)time * S + s_t) * A + action;
-      const int32_t tN = N[idx] + 1;
+      const int32_t tN = n_pre + 1;
       N[idx] = tN;
       const double x = (double)(H + 1) / (double)(H + tN);
       const bool alpha_py = !(x > q.min_at);  // max(min_at, x) returns the Python float unless x is larger
       const double alpha = alpha_py ? q.min_at : x;
-      const float qold = Q[idx];
+      float qold;
+      if (fastA) {
+        qold = qv[0];
+#pragma unroll
+        for (int a = 1; a < AM; ++a)
+          if (a == action) qold = qv[a];
+      } else {
+        qold = Q[idx];
+      }
       const float rv = __fadd_rn((float)reward, vnext);  // python float + np.float32 -> float32
       float qnew;
       if (UCB == 0) {
@@ -149,10 +219,12 @@ __global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, 
         const double first = alpha_py ? (double)__fmul_rn((float)alpha, qold) : alpha * (double)qold;
         qnew = (float)(first + (1.0 - alpha) * ((double)rv + b_t));
       } else {
-        MU[idx] = __fadd_rn(MU[idx], vnext);
-        SG[idx] = __fadd_rn(SG[idx], __fmul_rn(vnext, vnext));
-        const float old_beta = BT[idx];
-        const float dm = __fsub_rn(SG[idx], MU[idx]);
+        const float mu_new = __fadd_rn(mu_pre, vnext);
+        const float sg_new = __fadd_rn(sg_pre, __fmul_rn(vnext, vnext));
+        MU[idx] = mu_new;
+        SG[idx] = sg_new;
+        const float old_beta = bt_pre;
+        const float dm = __fsub_rn(sg_new, mu_new);
         const float hdm2 = __fmul_rn((float)H, __fmul_rn(dm, dm));
         const int32_t t2 = (int32_t)((uint32_t)tN * (uint32_t)tN);  // np.int32 ** 2 wraps like numpy
         const double inner = (double)hdm2 / (double)t2 + (double)H;  // float32 / int32 -> float64
@@ -172,9 +244,16 @@ __global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, 
         }
       }
       Q[idx] = qnew;
-      const float* qr = Q + ((int64_t)time * S + s_t) * A;
-      float m2 = qr[0];
-      for (int a = 1; a < A; ++a) m2 = fmaxf(m2, qr[a]);
+      float m2;
+      if (fastA) {   // the row from registers, the updated entry replaced
+        m2 = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < AM; ++a) m2 = fmaxf(m2, (a == action) ? qnew : qv[a]);
+      } else {
+        const float* qr = Q + ((int64_t)time * S + s_t) * A;
+        m2 = qr[0];
+        for (int a = 1; a < A; ++a) m2 = fmaxf(m2, qr[a]);
+      }
       V[(int64_t)time * S + s_t] = (m2 < (float)H) ? m2 : (float)H;  // min(H, Q[time, s_t].max())
     }
     if (ty == 2) {
@@ -441,6 +520,12 @@ __global__ void __launch_bounds__(256) k_qlearn_continuous(EnvTables t, QlcArgs 
   double sum = cum_reward[b];
   int64_t step = step0;
   for (; step < n_steps; ++step) {
+    // loads issued as early as their addresses are known (see k_qlearn_episodic): row descriptors of all actions next to
+    // the Q row, the visit count right after the action, both MT19937 words of the draw together
+    constexpr int AM = 4;
+    const bool fastA = A <= AM;
+    double qv[AM];
+    RowDesc rd[AM];
     int action = 0;
     int32_t s_t, obs;
     double reward;
@@ -448,12 +533,33 @@ __global__ void __launch_bounds__(256) k_qlearn_continuous(EnvTables t, QlcArgs 
       s_t = rc.pend_prev[b];
       action = rc.pend_act[b];
       obs = cur;
+      if (fastA) {
+#pragma unroll
+        for (int a = 0; a < AM; ++a) qv[a] = (a < A) ? Q[(int64_t)s_t * A + a] : -INFINITY;
+      }
     } else {
       const double* qrow = Q + (int64_t)cur * A;
-      double qmax = qrow[0];
-      for (int a = 1; a < A; ++a) qmax = fmax(qmax, qrow[a]);
+      if (fastA) {
+        const RowDesc* rp = t.row + (soff + cur) * A;
+#pragma unroll
+        for (int a = 0; a < AM; ++a) {
+          qv[a] = (a < A) ? qrow[a] : -INFINITY;
+          if (a < A) rd[a] = rp[a];
+        }
+      }
+      double qmax;
       int n_tie = 0;
-      for (int a = 0; a < A; ++a) n_tie += (qrow[a] == qmax) ? 1 : 0;
+      if (fastA) {
+        qmax = qv[0];
+#pragma unroll
+        for (int a = 1; a < AM; ++a) qmax = fmax(qmax, qv[a]);
+#pragma unroll
+        for (int a = 0; a < AM; ++a) n_tie += (a < A && qv[a] == qmax) ? 1 : 0;
+      } else {
+        qmax = qrow[0];
+        for (int a = 1; a < A; ++a) qmax = fmax(qmax, qrow[a]);
+        for (int a = 0; a < A; ++a) n_tie += (qrow[a] == qmax) ? 1 : 0;
+      }
       int pick = 0;
       if (n_tie > 1) {
         const uint32_t mx = (uint32_t)(n_tie - 1);
@@ -465,15 +571,33 @@ __global__ void __launch_bounds__(256) k_qlearn_continuous(EnvTables t, QlcArgs 
         *mtp = pos;
         pick = (int)v;
       }
-      for (int a = 0, k = 0; a < A; ++a)
-        if (qrow[a] == qmax) { if (k == pick) action = a; ++k; }
+      if (fastA) {
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < AM; ++a)
+          if (a < A && qv[a] == qmax) { if (k == pick) action = a; ++k; }
+      } else {
+        for (int a = 0, k = 0; a < A; ++a)
+          if (qrow[a] == qmax) { if (k == pick) action = a; ++k; }
+      }
       if (act_trace) act_trace[step * t.B + b] = (int8_t)action;
       s_t = cur;
+    }
+    const int64_t idx = (int64_t)s_t * A + action;
+    const int32_t n_pre = train ? N[idx] : 0;   // its load rides under the transition's round trips
+    const bool was_pending = RC && pending;
+    RowDesc dsel;
+    if (fastA && !was_pending) {
+      dsel = rd[0];
+#pragma unroll
+      for (int a = 1; a < AM; ++a)
+        if (a == action) dsel = rd[a];
     }
     if (RC) {
       double rraw = 0.0;
       int64_t e;
       if (pending) { e = rc.pend_e[b]; pending = false; }
+      else if (fastA) { env_transition_desc<true>(t, soff, ebase, key, cur, h, nt, action, obs, rraw, e, dsel); ++nt; }
       else env_transition(t, soff, ebase, key, cur, h, nt, action, obs, rraw, e);  // continuous: never terminates
       if (!rc_fetch(t.sp_rkind, rc, e, rraw)) {
         rc_park(rc, b, e, s_t, action);
@@ -481,19 +605,34 @@ __global__ void __launch_bounds__(256) k_qlearn_continuous(EnvTables t, QlcArgs 
         break;
       }
       reward = rraw * t.rscale - t.rmin;
+    } else if (fastA) {
+      const unsigned long long n0 = nt;
+      double rraw;
+      int64_t e;
+      env_transition_desc<true>(t, soff, ebase, key, cur, h, n0, action, obs, rraw, e, dsel);
+      ++nt;
+      if (t.sp_rkind && t.sp_rkind[e] == 1) rraw = philox_beta(t.sp_rp0[e], t.sp_rp1[e], n0, key);  // throughput mode only
+      reward = rraw * t.rscale - t.rmin;
     } else {
       env_step(t, soff, ebase, key, cur, h, nt, action, obs, reward);  // continuous: never terminates
     }
     sum += reward;
     if (train) {
-      const int64_t idx = (int64_t)s_t * A + action;
-      const int32_t n = N[idx] + 1;
+      const int32_t n = n_pre + 1;
       N[idx] = n;
       const double x = (Hh + 1.0) / (Hh + (double)n);
       const double alpha = (x > q.min_at) ? x : q.min_at;  // max(min_at, x)
       const double b_t = q.four_span * sqrt(Hh / (double)n * q.log_term);
       const double target = (reward + gamma * V[obs]) + b_t;
-      const double qold = Q[idx];
+      double qold;
+      if (fastA) {
+        qold = qv[0];
+#pragma unroll
+        for (int a = 1; a < AM; ++a)
+          if (a == action) qold = qv[a];
+      } else {
+        qold = Q[idx];
+      }
       const double qm = (1.0 - alpha) * qold + alpha * target;
       QM[idx] = qm;
       Q[idx] = (qm < qold) ? qm : qold;  // min(Q, Q_main)

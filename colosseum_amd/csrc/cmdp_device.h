@@ -61,6 +61,31 @@ __device__ __forceinline__ double mt_random(uint32_t* __restrict__ mt, int32_t* 
   return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
 }
 
+// The same draw with the loads of BOTH words issued before either twist: word k + 1 reads mt[p1], mt[p1 + 1] and
+// mt[p1 +- 397 / 227], none of which is the one entry (mt[p]) word k writes, so the six loads are independent -- one memory
+// round trip instead of two for a stream that lives in HBM (the agent kernels: one lane per instance, every access a
+// dependent round trip).
+__device__ __forceinline__ double mt_random_pair(uint32_t* __restrict__ mt, int32_t* __restrict__ pos_ptr) {
+  const int p = *pos_ptr;
+  const int p1 = (p == 623) ? 0 : p + 1;
+  const int p2 = (p1 == 623) ? 0 : p1 + 1;
+  const int pm = (p >= 227) ? p - 227 : p + 397;
+  const int pm1 = (p1 >= 227) ? p1 - 227 : p1 + 397;
+  const uint32_t m0 = mt[p], m1 = mt[p1], m2 = mt[p2], f0 = mt[pm], f1 = mt[pm1];
+  const uint32_t y0 = (m0 & 0x80000000u) | (m1 & 0x7fffffffu);
+  uint32_t v0 = f0 ^ (y0 >> 1) ^ ((y0 & 1u) ? 0x9908b0dfu : 0u);
+  // word k + 1's "far" entry is the NEW value of mt[p] exactly when pm1 == p (p1 - 227 == p never holds; p1 + 397 == p never
+  // holds either), so f1 is always the old value read above
+  const uint32_t y1 = (m1 & 0x80000000u) | (m2 & 0x7fffffffu);
+  uint32_t v1 = f1 ^ (y1 >> 1) ^ ((y1 & 1u) ? 0x9908b0dfu : 0u);
+  mt[p] = v0;
+  mt[p1] = v1;
+  *pos_ptr = p2;
+  v0 ^= v0 >> 11; v0 ^= (v0 << 7) & 0x9d2c5680u; v0 ^= (v0 << 15) & 0xefc60000u; v0 ^= v0 >> 18;
+  v1 ^= v1 >> 11; v1 ^= (v1 << 7) & 0x9d2c5680u; v1 ^= (v1 << 15) & 0xefc60000u; v1 ^= v1 >> 18;
+  return ((double)(v0 >> 5) * 67108864.0 + (double)(v1 >> 6)) * (1.0 / 9007199254740992.0);
+}
+
 // random.Random(seed) seeding == init_by_array([seed])
 __device__ inline void mt_seed_python_int(uint32_t* __restrict__ mt, uint32_t seed) {
   mt[0] = 19650218u;

@@ -109,22 +109,21 @@ __device__ __forceinline__ int32_t env_reset(const EnvTables& t, int b, int64_t 
 // action -> successor, visit counts, in-episode time.  Returns the step type (1 MID, 2 LAST); `action` < 0 requests the
 // Philox random-policy action; `e` receives the global entry of the transition taken, `rraw` its deterministic reward /
 // distribution mean before the range rescale.
-__device__ __forceinline__ int env_transition(const EnvTables& t, int64_t soff, int64_t ebase, uint2 key, int32_t& cur,
-                                              int32_t& h, unsigned long long& n_trans, int& action, int32_t& obs,
-                                              double& rraw, int64_t& e) {
-  const unsigned long long n = n_trans;
-  if (action < 0) action = philox_action(n, key, t.A);
-  n_trans++;
+// The core takes the row descriptor of (cur, action) by value.  `PAIR`: the two MT19937 words of a draw are fetched together
+// (the agent kernels, which also fetch the descriptors of all actions next to the Q row, before the action is known).
+template <bool PAIR>
+__device__ __forceinline__ int env_transition_desc(const EnvTables& t, int64_t soff, int64_t ebase, uint2 key, int32_t& cur,
+                                                   int32_t& h, unsigned long long n, int action, int32_t& obs,
+                                                   double& rraw, int64_t& e, const RowDesc d) {
   h += 1;
-  const int64_t r = (soff + cur) * t.A + action;
-  const RowDesc d = t.row[r];
   int32_t nxt = d.next_if_det;
   rraw = d.reward_if_det;
   e = ebase + d.first;
   if (d.n > 1) {  // NextStateSampler.sample (custom_samplers.py:59-72)
     double u;
     if (t.rng_mode == 0) {
-      u = mt_random(t.mt + (int64_t)d.mt_slot * 624, t.mt_pos + d.mt_slot);
+      u = PAIR ? mt_random_pair(t.mt + (int64_t)d.mt_slot * 624, t.mt_pos + d.mt_slot)
+               : mt_random(t.mt + (int64_t)d.mt_slot * 624, t.mt_pos + d.mt_slot);
     } else {
       uint32_t w[4];
       philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 0u, 0u, key.x, key.y, w);
@@ -144,6 +143,16 @@ __device__ __forceinline__ int env_transition(const EnvTables& t, int64_t soff, 
   }
   obs = nxt;
   return 1;
+}
+
+__device__ __forceinline__ int env_transition(const EnvTables& t, int64_t soff, int64_t ebase, uint2 key, int32_t& cur,
+                                              int32_t& h, unsigned long long& n_trans, int& action, int32_t& obs,
+                                              double& rraw, int64_t& e) {
+  const unsigned long long n = n_trans;
+  if (action < 0) action = philox_action(n, key, t.A);
+  n_trans++;
+  const RowDesc d = t.row[(soff + cur) * t.A + action];
+  return env_transition_desc<false>(t, soff, ebase, key, cur, h, n, action, obs, rraw, e, d);
 }
 
 // The whole step incl. the reward (`sample_reward`, base.py:1187-1207) for handles whose rewards are deterministic or
