@@ -121,9 +121,10 @@ class BatchedMDP:
         """Blocks of 5000 samples drawn so far and park / fill / relaunch rounds (CMDP_FLAG_REWARD_CACHE)."""
         v = C.c_double()
         out = {}
-        for k, w in (("fills", L.STAT_REWARD_FILLS), ("rounds", L.STAT_REWARD_ROUNDS)):
+        for k, w in (("fills", L.STAT_REWARD_FILLS), ("rounds", L.STAT_REWARD_ROUNDS), ("fill_ms", L.STAT_REWARD_FILL_MS),
+                     ("round_ms", L.STAT_REWARD_ROUND_MS)):
             L.check(self._lib.cmdp_stat(self._h, w, C.byref(v)))
-            out[k] = int(v.value)
+            out[k] = int(v.value) if k in ("fills", "rounds") else float(v.value)
         return out
 
     @property

@@ -16,6 +16,7 @@ import ast
 import csv
 import os
 import re
+import time
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Sequence
@@ -96,7 +97,10 @@ def enumerate_instances(mdp_configs: Dict[str, Dict[str, Dict[str, Any]]], n_see
 
 
 def _build_one(ins: Instance):
-    return make_model(ins.mdp_cls, seed=ins.seed, **ins.mdp_kwargs)
+    m = make_model(ins.mdp_cls, seed=ins.seed, **ins.mdp_kwargs)
+    m.csr()             # the DP views every batch needs, computed where the model is built (a pool of processes), not under
+    m.reward_matrix()   # the GIL of the threads that drive the device batches; they travel with the model (small arrays)
+    return m
 
 
 def _build_models(instances: Sequence[Instance], workers: int):
@@ -129,6 +133,7 @@ def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_m
     # the reference's transition streams -- rows equal the reference's for that seed.  "philox": sampled on the device
     # from counter-based streams (distribution-exact throughput mode; no host work).
     exact = stochastic and beta_rewards == "reference"
+    t0 = time.time()
     env = BatchedMDP(models, rng_mode=L.RNG_PHILOX if stochastic and not exact else rng_mode,
                      philox_keys=np.asarray(seeds, np.uint64) * np.uint64(0x9E3779B1) + np.uint64(17),
                      flags=L.FLAG_REWARD_CACHE if exact else 0)
@@ -138,9 +143,15 @@ def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_m
     else:
         agent = BatchedQLearningContinuous(env, seeds, optimization_horizon=n_steps, **agent_kwargs)
         loop = BatchedContinuousLoop(env, agent)
+    t1 = time.time()
     rows = loop.run(n_steps, log_every, max_time)
+    t2 = time.time()
     for b, table in enumerate(rows):  # what MDPLoop.run returns first: where the time limit froze training (-1: it did not)
         table.last_training_step = int(loop.last_training_step[b])
+    if exact and rows:
+        rows[0].reward_cache_stats = env.reward_cache_stats()
+    if rows:
+        rows[0].phase_seconds = (t1 - t0, t2 - t1)   # tables + baselines + agent | the interaction itself
     agent.close()
     env.close()
     return rows
@@ -182,7 +193,6 @@ def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, r
     results: Dict[int, list] = {}
 
     def work(idx):
-        import time
 
         ins = instances[idx[0]]
         t0 = time.time()
@@ -191,8 +201,12 @@ def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, r
         if on_group_done:
             on_group_done(idx, rows)
         if progress:
+            rcs = getattr(rows[0], "reward_cache_stats", None) if rows else None
+            ph = getattr(rows[0], "phase_seconds", None) if rows else None
             progress(f"{ins.label}: {len(idx)} instances, S={models[idx[0]].n_states}, H={models[idx[0]].H}, "
-                     f"{time.time() - t0:.1f} s")
+                     f"{time.time() - t0:.1f} s" + (f" (set-up and baselines {ph[0]:.1f} s, interaction {ph[1]:.1f} s)" if ph else "")
+                     + (f", reward blocks {rcs['fills']} in {rcs['rounds']} rounds, {rcs['round_ms'] / 1e3:.1f} s "
+                                                    f"in rounds of which {rcs['fill_ms'] / 1e3:.1f} s drawing" if rcs else ""))
         return idx, rows
 
     # Device batches are small next to the GPU (20-220 instances: a handful of wavefronts in latency-bound kernels), so a

@@ -116,6 +116,7 @@ struct cmdp {
   size_t rc_chunk_blocks = 0, rc_next_block = 0;  // blocks handed out so far
   int rc_cap = 0;                                 // blocks one install pass can stage
   int64_t rc_fills = 0, rc_rounds = 0;            // CMDP_STAT_REWARD_FILLS / _ROUNDS
+  double rc_fill_ms = 0.0, rc_round_ms = 0.0;     // CMDP_STAT_REWARD_FILL_MS / _ROUND_MS
   double* rc_stage_h = nullptr;                   // pinned [rc_cap][5000]
   double** rc_dst_h = nullptr;                    // pinned [rc_cap]
   int32_t* rc_ent_h = nullptr;                    // pinned [rc_cap]
@@ -139,6 +140,8 @@ struct cmdp {
   int max_state_unique = 0;  // distinct successor columns of a state over its A rows (0: not computed / rows unsorted)
   bool known_reset = false;  // every instance is known to be past reset() (cmdp_rollout_async checks once, cmdp_step clears)
   hipEvent_t ev_dp0 = nullptr, ev_dp1 = nullptr;  // around the sweep kernel of the last discounted solve (cmdp_stat)
+  hipEvent_t ev_row[2] = {nullptr, nullptr};      // logged loop: policy + state snapshot taken | evaluation of the row complete
+  DevBuf<int32_t> d_cur_snap;                     // logged loop: current states at the row (the solve runs beside the next interval)
   int last_dp_kernel = 0;     // CMDP_STAT_DP_KERNEL: 1 K2, 2 K2R, 5 K2U, 6 K3 (Gauss-Seidel)
   int dp_kernel = 0;  // 0 auto, 1 LDS/global-CSR workgroup kernel, 2 register-resident kernel K2R, 5 its distinct-successor form K2U (3, 4: diameter only)
 
@@ -471,6 +474,14 @@ int cmdp_device_count(void) {
 
 int cmdp_set_device(int device) {
   HIP_TRY(hipSetDevice(device));
+  // CMDP_SYNC_MODE = spin | yield | block: how host threads wait in hipStreamSynchronize (tuning aid for hosts with a CPU
+  // quota: several threads driving batches concurrently each spin on a core by default)
+  if (const char* e = std::getenv("CMDP_SYNC_MODE")) {
+    const unsigned f = !std::strcmp(e, "block") ? hipDeviceScheduleBlockingSync
+                     : !std::strcmp(e, "yield") ? hipDeviceScheduleYield
+                     : !std::strcmp(e, "spin") ? hipDeviceScheduleSpin : hipDeviceScheduleAuto;
+    HIP_TRY(hipSetDeviceFlags(f));
+  }
   return CMDP_OK;
 }
 
@@ -497,6 +508,8 @@ int cmdp_destroy(cmdp_t* h) {
   }
   for (int i = 0; i < 5; ++i)
     if (h->ev_k1u[i]) (void)hipEventDestroy(h->ev_k1u[i]);
+  for (int i = 0; i < 2; ++i)
+    if (h->ev_row[i]) (void)hipEventDestroy(h->ev_row[i]);
   for (double* c : h->rc_chunks) (void)hipFree(c);
   if (h->rc_stage_h) (void)hipHostFree(h->rc_stage_h);
   if (h->rc_dst_h) (void)hipHostFree(h->rc_dst_h);
@@ -1072,6 +1085,7 @@ static int rc_drive(cmdp_t* h, F&& launch) {
     HIP_TRY(hipStreamSynchronize(st));
     const int count = h->rc_list_h[0];
     if (count == 0) return CMDP_OK;
+    const auto t_round = std::chrono::steady_clock::now();
     if (count < 0 || count > B) return fail(CMDP_ERR_HIP, "reward cache: corrupt park count %d", count);
     if (!h->rc_streams_set)
       return fail(CMDP_ERR_INVALID, "CMDP_FLAG_REWARD_CACHE: a Beta reward is needed but cmdp_set_reward_streams was not called");
@@ -1090,7 +1104,9 @@ static int rc_drive(cmdp_t* h, F&& launch) {
         double* out = h->rc_stage_h + (size_t)j * CMDP_RC_BLOCK;
         for (int k = 0; k < CMDP_RC_BLOCK; ++k) out[k] = rs.beta(pa, pb);
       };
+      const auto t_fill = std::chrono::steady_clock::now();
       cmdp_rc::Pool::get().parallel_for(n, fill);
+      h->rc_fill_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fill).count();
       for (int j = 0; j < n; ++j) {
         const int b = h->rc_list_h[j0 + j];
         const int32_t c = h->h_canon[(size_t)h->rc_pend_h[b]];
@@ -1118,6 +1134,7 @@ static int rc_drive(cmdp_t* h, F&& launch) {
       if (j0 + n < count) HIP_TRY(hipStreamSynchronize(st));  // the pinned staging area is reused by the next slice
     }
     if (int rc = launch(1)) return rc;
+    h->rc_round_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_round).count();
   }
 }
 
@@ -1569,6 +1586,10 @@ int cmdp_stat(cmdp_t* h, int which, double* out) {
   }
   if (which == CMDP_STAT_REWARD_FILLS || which == CMDP_STAT_REWARD_ROUNDS) {
     *out = (double)(which == CMDP_STAT_REWARD_FILLS ? h->rc_fills : h->rc_rounds);
+    return CMDP_OK;
+  }
+  if (which == CMDP_STAT_REWARD_FILL_MS || which == CMDP_STAT_REWARD_ROUND_MS) {
+    *out = which == CMDP_STAT_REWARD_FILL_MS ? h->rc_fill_ms : h->rc_round_ms;
     return CMDP_OK;
   }
   return fail(CMDP_ERR_INVALID, "unknown statistic %d", which);
@@ -2833,14 +2854,15 @@ static int build_chain_plan(cmdp_t* h) {
 // `copy_back` false: `avg` / `kind` (when given) are DEVICE-ACCESSIBLE buffers (page-locked host memory in the logged loop) the
 // kernels write directly -- no copy kernel per row; nothing is synchronised.
 static int chain_launch(cmdp_t* h, const float* d_pi, const int32_t* d_act, const int32_t* d_start, const uint8_t* mask,
-                        double* avg, int32_t* kind, int32_t* n_classes, bool mask_on_device = false, bool copy_back = true) {
+                        double* avg, int32_t* kind, int32_t* n_classes, bool mask_on_device = false, bool copy_back = true,
+                        hipStream_t on_stream = nullptr) {
   if (!h->has_dp) return fail(CMDP_ERR_INVALID, "the handle was created without the DP half (CSR transition matrices)");
   if (h->H != 0) return fail(CMDP_ERR_INVALID, "average rewards are defined for continuous instances (horizon 0)");
   const size_t lds = chain_lds_bytes(h->max_S, h->max_row_nnz);
   if (lds > (size_t)kLdsBudget)
     return fail(CMDP_ERR_UNSUPPORTED, "instance with %d states (max %d successors per row) exceeds the LDS budget of K9",
                 h->max_S, h->max_row_nnz);
-  hipStream_t st = h->stream;
+  hipStream_t st = on_stream ? on_stream : h->stream;   // the logged loop runs the solve beside the agents' next interval
   const int B = h->B;
   if (h->d_ch_off.n < (size_t)B + 1) {
     std::vector<int64_t> off(B + 1, 0);
@@ -3391,11 +3413,13 @@ int cmdp_qlearning_run_logged(cmdp_agent_t* a, const cmdp_loop_desc* d, int64_t 
   Tracker tr;
   tr.init(B, d->n_check, d->base_val, d->base_kind);
   EpisodicInputs ein{h->H, d->opt0, d->worst0, d->start_pos, d->start_prob, d->kmax};
-  PinnedBuf<double> cum, avg;
+  // `cum` twice: the next interval's kernel may already be writing its sums while the host reads this row's
+  PinnedBuf<double> cum[2], avg;
   PinnedBuf<float> v0;
   PinnedBuf<int32_t> snap, akind;
   PinnedBuf<uint8_t> mask, need;
-  if (int rc = cum.alloc(B)) return rc;
+  if (int rc = cum[0].alloc(B)) return rc;
+  if (int rc = cum[1].alloc(B)) return rc;
   if (int rc = avg.alloc(B)) return rc;
   if (int rc = v0.alloc((size_t)NS)) return rc;
   if (int rc = snap.alloc((size_t)3 * B)) return rc;
@@ -3405,7 +3429,7 @@ int cmdp_qlearning_run_logged(cmdp_agent_t* a, const cmdp_loop_desc* d, int64_t 
   if (a->d_mask.n < (size_t)B) HIP_TRY(a->d_mask.alloc(B));
   if (h->d_ch_mask.n < (size_t)B) HIP_TRY(h->d_ch_mask.alloc(B));
   std::vector<int64_t> start_abs((size_t)B);
-  for (int b = 0; b < B; ++b) { mask.p[b] = 1; cum.p[b] = 0.0; if (last_training_step) last_training_step[b] = -1; }
+  for (int b = 0; b < B; ++b) { mask.p[b] = 1; cum[0].p[b] = cum[1].p[b] = 0.0; if (last_training_step) last_training_step[b] = -1; }
   HIP_TRY(hipMemcpyAsync(a->d_mask.p, mask.p, B, hipMemcpyHostToDevice, st));
   // MDPLoop.run: visitation counts cleared, environment reset (agent_mdp_interaction.py:219-224)
   if (int rc = cmdp_reset_visits(h)) return rc;
@@ -3413,11 +3437,75 @@ int cmdp_qlearning_run_logged(cmdp_agent_t* a, const cmdp_loop_desc* d, int64_t 
   const auto t_start = std::chrono::steady_clock::now();
   auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
 
-  auto log_row = [&](int64_t i, int64_t t, int64_t n_since, bool in_loop) -> int {
-    // evaluation of the agents' current greedy policies, then one synchronisation for everything this row reads
-    // Everything a row reads comes back WITHOUT copy kernels: the kernels write into page-locked host memory directly
-    // (V[0, :], the start states and in-episode times, the average rewards and their kinds, the reward sums), and read the
-    // evaluation mask from it -- a C4 run issued 580 000 copies of a few hundred bytes, 32 us each under load.
+  // The rows of the run.  Row i: `n_run` steps whose reward sums the row logs (the reference reads `_cumulative_reward` at
+  // step t BEFORE adding that step's reward), then -- inside the loop -- step t itself, whose update the logged policy
+  // already contains; then the evaluation of the agents' greedy policies.  log_every == 1 leaves no step between two rows:
+  // the sum through step t-1 is then what the previous row's single step left.
+  struct Row { int64_t t, n_run, n_since; bool in_loop; };
+  std::vector<Row> plan;
+  {
+    int64_t done = 0, n_since = 0;
+    for (int64_t tl : log_ts) {
+      if (tl - done > 0) n_since += tl - done;
+      plan.push_back(Row{tl, tl - done, n_since, true});
+      done = tl + 1;
+      n_since = 1;
+    }
+    if (T - done > 0) n_since += T - done;
+    plan.push_back(Row{T - 1, T - done, n_since, false});
+  }
+  const size_t n_rows = plan.size();
+
+  // Two things overlap with the evaluation of row i and with the host's work on it: the agents' NEXT interval (same stream,
+  // enqueued before the host waits) and, for the continuous agent, the stationary-distribution solve itself (second stream,
+  // on a snapshot of the policy and of the current states).  Both need the training mask of the next interval before row
+  // i's result is known.  The mask changes in two ways only: (a) an instance freezes -- `after_log` requires the last
+  // n_check normalised regrets, this row's included, to be ~0 and t > 0.2 T, so a row whose n_check - 1 predecessors are not
+  // all ~0 cannot freeze anything, and the host knows that BEFORE the row; (b) the time limit -- rows closer than a few
+  // seconds to it are not run ahead.  Rows that could change the mask are processed in order, as before: the results are
+  // the same either way (tests/test_gpu_mdploop.py holds both against the step-by-step loop).
+  static const bool pipeline_env = !(std::getenv("CMDP_LOGGED_PIPELINE") && std::atoi(std::getenv("CMDP_LOGGED_PIPELINE")) == 0);
+  static const bool block_env = std::getenv("CMDP_SYNC_MODE") && !std::strcmp(std::getenv("CMDP_SYNC_MODE"), "block");
+  // CMDP_LOGGED_DRAIN_EVERY = n: the stream is drained completely every n rows (0: never).  Only for runs under rocprofv3,
+  // whose queue interception faulted in hipLaunchKernel's argument copy once a stream stayed busy long enough for the
+  // runtime's kernel-argument pool to wrap (ROCm 7.2; the same run outside the profiler is fine).
+  static const int drain_env = std::getenv("CMDP_LOGGED_DRAIN_EVERY") ? std::atoi(std::getenv("CMDP_LOGGED_DRAIN_EVERY")) : 0;
+  for (int i = 0; i < 2; ++i)
+    if (!h->ev_row[i]) HIP_TRY(hipEventCreateWithFlags(&h->ev_row[i], hipEventDisableTiming | (block_env ? hipEventBlockingSync : 0)));
+  hipStream_t sx = st;
+  if (!episodic && pipeline_env) {
+    if (!h->aux_stream) HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+    sx = h->aux_stream;
+    if (h->d_cur_snap.n < (size_t)B) HIP_TRY(h->d_cur_snap.alloc(B));
+  }
+  const double atol = episodic ? 1e-4 : 1e-5;
+  auto mask_may_change = [&](const Row& r) -> bool {
+    if (d->max_time - elapsed() < 5.5) return true;
+    for (int b = 0; b < B; ++b) {
+      const Instance& x = tr.inst[(size_t)b];
+      if (!episodic && !x.training && !x.cached) return true;   // the cached evaluation is taken at this row: `need` changes
+      if (x.training && may_freeze(x, tr.n_check, r.t, T, atol)) return true;
+    }
+    return false;
+  };
+
+  auto enqueue_interval = [&](size_t i) -> int {
+    const Row& r = plan[i];
+    double* c = cum[i & 1].p;
+    if (r.n_run > 0) {   // the kernel leaves the sums in `c` (page-locked) itself
+      if (int rc = ql_enqueue_run(a, r.n_run, a->d_mask.p, nullptr, c)) return rc;
+    } else {
+      HIP_TRY(hipMemcpyAsync(c, a->d_rsum.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+    }
+    if (r.in_loop)
+      if (int rc = ql_enqueue_run(a, 1, a->d_mask.p, nullptr)) return rc;
+    return CMDP_OK;
+  };
+
+  // evaluation of the agents' current greedy policies; everything a row reads comes back WITHOUT copy kernels: the kernels
+  // write into page-locked host memory directly (V[0, :], the start states and in-episode times, the average rewards and
+  // their kinds, the reward sums) and read the evaluation mask from it
+  auto enqueue_eval = [&]() -> int {
     if (episodic) {
       if (int rc = ql_enqueue_evaluate(a, v0.p, snap.p)) return rc;
     } else {
@@ -3429,63 +3517,84 @@ int cmdp_qlearning_run_logged(cmdp_agent_t* a, const cmdp_loop_desc* d, int64_t 
         hipLaunchKernelGGL(k_greedy_policy_episodic<double>, dim3(B), dim3(64), 0, st, B, h->A, 1, 1, h->d_state_off.p,
                            a->d_Qc.p, a->d_pi.p);
         HIP_TRY(hipGetLastError());
-        if (int rc = chain_launch(h, a->d_pi.p, nullptr, h->d_cur.p, need.p, avg.p, akind.p, nullptr, true, false))
-          return rc;
+        const int32_t* start = h->d_cur.p;
+        if (sx != st) {
+          HIP_TRY(hipMemcpyAsync(h->d_cur_snap.p, h->d_cur.p, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, st));
+          start = h->d_cur_snap.p;
+          HIP_TRY(hipEventRecord(h->ev_row[0], st));
+          HIP_TRY(hipStreamWaitEvent(sx, h->ev_row[0], 0));
+        }
+        if (int rc = chain_launch(h, a->d_pi.p, nullptr, start, need.p, avg.p, akind.p, nullptr, true, false, sx)) return rc;
+        HIP_TRY(hipEventRecord(h->ev_row[1], sx));
+        return CMDP_OK;
       }
     }
-    HIP_TRY(hipStreamSynchronize(st));
-    const double sps = (double)t / std::max(elapsed(), 1e-9);
-    double* val = values + (size_t)i * N_COLUMNS * B;
-    uint8_t* knd = kinds + (size_t)i * N_COLUMNS * B;
-    steps[i] = t;
+    HIP_TRY(hipEventRecord(h->ev_row[1], st));
+    return CMDP_OK;
+  };
+
+  // CMDP_LOGGED_DEBUG=1: where the host thread's time went (stderr, one line per call)
+  static const bool debug_env = std::getenv("CMDP_LOGGED_DEBUG") != nullptr;
+  double t_enq = 0.0, t_wait = 0.0, t_host = 0.0;
+  int64_t n_ahead = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a0, std::chrono::steady_clock::time_point a1) { return std::chrono::duration<double>(a1 - a0).count(); };
+  if (int rc = enqueue_interval(0)) return rc;
+  for (size_t i = 0; i < n_rows; ++i) {
+    const Row& r = plan[i];
+    const auto c0 = now();
+    if (int rc = enqueue_eval()) return rc;
+    const bool ahead = pipeline_env && i + 1 < n_rows && !(drain_env > 0 && (i + 1) % (size_t)drain_env == 0) && !mask_may_change(r);
+    if (ahead)
+      if (int rc = enqueue_interval(i + 1)) return rc;
+    n_ahead += ahead;
+    const auto c1 = now();
+    HIP_TRY(hipEventSynchronize(h->ev_row[1]));
+    const auto c2 = now();
+    t_enq += secs(c0, c1);
+    t_wait += secs(c1, c2);
+    const double sps = (double)r.t / std::max(elapsed(), 1e-9);
+    double* val = values + i * N_COLUMNS * B;
+    uint8_t* knd = kinds + i * N_COLUMNS * B;
+    const double* cm = cum[i & 1].p;
+    steps[i] = r.t;
     if (episodic) {
       // the reference logs step t before the reset that follows a termination: if step t ended an episode (in-episode
       // time back at 0), its `last_starting_node` is still the start of the episode that ended
       for (int b = 0; b < B; ++b)   // snap: last_start | prev_start | hstep
-        start_abs[(size_t)b] = h->state_off[b] + ((snap.p[2 * B + b] == 0 && in_loop) ? snap.p[B + b] : snap.p[b]);
-      episodic_update(tr, ein, t, T, v0.p, start_abs.data(), cum.p, n_since, in_loop, sps, val, knd);
+        start_abs[(size_t)b] = h->state_off[b] + ((snap.p[2 * B + b] == 0 && r.in_loop) ? snap.p[B + b] : snap.p[b]);
+      episodic_update(tr, ein, r.t, T, v0.p, start_abs.data(), cm, r.n_since, r.in_loop, sps, val, knd);
     } else {
-      continuous_update(tr, t, T, need.p, avg.p, akind.p, cum.p, n_since, in_loop, sps, val, knd);
+      continuous_update(tr, r.t, T, need.p, avg.p, akind.p, cm, r.n_since, r.in_loop, sps, val, knd);
     }
-    return CMDP_OK;
-  };
-
-  int64_t done = 0, n_since = 0;
-  for (size_t i = 0; i < log_ts.size(); ++i) {
-    const int64_t tl = log_ts[i];
-    // the reference reads `_cumulative_reward` at step tl BEFORE adding that step's reward: the sum is copied after step
-    // tl-1, then step tl runs (whose update the logged policy already contains)
-    if (tl - done > 0) {   // the kernel leaves the sums in `cum` (page-locked) itself
-      if (int rc = ql_enqueue_run(a, tl - done, a->d_mask.p, nullptr, cum.p)) return rc;
-      n_since += tl - done;
-    } else {
-      // no step lies between two rows (log_every == 1): the sum through step tl-1, not the one of an earlier row
-      HIP_TRY(hipMemcpyAsync(cum.p, a->d_rsum.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
-    }
-    if (int rc = ql_enqueue_run(a, 1, a->d_mask.p, nullptr)) return rc;
-    done = tl + 1;
-    if (int rc = log_row((int64_t)i, tl, n_since, true)) return rc;
+    if (!r.in_loop) { t_host += secs(c2, now()); break; }
     bool changed = false;
     const bool out_of_time = d->max_time - elapsed() < 0.5;  // `_limit_exceeded` (agent_mdp_interaction.py:172-177) for the batch
     for (int b = 0; b < B; ++b) {
       if (out_of_time && tr.inst[(size_t)b].training) {
         tr.inst[(size_t)b].training = false;
-        if (last_training_step) last_training_step[b] = tl;
+        if (last_training_step) last_training_step[b] = r.t;
       }
       const uint8_t m = tr.inst[(size_t)b].training ? 1 : 0;
       changed = changed || m != mask.p[b];
       mask.p[b] = m;
     }
+    if (changed && ahead)   // cannot happen (see mask_may_change); a wrong row must not be returned silently
+      return fail(CMDP_ERR_HIP, "logged loop: the training mask changed at step %lld although the next interval was already running",
+                  (long long)r.t);
     if (changed) HIP_TRY(hipMemcpyAsync(a->d_mask.p, mask.p, B, hipMemcpyHostToDevice, st));
-    n_since = 1;
+    const auto c3 = now();
+    t_host += secs(c2, c3);
+    if (!ahead) {
+      if (drain_env > 0 && (i + 1) % (size_t)drain_env == 0) HIP_TRY(hipStreamSynchronize(st));
+      if (int rc = enqueue_interval(i + 1)) return rc;
+      t_enq += secs(c3, now());
+    }
   }
-  if (T - done > 0) {
-    n_since += T - done;
-    if (int rc = ql_enqueue_run(a, T - done, a->d_mask.p, nullptr, cum.p)) return rc;
-  } else {
-    HIP_TRY(hipMemcpyAsync(cum.p, a->d_rsum.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
-  }
-  if (int rc = log_row((int64_t)log_ts.size(), T - 1, n_since, false)) return rc;
+  HIP_TRY(hipStreamSynchronize(st));
+  if (debug_env)
+    std::fprintf(stderr, "[logged loop] %d instances, %zu rows (%lld with the next interval started early): enqueue %.2f s, waiting for the device %.2f s, "
+                 "host row work %.2f s\n", B, n_rows, (long long)n_ahead, t_enq, t_wait, t_host);
   if (is_training)
     for (int b = 0; b < B; ++b) is_training[b] = tr.inst[(size_t)b].training ? 1 : 0;
   h->known_reset = true;

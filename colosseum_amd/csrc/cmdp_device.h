@@ -172,10 +172,11 @@ __device__ __forceinline__ float wave_min(float v) {
 
 // ---------------------------------------------------------------------------------------------------
 // Beta(a, b) reward of transition n in CMDP_RNG_PHILOX mode (build-defined; the reference-exact path is the
-// host sampler of colosseum_amd/mdp/reward_sampler.py).  X = Ga / (Ga + Gb) with Marsaglia-Tsang gamma variates;
+// host sampler of colosseum_amd/mdp/reward_sampler.py).  a == 1 or b == 1: inverse CDF of the first uniform of block
+// (n, domain 3, draw 0).  Otherwise X = Ga / (Ga + Gb) with Marsaglia-Tsang gamma variates;
 // every Philox block (n, domain 3, draw k) supplies the two uniforms of one Box-Muller normal and, in its second
 // half, the acceptance uniform; shapes below one use Gamma(shape + 1) * U^(1/shape).  The CPU oracle runs the
-// same recipe with libm, so the two agree to rounding of log/sqrt/cos/pow (tests compare with rtol 1e-12).
+// same recipe with libm, so the two agree to rounding of log/sqrt/cos/pow/log1p/expm1/exp (tests compare with rtol 1e-12).
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double philox_gamma(double shape, unsigned long long n, uint2 key, uint32_t& draw,
                                                uint32_t domain = 3u) {
@@ -202,6 +203,16 @@ __device__ __forceinline__ double philox_gamma(double shape, unsigned long long 
 }
 
 __device__ __forceinline__ double philox_beta(double a, double b, unsigned long long n, uint2 key) {
+  // one shape equal to one (nearly every triple of the reference's MDP families: Beta(1, b) away from the goal, Beta(a, 1)
+  // at it): the inverse CDF, x = 1 - (1 - u)^(1/b) resp. (1 - u)^(1/a), from ONE uniform -- an exact sampler at a tenth of
+  // the instructions of two rejection-sampled gammas (the agent kernels run one lane per instance: the sampler WAS their
+  // step time)
+  if (a == 1.0 || b == 1.0) {
+    uint32_t w[4];
+    philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 3u, 0u, key.x, key.y, w);
+    const double l = log1p(-u53(w[0], w[1]));  // log(1 - u), u in [0, 1)
+    return a == 1.0 ? -expm1(l / b) : exp(l / a);
+  }
   uint32_t draw = 0;
   const double ga = philox_gamma(a, n, key, draw);
   const double gb = philox_gamma(b, n, key, draw);

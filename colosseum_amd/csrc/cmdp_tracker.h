@@ -164,6 +164,22 @@ class Tracker {
   }
 };
 
+// Could the row at step t freeze this (training) instance?  `after_log` needs t > 0.2 T and the LAST n_check normalised regrets,
+// the row's own included, close to zero: so not unless the latest n_check - 1 entries already are.  Conservative in the one
+// thing that is not known before the row (whether all n_check entries are float32, which selects the comparison): an entry
+// counts as close if it is under either.  Used by the logged loop to decide whether the next interval may start before the
+// row's result is known.
+inline bool may_freeze(const Instance& x, int n_check, int64_t t, int64_t T, double atol) {
+  if (!((double)t > 0.2 * (double)T)) return false;
+  const int need = n_check - 1;
+  if ((int)x.ring.size() < need) return false;
+  for (int k = 0; k < need; ++k) {
+    const Num& r = x.ring[x.ring.size() - 1 - (size_t)k];
+    if (!isclose_zero_y(r.v, true, atol) && !isclose_zero_y(r.v, false, atol)) return false;
+  }
+  return true;
+}
+
 // Episodic regrets (agent_mdp_interaction.py:534-578, indicators.py:29-45).
 struct EpisodicInputs {
   int H = 0;

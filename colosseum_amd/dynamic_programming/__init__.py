@@ -116,38 +116,44 @@ def _pick(rs, row):
     return rs.choice(np.where(row == row.max())[0])
 
 
+def _pick_rows(M):
+    """`_pick` for every row of M [n, A], in row order, from ONE RandomState(ARGMAX_SEED): rows with a single maximum are
+    taken in one vectorised pass -- `RandomState.choice` on one candidate draws nothing, so the stream is consumed by the
+    tie rows only, in their order, exactly as the row-by-row loop does."""
+    M = np.asarray(M)
+    n = len(M)
+    if n == 0:
+        return np.zeros(0, np.int64)
+    is_max = M == M.max(axis=1, keepdims=True)
+    picks = is_max.argmax(axis=1)
+    ties = np.flatnonzero(is_max.sum(axis=1) != 1)   # also rows of NaNs (no element equals the maximum): left to `_pick`
+    if len(ties):
+        rs = np.random.RandomState(ARGMAX_SEED)
+        for s in ties.tolist():
+            picks[s] = _pick(rs, M[s])
+    return picks
+
+
 def argmax_2d(A):
-    rs = np.random.RandomState(ARGMAX_SEED)
     X = np.zeros_like(A, np.float32)
-    for s in range(len(A)):
-        X[s, _pick(rs, A[s])] = 1
+    X[np.arange(len(A)), _pick_rows(A)] = 1
     return X
 
 
 def argmax_3d(A):
-    rs = np.random.RandomState(ARGMAX_SEED)
+    H, S = A.shape[:2]
     X = np.zeros(A.shape, np.float32)
-    for h in range(len(A)):
-        for s in range(A.shape[1]):
-            X[h, s, _pick(rs, A[h, s])] = 1.0
+    X.reshape(H * S, -1)[np.arange(H * S), _pick_rows(A.reshape(H * S, -1))] = 1.0
     return X
 
 
 def get_deterministic_policy_from_q_values(Q):
-    rs = np.random.RandomState(ARGMAX_SEED)
-    X = np.zeros(Q.shape[:-1], np.int32)
-    for s in range(len(Q)):
-        X[s] = np.int32(_pick(rs, Q[s]))
-    return X
+    return _pick_rows(Q).astype(np.int32)
 
 
 def get_deterministic_policy_from_q_values_finite_horizon(Q):
-    rs = np.random.RandomState(ARGMAX_SEED)
-    X = np.zeros(Q.shape[:-1], np.int32)
-    for h in range(len(Q)):
-        for s in range(Q.shape[1]):
-            X[h, s] = np.int32(_pick(rs, Q[h, s]))
-    return X
+    H, S = Q.shape[:2]
+    return _pick_rows(Q.reshape(H * S, -1)).astype(np.int32).reshape(H, S)
 
 
 def get_policy_from_q_values(Q, stochastic_form=False):

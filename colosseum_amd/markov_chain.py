@@ -26,13 +26,16 @@ def get_transition_probabilities(T: np.ndarray, policy: np.ndarray) -> np.ndarra
 
 
 def gth_batch(mats: Sequence[np.ndarray]) -> List[np.ndarray]:
-    """Stationary distributions of single-recurrent-class chains on the device (float64 GTH)."""
+    """Stationary distributions of single-recurrent-class chains on the device (float64 GTH).  The matrices are widened to
+    float64 straight into the one buffer the call takes (no per-matrix copies: a batch of baselines is ~1 GB of them)."""
     lib = L.load()
-    mats = [np.ascontiguousarray(m, np.float64) for m in mats]
     if not mats:
         return []
     dims = np.array([m.shape[0] for m in mats], np.int32)
-    flat = np.concatenate([m.ravel() for m in mats])
+    moff = np.concatenate([[0], np.cumsum(dims.astype(np.int64) ** 2)])
+    flat = np.empty(int(moff[-1]), np.float64)
+    for m, o, n in zip(mats, moff, dims):
+        flat[o: o + int(n) * int(n)].reshape(n, n)[...] = m
     out = np.zeros(int(dims.sum()), np.float64)
     L.check(lib.cmdp_gth(len(mats), L.ptr(dims), L.ptr(flat), L.ptr(out)))
     off = np.concatenate([[0], np.cumsum(dims)])
@@ -170,7 +173,7 @@ def get_average_reward_batch(problems, builtin_sum: bool = False) -> List[float]
                 slots.append((cls, w, None))
             else:
                 slots.append((cls, w, len(mats)))
-                mats.append(tps[np.ix_(cls, cls)])
+                mats.append(tps if len(cls) == len(tps) else tps[np.ix_(cls, cls)])   # the whole chain: no gather
         prepared.append((ars, len(tps), dtype, slots))
     sols = gth_batch(mats)
     out = []

@@ -52,6 +52,7 @@ class TabularModel:
     extra: Dict = field(default_factory=dict)
     _dense: Optional[Tuple[np.ndarray, np.ndarray]] = None
     _csr: Optional[Tuple[np.ndarray, np.ndarray, np.ndarray]] = None
+    _R: Optional[np.ndarray] = None
 
     @property
     def is_episodic(self) -> bool:
@@ -85,16 +86,25 @@ class TabularModel:
         return self._csr
 
     def reward_matrix(self) -> np.ndarray:
-        """R[s, a] = float32(sum_k p_k * mean_k), float64 accumulation in creation order (mdp_creation.py:73-81)."""
-        SA = self.n_states * self.n_actions
-        R = np.zeros(SA, np.float32)
-        for r in range(SA):
-            lo, hi = int(self.sp_ptr[r]), int(self.sp_ptr[r + 1])
-            acc = 0
-            for p, m in zip(self.sp_prob[lo:hi].tolist(), self.sp_rmean[lo:hi].tolist()):
-                acc += p * m
-            R[r] = acc
-        return R.reshape(self.n_states, self.n_actions)
+        """R[s, a] = float32(sum_k p_k * mean_k), float64 accumulation in creation order (mdp_creation.py:73-81).
+        Computed once (the array is shared between calls and read-only); rows are padded to the longest one and added up
+        entry by entry -- `acc + 0.0 * 0.0 == acc` exactly, so the padding leaves the left-to-right sums untouched."""
+        if self._R is None:
+            SA = self.n_states * self.n_actions
+            ptr = np.asarray(self.sp_ptr, np.int64)
+            n = np.diff(ptr)
+            rows = np.repeat(np.arange(SA), n)
+            pos = np.arange(len(self.sp_prob)) - np.repeat(ptr[:-1], n)
+            K = int(n.max()) if SA else 0
+            prod = np.zeros((SA, K))
+            prod[rows, pos] = np.asarray(self.sp_prob, np.float64) * np.asarray(self.sp_rmean, np.float64)
+            acc = np.zeros(SA)
+            for k in range(K):
+                acc = acc + prod[:, k]
+            R = acc.astype(np.float32).reshape(self.n_states, self.n_actions)
+            R.setflags(write=False)
+            self._R = R
+        return self._R
 
     def dense(self) -> Tuple[np.ndarray, np.ndarray]:
         """Dense (T float32 [S,A,S], R float32 [S,A]) as `BaseMDP.transition_matrix_and_rewards`."""

@@ -209,7 +209,11 @@ enum { CMDP_STAT_DP_KERNEL_MS = 1, CMDP_STAT_DP_KERNEL = 2,
        CMDP_STAT_ROLLOUT_KERNEL_MS = 5, /* K1U: HIP-event time of k_rollout_tmpl_stream in the last launch (last segment) */
        CMDP_STAT_HIST_KERNEL_MS = 6,    /* K1U: ... and of its k_trace_hist (on the second stream when overlapped)          */
        CMDP_STAT_CHAIN_FAST_INSTANCES = 7 /* instances (evaluated or masked out) the last average-reward call did NOT hand to K9:
-                                             those K9F solved (irreducible chain, fill-reducing elimination order)          */ };
+                                             those K9F solved (irreducible chain, fill-reducing elimination order)          */,
+       CMDP_STAT_REWARD_FILL_MS = 8,   /* CMDP_FLAG_REWARD_CACHE: host wall time spent drawing blocks (all host threads together
+                                          count once: the time the calling thread waited for the draws)                       */
+       CMDP_STAT_REWARD_ROUND_MS = 9   /* ... and wall time of the park rounds as a whole: copy of the park list, draws, install,
+                                          up to the relaunch                                                                  */ };
 int cmdp_stat(cmdp_t* h, int which, double* out);
 /* Latency floor of the LDS-resident rollout kernels, measured on the current device: one wavefront per CU follows
    per-lane uint16 tables in LDS for n_steps dependent reads.  CMDP_CALIB_LDS_READ: the bare dependent ds_read_u16
