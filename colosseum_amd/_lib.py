@@ -15,6 +15,7 @@ POLICY_RANDOM, POLICY_HOST_ACTIONS, POLICY_GREEDY_Q = 0, 1, 2
 SCHEME_AUTO, SCHEME_JACOBI, SCHEME_GAUSS_SEIDEL = 0, 1, 2
 LAYOUT_CSR, LAYOUT_DENSE = 0, 1
 FLAG_REWARD_MEANS = 1
+FLAG_BETA_GAMMAS = 4   # device-sampled Beta rewards: two gammas for every shape (rounds 1-2 recipe)
 FLAG_REWARD_CACHE = 2  # reference-exact per-triple reward caches for batches (csrc/cmdp_reward_cache.h)
 OPT_ROLLOUT_KERNEL = 1
 OPT_DP_KERNEL = 2

@@ -136,7 +136,7 @@ def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_m
     t0 = time.time()
     env = BatchedMDP(models, rng_mode=L.RNG_PHILOX if stochastic and not exact else rng_mode,
                      philox_keys=np.asarray(seeds, np.uint64) * np.uint64(0x9E3779B1) + np.uint64(17),
-                     flags=L.FLAG_REWARD_CACHE if exact else 0)
+                     flags=L.FLAG_REWARD_CACHE if exact else (L.FLAG_BETA_GAMMAS if beta_rewards == "philox-gammas" else 0))
     if agent_cls == "QLearningEpisodic":
         agent = BatchedQLearningEpisodic(env, seeds, optimization_horizon=n_steps, **agent_kwargs)
         loop = BatchedEpisodicLoop(env, agent)
@@ -150,10 +150,10 @@ def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_m
         table.last_training_step = int(loop.last_training_step[b])
     if exact and rows:
         rows[0].reward_cache_stats = env.reward_cache_stats()
-    if rows:
-        rows[0].phase_seconds = (t1 - t0, t2 - t1)   # tables + baselines + agent | the interaction itself
     agent.close()
     env.close()
+    if rows:
+        rows[0].phase_seconds = (t1 - t0, t2 - t1, time.time() - t2)   # tables + baselines + agent | the interaction | release
     return rows
 
 
@@ -170,7 +170,7 @@ def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, r
     (default: the reference's reward caches and streams, rows equal the reference's) or "philox" (device-sampled Beta
     rewards, distribution-exact).  `on_group_done(indices, rows)` is called from the worker thread as soon as a device
     batch has finished (the runner writes that batch's log files then, so an interrupted run resumes from them)."""
-    assert beta_rewards in ("reference", "philox")
+    assert beta_rewards in ("reference", "philox", "philox-gammas")
     agent_configs = agent_configs or DEFAULT_AGENT_CONFIGS
     lo, hi = shard_range(len(instances), rank, world)
     skip = set(skip or ())
@@ -204,7 +204,7 @@ def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, r
             rcs = getattr(rows[0], "reward_cache_stats", None) if rows else None
             ph = getattr(rows[0], "phase_seconds", None) if rows else None
             progress(f"{ins.label}: {len(idx)} instances, S={models[idx[0]].n_states}, H={models[idx[0]].H}, "
-                     f"{time.time() - t0:.1f} s" + (f" (set-up and baselines {ph[0]:.1f} s, interaction {ph[1]:.1f} s)" if ph else "")
+                     f"{time.time() - t0:.1f} s" + (f" (set-up and baselines {ph[0]:.1f} s, interaction {ph[1]:.1f} s, release {ph[2]:.1f} s)" if ph else "")
                      + (f", reward blocks {rcs['fills']} in {rcs['rounds']} rounds, {rcs['round_ms'] / 1e3:.1f} s "
                                                     f"in rounds of which {rcs['fill_ms'] / 1e3:.1f} s drawing" if rcs else ""))
         return idx, rows

@@ -104,6 +104,7 @@ struct cmdp {
   int64_t n_states = 0, n_rows = 0, n_entries = 0, n_csr = 0, n_slots = 0;
   bool has_env = false, has_dp = false;
   bool sample_beta = false;  // Beta rewards drawn on the device (CMDP_RNG_PHILOX without CMDP_FLAG_REWARD_MEANS)
+  bool beta_gammas = false;  // CMDP_FLAG_BETA_GAMMAS
   // CMDP_FLAG_REWARD_CACHE: the reference's per-triple caches of 5000 samples from the MDP's own numpy stream
   // (cmdp_reward_cache.h): blocks in HBM, drawn on the host whenever an instance parks
   bool reward_cache = false, rc_streams_set = false;
@@ -236,7 +237,7 @@ struct cmdp {
   EnvTables env() {
     EnvTables t{};
     t.B = B; t.A = A; t.H = H; t.rng_mode = rng_mode;
-    t.rscale = rmax - rmin; t.rmin = rmin;
+    t.rscale = rmax - rmin; t.rmin = rmin; t.beta_gammas = beta_gammas ? 1 : 0;
     t.state_off = d_state_off.p; t.entry_base = d_entry_base.p; t.row = d_row.p;
     t.sp_next = d_sp_next.p; t.sp_cum = d_sp_cum.p; t.sp_reward = d_sp_reward.p;
     t.sp_rkind = d_sp_rkind.p; t.sp_rp0 = d_sp_rp0.p; t.sp_rp1 = d_sp_rp1.p;
@@ -584,6 +585,7 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
     const bool reward_cache = any_beta && (d->flags & CMDP_FLAG_REWARD_CACHE);
     const bool sample_beta = any_beta && !(d->flags & (CMDP_FLAG_REWARD_MEANS | CMDP_FLAG_REWARD_CACHE));
     h->sample_beta = sample_beta;
+    h->beta_gammas = (d->flags & CMDP_FLAG_BETA_GAMMAS) != 0;
     h->reward_cache = reward_cache;
     if (reward_cache) {
       if (!d->sp_rp0 || !d->sp_rp1 || d->layout != CMDP_LAYOUT_CSR)

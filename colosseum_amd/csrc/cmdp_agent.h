@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256) k_qlearn_episodic(EnvTables t, QlArgs q, 
       int64_t e;
       ty = env_transition_desc<true>(t, soff, ebase, key, cur, h, n0, action, obs, rraw, e, dsel);
       ++nt;
-      if (t.sp_rkind && t.sp_rkind[e] == 1) rraw = philox_beta(t.sp_rp0[e], t.sp_rp1[e], n0, key);  // throughput mode only
+      if (t.sp_rkind && t.sp_rkind[e] == 1) rraw = philox_beta(t.sp_rp0[e], t.sp_rp1[e], n0, key, t.beta_gammas);  // throughput mode only
       reward = rraw * t.rscale - t.rmin;
     } else {
       ty = env_step(t, soff, ebase, key, cur, h, nt, action, obs, reward);
@@ -611,7 +611,7 @@ __global__ void __launch_bounds__(256) k_qlearn_continuous(EnvTables t, QlcArgs 
       int64_t e;
       env_transition_desc<true>(t, soff, ebase, key, cur, h, n0, action, obs, rraw, e, dsel);
       ++nt;
-      if (t.sp_rkind && t.sp_rkind[e] == 1) rraw = philox_beta(t.sp_rp0[e], t.sp_rp1[e], n0, key);  // throughput mode only
+      if (t.sp_rkind && t.sp_rkind[e] == 1) rraw = philox_beta(t.sp_rp0[e], t.sp_rp1[e], n0, key, t.beta_gammas);  // throughput mode only
       reward = rraw * t.rscale - t.rmin;
     } else {
       env_step(t, soff, ebase, key, cur, h, nt, action, obs, reward);  // continuous: never terminates

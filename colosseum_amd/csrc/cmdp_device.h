@@ -202,12 +202,12 @@ __device__ __forceinline__ double philox_gamma(double shape, unsigned long long 
   return boost * d;  // unreachable in practice (acceptance > 95 % per attempt)
 }
 
-__device__ __forceinline__ double philox_beta(double a, double b, unsigned long long n, uint2 key) {
+__device__ __forceinline__ double philox_beta(double a, double b, unsigned long long n, uint2 key, int gammas_only) {
   // one shape equal to one (nearly every triple of the reference's MDP families: Beta(1, b) away from the goal, Beta(a, 1)
   // at it): the inverse CDF, x = 1 - (1 - u)^(1/b) resp. (1 - u)^(1/a), from ONE uniform -- an exact sampler at a tenth of
   // the instructions of two rejection-sampled gammas (the agent kernels run one lane per instance: the sampler WAS their
   // step time)
-  if (a == 1.0 || b == 1.0) {
+  if (!gammas_only && (a == 1.0 || b == 1.0)) {
     uint32_t w[4];
     philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 3u, 0u, key.x, key.y, w);
     const double l = log1p(-u53(w[0], w[1]));  // log(1 - u), u in [0, 1)

@@ -33,6 +33,7 @@ __device__ __forceinline__ void bump(int32_t* p) {
 struct EnvTables {
   int32_t B, A, H, rng_mode;
   double rscale, rmin;               // reward = r * rscale - rmin
+  int32_t beta_gammas;               // CMDP_FLAG_BETA_GAMMAS
   const int64_t* state_off;          // [B+1]
   const int64_t* entry_base;         // [B]
   const RowDesc* row;                // [R]
@@ -166,7 +167,7 @@ __device__ __forceinline__ int env_step(const EnvTables& t, int64_t soff, int64_
   double rraw;
   int64_t e;
   const int ty = env_transition(t, soff, ebase, key, cur, h, n_trans, action, obs, rraw, e);
-  if (BETA && t.sp_rkind && t.sp_rkind[e] == 1) rraw = philox_beta(t.sp_rp0[e], t.sp_rp1[e], n, key);  // throughput mode only
+  if (BETA && t.sp_rkind && t.sp_rkind[e] == 1) rraw = philox_beta(t.sp_rp0[e], t.sp_rp1[e], n, key, t.beta_gammas);  // throughput mode only
   reward = rraw * t.rscale - t.rmin;  // `r * (max - min) - min`, base.py:1205-1207
   return ty;
 }
@@ -1250,7 +1251,7 @@ __global__ void __launch_bounds__(256) k_rollout_dense(EnvTables t, DenseArgs dn
       ent += found;
       rraw = t.sp_reward[ent];
     }
-    if (BETA && t.sp_rkind && t.sp_rkind[ent] == 1) rraw = philox_beta(t.sp_rp0[ent], t.sp_rp1[ent], x.nt - 1, x.key);
+    if (BETA && t.sp_rkind && t.sp_rkind[ent] == 1) rraw = philox_beta(t.sp_rp0[ent], t.sp_rp1[ent], x.nt - 1, x.key, t.beta_gammas);
     x.sum += rraw * t.rscale - t.rmin;
     if (lane == 0) {
       bump(t.visits_s + x.soff + nxt);

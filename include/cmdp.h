@@ -98,7 +98,12 @@ enum {
      and the kernel is relaunched -- inside cmdp_step, cmdp_rollout, cmdp_qlearning_run and cmdp_qlearning_run_logged.
      Needs sp_rp0 / sp_rp1 and the CSR layout; the transition streams are whatever rng_mode says (CMDP_RNG_MT_COMPAT for
      the reference's).  Rollouts run on the lane-per-instance kernel; cmdp_rollout_async is synchronous in this mode. */
-  CMDP_FLAG_REWARD_CACHE = 2
+  CMDP_FLAG_REWARD_CACHE = 2,
+  /* CMDP_RNG_PHILOX with Beta rewards sampled on the device: EVERY Beta(a, b) as Ga / (Ga + Gb) with two Marsaglia-Tsang
+     gammas -- the recipe of rounds 1-2.  Without the flag a Beta with a == 1 or b == 1 (nearly every triple of the
+     reference's MDP families) is drawn by inverse CDF from one uniform: the same distribution from a tenth of the
+     instructions, other numbers.  The flag exists so that earlier runs can be reproduced (csrc/cmdp_device.h philox_beta). */
+  CMDP_FLAG_BETA_GAMMAS = 4
 };
 
 typedef struct cmdp cmdp_t;

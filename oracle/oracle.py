@@ -34,6 +34,7 @@ def lib():
                                         C.c_void_p, C.c_int32, C.c_uint64]
         L.oracle_env_destroy.argtypes = [C.c_void_p]
         L.oracle_env_set_reward_dists.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_env_set_beta_gammas.argtypes = [C.c_void_p, C.c_int]
         L.oracle_env_set_dense.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_env_reset.restype = C.c_int32
         L.oracle_env_reset.argtypes = [C.c_void_p]
@@ -83,7 +84,7 @@ class OracleEnv:
     """One instance of the interaction loop on the CPU oracle.  `model` is a colosseum_amd TabularModel
     (only its plain arrays are read)."""
 
-    def __init__(self, model, rng_mode=0, philox_key=0, dense=False, sample_beta=False):
+    def __init__(self, model, rng_mode=0, philox_key=0, dense=False, sample_beta=False, beta_gammas=False):
         L = lib()
         self._keep = dict(
             sp_ptr=np.ascontiguousarray(model.sp_ptr, np.int64),
@@ -110,6 +111,7 @@ class OracleEnv:
             k.update(r_kind=np.ascontiguousarray(model.sp_rkind, np.uint8), r_p0=np.ascontiguousarray(model.sp_rp0, np.float64),
                      r_p1=np.ascontiguousarray(model.sp_rp1, np.float64))
             L.oracle_env_set_reward_dists(self._e, _ptr(k["r_kind"]), _ptr(k["r_p0"]), _ptr(k["r_p1"]))
+            L.oracle_env_set_beta_gammas(self._e, int(bool(beta_gammas)))
         if dense:
             assert rng_mode == 1
             ptr, col, val = _csr64(model.csr())

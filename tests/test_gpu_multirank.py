@@ -93,7 +93,7 @@ def test_c4_at_its_real_length(need_gpu, tmp_path):
             "--out", str(tmp_path / "c4"), "--beta-rewards", "philox"]
     s = json.loads(_run([sys.executable] + args, timeout=500).strip().splitlines()[-1])
     assert s["instances"] == s["run"] == 1000 and s["steps_each"] == 500000 and s["skipped_existing"] == 0
-    assert s["mean_normalized_cumulative_regret"] == pytest.approx(380972.0156768999, rel=1e-12)
+    assert s["mean_normalized_cumulative_regret"] == pytest.approx(379778.62248119974, rel=1e-12)
     files = glob.glob(str(tmp_path / "c4" / "logs" / "*" / "seed*_logs.csv"))
     assert len(files) == 1000
     for f in files[::97]:

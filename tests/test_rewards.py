@@ -105,25 +105,28 @@ def test_device_beta_rewards_philox(need_gpu):
                     ("FrozenLakeContinuous", dict(seed=1, size=5, p_frozen=0.9, p_lazy=0.05, make_reward_stochastic=True,
                                                   reward_variance_multiplier=0.3))]:
         m = make_model(cls, **kw)
-        env = BatchedMDP([m, m], rng_mode=L.RNG_PHILOX, philox_keys=[7, 8], with_dp=False)
-        env.reset()
-        out = env.rollout(3000, None, trace=True)
-        for i in range(2):
-            e = O.OracleEnv(m, rng_mode=1, philox_key=7 + i, sample_beta=True)
-            e.reset()
-            ref = e.rollout(3000)
-            np.testing.assert_array_equal(out["obs"][:, i], ref["obs"])
-            np.testing.assert_allclose(out["rew"][:, i], ref["rew"], rtol=1e-12, atol=1e-300)
-            assert out["reward_sum"][i] == pytest.approx(ref["reward_sum"], rel=1e-12)
-        assert 0.0 < out["rew"].min() and out["rew"].max() < 1.0 and np.unique(out["rew"]).size > 5000
-        env.close()
+        # both recipes: inverse CDF for unit shapes (default), two gammas for every shape (CMDP_FLAG_BETA_GAMMAS, rounds 1-2)
+        for gammas in (False, True):
+            env = BatchedMDP([m, m], rng_mode=L.RNG_PHILOX, philox_keys=[7, 8], with_dp=False, flags=L.FLAG_BETA_GAMMAS if gammas else 0)
+            env.reset()
+            out = env.rollout(3000, None, trace=True)
+            for i in range(2):
+                e = O.OracleEnv(m, rng_mode=1, philox_key=7 + i, sample_beta=True, beta_gammas=gammas)
+                e.reset()
+                ref = e.rollout(3000)
+                np.testing.assert_array_equal(out["obs"][:, i], ref["obs"])
+                np.testing.assert_allclose(out["rew"][:, i], ref["rew"], rtol=1e-12, atol=1e-300)
+                assert out["reward_sum"][i] == pytest.approx(ref["reward_sum"], rel=1e-12)
+            assert 0.0 < out["rew"].min() and out["rew"].max() < 1.0 and np.unique(out["rew"]).size > 5000
+            env.close()
         with pytest.raises(L.CmdpError):  # reference-exact Beta sampling is host side: MT_COMPAT refuses to fake it
             BatchedMDP([m], rng_mode=L.RNG_MT_COMPAT, with_dp=False)
 
-    for a, b in ((0.5, 0.11), (2.0, 4.0), (24.0, 1.0), (1.0, 249.0), (0.3, 7.5)):
+    for a, b, fl in ((0.5, 0.11, 0), (2.0, 4.0, 0), (24.0, 1.0, 0), (1.0, 249.0, 0), (0.3, 7.5, 0), (1.0, 1.0, 0),
+                     (24.0, 1.0, L.FLAG_BETA_GAMMAS), (1.0, 249.0, L.FLAG_BETA_GAMMAS)):
         B = 64
         env = BatchedMDP(tables=_single_state_tables(B, a, b), rng_mode=L.RNG_PHILOX,
-                         philox_keys=np.arange(1000, 1000 + B, dtype=np.uint64))
+                         philox_keys=np.arange(1000, 1000 + B, dtype=np.uint64), flags=fl)
         env.reset()
         x = env.rollout(2000, None, trace=True)["rew"].ravel()
         env.close()

@@ -20,6 +20,9 @@ import yaml
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# many host threads, one device batch each: they sleep while they wait for the device instead of spinning on a core apiece
+# (the GPU boxes give a job a CPU quota; spinning threads starve the reward draws and the log writers of it)
+os.environ.setdefault("CMDP_SYNC_MODE", "block")
 from colosseum_amd import benchmark as bm  # noqa: E402
 from colosseum_amd.sharding import gather_instances, shard_range  # noqa: E402
 
@@ -38,9 +41,10 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0")
     ap.add_argument("--max-time", type=float, help="seconds of training per instance (default: the experiment's max_interaction_time_s)")
-    ap.add_argument("--beta-rewards", default="reference", choices=["reference", "philox"],
+    ap.add_argument("--beta-rewards", default="reference", choices=["reference", "philox", "philox-gammas"],
                     help="stochastic (Beta) rewards: 'reference' = the reference's per-triple caches of 5000 samples from the MDP's own "
-                         "numpy stream (rows equal the reference's); 'philox' = sampled on the device (distribution-exact, no host work)")
+                         "numpy stream (rows equal the reference's); 'philox' = sampled on the device (distribution-exact, no host work); "
+                         "'philox-gammas' = the same with the two-gamma sampler of rounds 1-2 for every shape (reproduces their numbers)")
     ap.add_argument("--overwrite", action="store_true",
                     help="run every instance; default: skip those whose log file exists, as the reference's resume does")
     args = ap.parse_args()
