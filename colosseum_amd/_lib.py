@@ -27,6 +27,7 @@ OPT_DIAMETER_RELABEL_MIN_STATES = 7
 STAT_DP_KERNEL_MS, STAT_DP_KERNEL, STAT_REWARD_FILLS, STAT_REWARD_ROUNDS, STAT_ROLLOUT_KERNEL_MS, STAT_HIST_KERNEL_MS = 1, 2, 3, 4, 5, 6
 STAT_CHAIN_FAST_INSTANCES = 7
 STAT_REWARD_FILL_MS, STAT_REWARD_ROUND_MS = 8, 9
+STAT_DIAMETER_CLUSTER_LAUNCHES, STAT_DIAMETER_CLUSTER_FALLBACKS = 10, 11
 NOISE_NONE, NOISE_GAUSSIAN, NOISE_GAUSSIAN_CORRELATED, NOISE_STUDENT_T, NOISE_STUDENT_T_CORRELATED = 0, 1, 2, 3, 4
 CALIB_LDS_READ, CALIB_LDS_CHAIN, CALIB_LDS_CHAIN_SHARED = 0, 1, 2
 DP_AUTO, DP_WORKGROUP, DP_REGISTER = 0, 1, 2

@@ -210,6 +210,10 @@ struct cmdp {
   double tile_rows_per_state = 0.0;  // tile rows gathered per state and sweep (1 + halo/cluster)
   DevBuf<int32_t> d_dl_inst, d_dl_t0, d_dl_cnt;
   DevBuf<int64_t> d_dl_voff;
+  DevBuf<float> d_k5c_red;          // K5C: the clusters' partial reductions
+  DevBuf<unsigned int> d_k5c_bar;   // K5C: barrier counters + error flag
+  int64_t k5c_launches = 0, k5c_timeouts = 0;
+  bool k5c_agent_scope = false;     // K5C: a cluster was found spread over XCDs once -- agent-scope barriers from then on
   size_t dl_ws_bytes = (size_t)24 << 30;  // value arrays of the target groups in flight per launch
   // observation tables (k_emit)
   DevBuf<float> d_obs_table, d_obs_out, d_obs_chol;
@@ -1590,6 +1594,10 @@ int cmdp_stat(cmdp_t* h, int which, double* out) {
     *out = (double)(which == CMDP_STAT_REWARD_FILLS ? h->rc_fills : h->rc_rounds);
     return CMDP_OK;
   }
+  if (which == CMDP_STAT_DIAMETER_CLUSTER_LAUNCHES || which == CMDP_STAT_DIAMETER_CLUSTER_FALLBACKS) {
+    *out = (double)(which == CMDP_STAT_DIAMETER_CLUSTER_LAUNCHES ? h->k5c_launches : h->k5c_timeouts);
+    return CMDP_OK;
+  }
   if (which == CMDP_STAT_REWARD_FILL_MS || which == CMDP_STAT_REWARD_ROUND_MS) {
     *out = which == CMDP_STAT_REWARD_FILL_MS ? h->rc_fill_ms : h->rc_round_ms;
     return CMDP_OK;
@@ -2207,23 +2215,109 @@ static int build_tiles(cmdp_t* h, int K) {
   return CMDP_OK;
 }
 
+// fixed-width rows of the K5S family (k_build_ell / build_ell_relabelled), built once per handle and width
+static int ensure_ell(cmdp_t* h, int K) {
+  hipStream_t st = h->stream;
+  if (h->ell_K != K) {
+    // CMDP_K5S_CLUSTER: tuning aid -- states per breadth-first cluster of the locality order, 0 = keep the caller's order
+    static const int cluster_env = std::getenv("CMDP_K5S_CLUSTER") ? std::atoi(std::getenv("CMDP_K5S_CLUSTER")) : -1;
+    const int cluster = cluster_env >= 0 ? cluster_env : kK5sCluster;
+    if (cluster > 0 && h->max_S >= h->relabel_min_states) {
+      if (int rc = build_ell_relabelled(h, K, cluster)) return rc;
+      h->ell_relabelled = true;
+    } else {
+      const size_t rows_p = (size_t)h->n_rows + 64 / K + 1;
+      HIP_TRY(h->d_ell_col.alloc(rows_p * K));
+      HIP_TRY(h->d_ell_val.alloc(rows_p * K));
+      hipLaunchKernelGGL(k_build_ell, dim3(grid_for((int64_t)rows_p, 256)), dim3(256), 0, st, h->n_rows, K,
+                         h->d_csr_ptr.p, h->d_csr_col.p, h->d_csr_val.p, h->d_ell_col.p, h->d_ell_val.p);
+      HIP_TRY(hipGetLastError());
+      h->ell_relabelled = false;
+    }
+    h->ell_K = K;
+  }
+  return CMDP_OK;
+}
+
 // K5S driver: targets [unit_lo, unit_hi) of the flat state space in groups of 64 consecutive targets of one instance;
 // as many groups per launch as the value-array workspace allows.
 static int diameter_lanes(cmdp_t* h, DpTables t, int64_t unit_lo, int64_t unit_hi) {
   hipStream_t st = h->stream;
   std::vector<int32_t> inst, t0, cnt;
   std::vector<int64_t> vfl;  // floats per group
+  // targets per lane: 2 on the fixed-width-row kernel (k_diam_lanes_ell_t: rows of 128 values, the row walk paid once per 128
+  // targets), 1 elsewhere; CMDP_K5S_T = 1 | 2 overrides (tuning aid)
+  static const int tpl_env = std::getenv("CMDP_K5S_T") ? std::atoi(std::getenv("CMDP_K5S_T")) : 0;
+  const int K_ell = h->max_row_nnz <= 2 ? 2 : (h->max_row_nnz <= 4 ? 4 : (h->max_row_nnz <= 8 ? 8 : 0));
+  const bool ell_ok = K_ell && h->dp_kernel != 4 && h->dp_kernel != 6 && h->A >= 2 && h->A <= 4 && h->A * K_ell <= 32;
+  const int TPL = (ell_ok && tpl_env == 2) ? 2 : 1;   // measured at C5: 2.47 s against 1.79 s -- the wider rows halve the L2 window
+  // K5C: clusters of workgroups per group (k_diam_cluster) for instances large enough for the value rows to overflow the L2s;
+  // CMDP_K5C = 0 switches it off, = CL (8 | 16 | 32) chooses the cluster size (tuning aid)
+  const int k5c_env = std::getenv("CMDP_K5C") ? std::atoi(std::getenv("CMDP_K5C")) : -1;   // read per call: the tests switch it
+  const int CLs = k5c_env > 0 ? k5c_env : 16;
+  const bool use_cluster = ell_ok && TPL == 1 && k5c_env != 0 && h->cus % (8 * CLs) == 0 && h->max_S >= h->relabel_min_states;
+  const int64_t GW = 64 * TPL;  // targets per group
   for (int b = 0; b < h->B; ++b) {
     const int64_t so = h->state_off[b], S = h->state_off[b + 1] - so;
     const int64_t lo = std::max<int64_t>(unit_lo, so) - so, hi = std::min<int64_t>(unit_hi, so + S) - so;
-    for (int64_t x = lo; x < hi; x += 64) {
+    for (int64_t x = lo; x < hi; x += GW) {
       inst.push_back(b);
       t0.push_back((int32_t)x);
-      cnt.push_back((int32_t)std::min<int64_t>(64, hi - x));
-      vfl.push_back(2 * S * 64);
+      cnt.push_back((int32_t)std::min<int64_t>(GW, hi - x));
+      vfl.push_back(2 * S * GW);
     }
   }
   const size_t G = inst.size();
+  if (use_cluster && G > 0) {
+    if (int rc = ensure_ell(h, K_ell)) return rc;
+    const int n_clusters = h->cus / CLs;
+    DiamClusterArgs ca{};
+    ca.n_groups = (int)G; ca.n_clusters = n_clusters; ca.vstride = 2 * (int64_t)h->max_S * 64;
+    const size_t vfloats = (size_t)n_clusters * (size_t)ca.vstride;
+    if (h->d_dl_v.n < vfloats) {
+      if (hipError_t e = h->d_dl_v.alloc(vfloats); e != hipSuccess)
+        return fail(CMDP_ERR_HIP, "K5C workspace of %zu bytes: %s", vfloats * sizeof(float), hipGetErrorString(e));
+    }
+    HIP_TRY(h->d_k5c_red.alloc((size_t)n_clusters * 2 * CLs * 2 * 64));
+    HIP_TRY(h->d_k5c_bar.alloc((size_t)n_clusters + 1 + (size_t)n_clusters * CLs));
+    HIP_TRY(h->d_dl_inst.upload(inst.data(), G, st));
+    HIP_TRY(h->d_dl_t0.upload(t0.data(), G, st));
+    HIP_TRY(h->d_dl_cnt.upload(cnt.data(), G, st));
+    ca.cred = h->d_k5c_red.p; ca.cbar = h->d_k5c_bar.p; ca.err = reinterpret_cast<int*>(h->d_k5c_bar.p + n_clusters);
+    ca.xcc = ca.err + 1;
+    // 2 s of the 100 MHz wall clock; CMDP_K5C_TIMEOUT_TICKS overrides (the test-suite sets 1 to drive the fall-back to K5S)
+    ca.timeout_ticks = std::getenv("CMDP_K5C_TIMEOUT_TICKS") ? std::atoll(std::getenv("CMDP_K5C_TIMEOUT_TICKS")) : 200000000LL;
+    DiamLanesArgs g{h->d_dl_inst.p, h->d_dl_t0.p, h->d_dl_cnt.p, nullptr, h->d_dl_v.p};
+    const int32_t* new_of = h->ell_relabelled ? h->d_ell_newof.p : nullptr;
+    const int A = h->A, K = K_ell;
+    const unsigned grid = (unsigned)(n_clusters * CLs);
+    // first with the XCD-scope barriers (the members verify that they share an XCD); a cluster spread over XCDs makes the
+    // launch end with err = 2 and it is repeated with agent-scope barriers; CMDP_K5C_SCOPE = agent skips the first form
+    static const bool agent_env = std::getenv("CMDP_K5C_SCOPE") && !std::strcmp(std::getenv("CMDP_K5C_SCOPE"), "agent");
+    for (int pass = (agent_env || h->k5c_agent_scope) ? 1 : 0; pass < 2; ++pass) {
+      HIP_TRY(h->d_k5c_bar.zero(st));   // counters, error flag, XCC ids
+      bool launched = true;
+#define K5C_CASE(CLT, AT, KT)                                                                                       \
+  if (CLs == CLT && A == AT && K == KT) {                                                                           \
+    if (pass == 0) hipLaunchKernelGGL((k_diam_cluster<CLT, AT, KT, true>), dim3(grid), dim3(1024), 0, st, t, g, ca, h->d_ell_col.p, h->d_ell_val.p, new_of); \
+    else hipLaunchKernelGGL((k_diam_cluster<CLT, AT, KT, false>), dim3(grid), dim3(1024), 0, st, t, g, ca, h->d_ell_col.p, h->d_ell_val.p, new_of); \
+  } else
+#define K5C_SHAPES(CLT) K5C_CASE(CLT, 2, 2) K5C_CASE(CLT, 2, 4) K5C_CASE(CLT, 2, 8) K5C_CASE(CLT, 3, 2) K5C_CASE(CLT, 3, 4) \
+                        K5C_CASE(CLT, 3, 8) K5C_CASE(CLT, 4, 2) K5C_CASE(CLT, 4, 4) K5C_CASE(CLT, 4, 8)
+      K5C_SHAPES(8) K5C_SHAPES(16) K5C_SHAPES(32) { launched = false; }
+#undef K5C_SHAPES
+#undef K5C_CASE
+      if (!launched) break;
+      HIP_TRY(hipGetLastError());
+      int err = 0;
+      HIP_TRY(hipMemcpyAsync(&err, ca.err, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (!err) { h->k5c_launches++; return CMDP_OK; }
+      if (err == 2 && pass == 0) { h->k5c_agent_scope = true; continue; }   // this device does not deal workgroups as assumed
+      h->k5c_timeouts++;   // a cluster's workgroups were not all resident: the groups are solved again, one workgroup each
+      break;
+    }
+  }
   // the workspace is also bounded by what the device has free right now (other handles / ranks sharing the GPU):
   // 80 % of the free bytes plus what this handle already holds for the purpose; fewer groups per launch, same results
   size_t ws_cap = h->dl_ws_bytes;
@@ -2282,24 +2376,7 @@ static int diameter_lanes(cmdp_t* h, DpTables t, int64_t unit_lo, int64_t unit_h
     if (tiles) {
       ell = true;  // handled
     } else if (K && h->dp_kernel != 4 && A >= 2 && A <= 4 && A * K <= 32) {
-      if (h->ell_K != K) {
-        // CMDP_K5S_CLUSTER: tuning aid -- states per breadth-first cluster of the locality order, 0 = keep the caller's order
-        static const int cluster_env = std::getenv("CMDP_K5S_CLUSTER") ? std::atoi(std::getenv("CMDP_K5S_CLUSTER")) : -1;
-        const int cluster = cluster_env >= 0 ? cluster_env : kK5sCluster;
-        if (cluster > 0 && h->max_S >= h->relabel_min_states) {
-          if (int rc = build_ell_relabelled(h, K, cluster)) return rc;
-          h->ell_relabelled = true;
-        } else {
-          const size_t rows_p = (size_t)h->n_rows + 64 / K + 1;
-          HIP_TRY(h->d_ell_col.alloc(rows_p * K));
-          HIP_TRY(h->d_ell_val.alloc(rows_p * K));
-          hipLaunchKernelGGL(k_build_ell, dim3(grid_for((int64_t)rows_p, 256)), dim3(256), 0, st, h->n_rows, K,
-                             h->d_csr_ptr.p, h->d_csr_col.p, h->d_csr_val.p, h->d_ell_col.p, h->d_ell_val.p);
-          HIP_TRY(hipGetLastError());
-          h->ell_relabelled = false;
-        }
-        h->ell_K = K;
-      }
+      if (int rc = ensure_ell(h, K)) return rc;
       const int32_t* new_of = h->ell_relabelled ? h->d_ell_newof.p : nullptr;
       ell = true;
       // wavefronts per group: 8 fill the chip when there are at least two groups per CU; with fewer groups than CUs (a
@@ -2309,7 +2386,14 @@ static int diameter_lanes(cmdp_t* h, DpTables t, int64_t unit_lo, int64_t unit_h
       // wants it -- C5 1.83 -> 1.75 s)
       const int k5s_nw = k5s_env ? k5s_env : (((int64_t)n <= (int64_t)h->cus || h->ell_relabelled) ? 16 : 8);
 #define ELL_CASE(AT, KT)                                                                                          \
-  if (A == AT && K == KT) {                                                                                       \
+  if (A == AT && K == KT && TPL == 2) {                                                                           \
+    if (k5s_nw == 16)                                                                                             \
+      hipLaunchKernelGGL((k_diam_lanes_ell_t<16, AT, KT, 2>), dim3((unsigned)n), dim3(1024), 0, st, t, g, \
+                         h->d_ell_col.p, h->d_ell_val.p, new_of);                                                 \
+    else                                                                                                          \
+      hipLaunchKernelGGL((k_diam_lanes_ell_t<8, AT, KT, 2>), dim3((unsigned)n), dim3(512), 0, st, t, g, \
+                         h->d_ell_col.p, h->d_ell_val.p, new_of);                                                 \
+  } else if (A == AT && K == KT) {                                                                                \
     if (k5s_nw == 16)                                                                                             \
       hipLaunchKernelGGL((k_diam_lanes_ell<16, AT, KT>), dim3((unsigned)n), dim3(1024), 0, st, t, g, \
                          h->d_ell_col.p, h->d_ell_val.p, new_of);                                                 \

@@ -2532,6 +2532,361 @@ __global__ void __launch_bounds__(NW * 64) k_diam_lanes_ell(DpTables t, DiamLane
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// K5C (round 3): K5S with a CLUSTER of CL workgroups per group of 64 targets.  K5S keeps one group per CU: thirty-two groups
+// per XCD stream 13 MB of value rows each (S = 50 272) through a 4 MB L2, and the rows are re-read 2.3 times.  Here the CL
+// workgroups of a cluster sit on the same XCD (workgroups are dealt to the XCDs round-robin, so the members are blockIdx
+// = xcd + 8 * (CL * c + m)), share one pair of value arrays and split every sweep between them: 32 / CL streams per L2
+// instead of 32, each with CL times the window.  Per sweep the members meet at ONE barrier (a monotone counter per cluster
+// in HBM, release / acquire at agent scope; every member then reduces the same CL partial (max |dV|, min V) rows in the
+// same order, so all of them take the same decisions and execute the same number of barriers).  The launch is persistent:
+// n_clusters * CL workgroups, cluster q solves groups q, q + n_clusters, ...  Arithmetic per target = K5S's, term for term.
+// The barrier spins with a wall-clock limit: if the members of a cluster are not all resident (CUs held by another
+// kernel), every workgroup leaves through the same exit with `*err` set and the host repeats the launch on K5S.
+// ---------------------------------------------------------------------------------------------------------------
+// tuning switch of the K5C kernels: the new value rows written with nontemporal stores (they are not read again before the
+// next sweep, by which time they have left the L2 anyway)
+#ifndef CMDP_K5C_NT_STORE
+#define CMDP_K5C_NT_STORE 1
+#endif
+constexpr bool NT_STORE = CMDP_K5C_NT_STORE != 0;
+
+struct DiamClusterArgs {
+  int n_groups, n_clusters;
+  int64_t vstride;            // floats per cluster (two value arrays of the largest instance)
+  float* cred;                // [n_clusters][2][CL][2][64] partial reductions
+  unsigned int* cbar;         // [n_clusters] barrier counters (zero at launch)
+  int* err;                   // 1: a barrier timed out; 2: a cluster's workgroups are not on one XCD
+  int* xcc;                   // [n_clusters][CL] XCC id of every member (XCD-scope barriers only)
+  long long timeout_ticks;    // wall_clock64 ticks (100 MHz)
+};
+
+// XCD = true: the members have verified (HW_REG_XCC_ID) that they share an XCD, i.e. one L2.  Stores are complete when
+// the L2 has acknowledged them (the vector L1 is write-through), so the release is a wait for the outstanding stores and the
+// acquire only drops the wave's L1 lines (`buffer_inv sc0`); the agent-scope pair would write the whole L2 back and
+// invalidate it once per sweep.
+template <int CL, bool XCD>
+__device__ __forceinline__ bool cluster_barrier(unsigned int* bar, unsigned int& epoch, int* err, long long timeout_ticks) {
+  // all stores of this workgroup (value rows, partials) before the arrival; the workgroup's arrival is one atomic
+  if (XCD) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  ++epoch;
+  __shared__ int ok_s;
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int want = epoch * (unsigned int)CL;
+    const long long t0 = (long long)wall_clock64();
+    int ok = 1;
+    while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+      if ((long long)wall_clock64() - t0 > timeout_ticks) {
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    ok_s = ok;
+  }
+  __syncthreads();
+  if (XCD) asm volatile("buffer_inv sc0" ::: "memory");
+  else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return ok_s != 0;
+}
+
+template <int CL, int A, int K, bool XCD>
+__global__ void __launch_bounds__(1024) k_diam_cluster(DpTables t, DiamLanesArgs g, DiamClusterArgs ca, const int32_t* __restrict__ ecol,
+                                                      const float* __restrict__ eval_, const int32_t* __restrict__ new_of) {
+  constexpr int NW = 16, AK = A * K, U = 64 / AK, XCDS = 8;
+  static_assert(U >= 1, "A*K must not exceed 64");
+  __shared__ float red_d[NW][64];
+  __shared__ float red_m[NW][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int xcd = blockIdx.x % XCDS, idx = blockIdx.x / XCDS;
+  const int member = idx % CL;
+  const int cluster = xcd + XCDS * (idx / CL);
+  if (cluster >= ca.n_clusters) return;
+  unsigned int* bar = ca.cbar + cluster;
+  float* cred = ca.cred + (int64_t)cluster * 2 * CL * 2 * 64;
+  float* vbase = g.vbuf + (int64_t)cluster * ca.vstride;
+  unsigned int epoch = 0;
+  unsigned int sweep_no = 0;   // parity of the partial rows: continues across the cluster's groups
+  if (XCD) {
+    // the cheap barrier is only right if the members really share an L2: every member publishes its XCC id, all compare
+    // after one agent-scope barrier, and a cluster that is spread over XCDs reports it (the host repeats the launch with
+    // agent-scope barriers)
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;   // HW_REG_XCC_ID[3:0]
+    if (threadIdx.x == 0) __hip_atomic_store(ca.xcc + (int64_t)cluster * CL + member, (int)xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!cluster_barrier<CL, false>(bar, epoch, ca.err, ca.timeout_ticks)) return;
+    bool same = true;
+    for (int m = 0; m < CL; ++m)
+      same = same && __hip_atomic_load(ca.xcc + (int64_t)cluster * CL + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)xcc;
+    if (!same) {
+      if (threadIdx.x == 0) __hip_atomic_store(ca.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
+  constexpr int CW = CL * NW;  // wavefronts of the cluster
+  const int cw = member * NW + wave;
+
+  for (int grp = cluster; grp < ca.n_groups; grp += ca.n_clusters) {
+    const int b = g.grp_inst[grp];
+    const int64_t soff = t.state_off[b];
+    const int S = (int)(t.state_off[b + 1] - soff);
+    const int32_t* ec = ecol + soff * AK;
+    const float* ev = eval_ + soff * AK;
+    const int target = g.grp_target0[grp] + lane;
+    const bool active = lane < g.grp_count[grp];
+    const int target_row = (new_of && active) ? new_of[soff + target] : target;
+    float* Vold = vbase;
+    float* Vnew = vbase + (int64_t)S * 64;
+    // zero both arrays, the members' slices interleaved
+    for (int64_t i = (int64_t)member * 1024 + threadIdx.x; i < (int64_t)S * 128; i += (int64_t)CL * 1024) Vold[i] = 0.0f;
+    if (!cluster_barrier<CL, XCD>(bar, epoch, ca.err, ca.timeout_ticks)) return;
+
+    const int s_begin = cw * U;
+    constexpr int STRIDE = CW * U;
+    bool done = !active;
+    float result = 0.0f;
+    int status = active ? -5 : 0;
+    int64_t it = 0;
+    while (it < t.max_sweeps) {
+      ++it;
+      float dmax = 0.0f, vmin = 3.0e38f;
+      if (s_begin < S) {
+        const int sl = lane / AK;
+        int ccol = (s_begin + sl < S) ? ec[(int64_t)s_begin * AK + lane] : 0;
+        float cval = ev[(int64_t)s_begin * AK + lane];
+        for (int s0 = s_begin; s0 < S; s0 += STRIDE) {
+          const int sn = (s0 + STRIDE < S) ? s0 + STRIDE : s0;
+          const int ncol = (sn + sl < S) ? ec[(int64_t)sn * AK + lane] : 0;
+          const float nval = ev[(int64_t)sn * AK + lane];
+          float x[U * AK], vo[U];
+#pragma unroll
+          for (int e = 0; e < U * AK; ++e) {
+            const int c = __builtin_amdgcn_readlane(ccol, e);
+            x[e] = Vold[(int64_t)c * 64 + lane];
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int s = (s0 + u < S) ? s0 + u : s0;
+            vo[u] = Vold[(int64_t)s * 64 + lane];
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int s = s0 + u;
+            if (s < S) {
+              float v = 0.0f;
+#pragma unroll
+              for (int a = 0; a < A; ++a) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                  const int e = (u * A + a) * K + k;
+                  const float coef = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cval), e));
+                  acc = __fadd_rn(acc, __fmul_rn(coef, x[e]));
+                }
+                const float q = __fadd_rn(-1.0f, __fmul_rn(t.gamma, acc));
+                v = (a == 0) ? q : fmaxf(v, q);
+              }
+              if (s == target_row) v = __fadd_rn(0.0f, __fmul_rn(t.gamma, __fadd_rn(0.0f, __fmul_rn(1.0f, vo[u]))));
+              if (NT_STORE) __builtin_nontemporal_store(v, Vnew + (int64_t)s * 64 + lane); else Vnew[(int64_t)s * 64 + lane] = v;
+              dmax = fmaxf(dmax, fabsf(vo[u] - v));
+              vmin = fminf(vmin, v);
+            }
+          }
+          ccol = ncol;
+          cval = nval;
+        }
+      }
+      // the workgroup's partial row, then the cluster's
+      red_d[wave][lane] = dmax;
+      red_m[wave][lane] = vmin;
+      __syncthreads();
+      const int par = (int)(sweep_no & 1u);
+      ++sweep_no;
+      if (wave == 0) {
+        float d = 0.0f, m = 3.0e38f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          d = fmaxf(d, red_d[w][lane]);
+          m = fminf(m, red_m[w][lane]);
+        }
+        float* row = cred + ((int64_t)(par * CL + member) * 2) * 64;
+        row[lane] = d;
+        row[64 + lane] = m;
+      }
+      if (!cluster_barrier<CL, XCD>(bar, epoch, ca.err, ca.timeout_ticks)) return;
+      float diff = 0.0f, mn = 3.0e38f;
+#pragma unroll
+      for (int m = 0; m < CL; ++m) {
+        const float* row = cred + ((int64_t)(par * CL + m) * 2) * 64;
+        diff = fmaxf(diff, __builtin_nontemporal_load(row + lane));
+        mn = fminf(mn, __builtin_nontemporal_load(row + 64 + lane));
+      }
+      float* tmp = Vold; Vold = Vnew; Vnew = tmp;
+      if (!done && (double)diff < t.eps) {
+        done = true;
+        result = -mn;
+        status = 0;
+      }
+      if (__all(done)) break;
+    }
+    if (member == 0 && wave == 0 && active) {
+      t.per_target[soff + target] = result;
+      t.status[soff + target] = status;
+    }
+  }
+}
+
+// K5S with T targets per lane (round 3).  The value rows become 64 * T floats wide -- `V[state][lane * T + j]`, one
+// `global_load_dwordx2` per lane and gather for T = 2 -- so the walk over the fixed-width rows, the `v_readlane` broadcasts
+// and the address arithmetic are paid once per 128 targets instead of once per 64, and the memory pipeline moves 512-byte rows.
+// Arithmetic per target is the T = 1 kernel's, term for term (same products, same order): bit-equal results.  The U states
+// of a chunk are consumed in sub-batches of UB states (UB * A * K * T gathered values in registers at a time).
+template <int NW, int A, int K, int T>
+__global__ void __launch_bounds__(NW * 64) k_diam_lanes_ell_t(DpTables t, DiamLanesArgs g, const int32_t* __restrict__ ecol,
+                                                             const float* __restrict__ eval_, const int32_t* __restrict__ new_of) {
+  constexpr int AK = A * K, U = 64 / AK, W = 64 * T;
+  constexpr int UB = (32 / AK) >= 1 ? ((32 / AK) < U ? (32 / AK) : U) : 1;
+  static_assert(U >= 1, "A*K must not exceed 64");
+  typedef float vecT __attribute__((ext_vector_type(T)));
+  __shared__ float red_d[2][NW][W];
+  __shared__ float red_m[2][NW][W];
+  const int grp = blockIdx.x;
+  const int b = g.grp_inst[grp];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t soff = t.state_off[b];
+  const int S = (int)(t.state_off[b + 1] - soff);
+  const int32_t* ec = ecol + soff * AK;
+  const float* ev = eval_ + soff * AK;
+  int target[T], target_row[T];
+  bool active[T], done[T];
+  float result[T];
+  int status[T];
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    target[j] = g.grp_target0[grp] + lane * T + j;
+    active[j] = lane * T + j < g.grp_count[grp];
+    target_row[j] = (new_of && active[j]) ? new_of[soff + target[j]] : (active[j] ? target[j] : -1);
+    done[j] = !active[j];
+    result[j] = 0.0f;
+    status[j] = active[j] ? -5 : 0;
+  }
+  float* Vold = g.vbuf + g.grp_voff[grp];
+  float* Vnew = Vold + (int64_t)S * W;
+  for (int64_t i = threadIdx.x; i < (int64_t)S * W * 2; i += NW * 64) Vold[i] = 0.0f;
+  __syncthreads();
+  const int s_begin = wave * U;
+  const int s_end = S;
+  constexpr int STRIDE = NW * U;
+
+  int64_t it = 0;
+  while (it < t.max_sweeps) {
+    ++it;
+    float dmax[T], vmin[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) { dmax[j] = 0.0f; vmin[j] = 3.0e38f; }
+    if (s_begin < s_end) {
+      const int sl = lane / AK;
+      int ccol = (s_begin + sl < S) ? ec[(int64_t)s_begin * AK + lane] : 0;
+      float cval = ev[(int64_t)s_begin * AK + lane];
+      for (int s0 = s_begin; s0 < s_end; s0 += STRIDE) {
+        const int sn = (s0 + STRIDE < s_end) ? s0 + STRIDE : s0;
+        const int ncol = (sn + sl < S) ? ec[(int64_t)sn * AK + lane] : 0;
+        const float nval = ev[(int64_t)sn * AK + lane];
+#pragma unroll
+        for (int u0 = 0; u0 < U; u0 += UB) {
+          vecT x[UB * AK], vo[UB];
+#pragma unroll
+          for (int e = 0; e < UB * AK; ++e) {
+            const int ee = u0 * AK + e;
+            if (ee < U * AK) {
+              const int c = __builtin_amdgcn_readlane(ccol, ee);
+              x[e] = *reinterpret_cast<const vecT*>(Vold + (int64_t)c * W + lane * T);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            const int s = (u0 + u < U && s0 + u0 + u < s_end) ? s0 + u0 + u : s0;
+            vo[u] = *reinterpret_cast<const vecT*>(Vold + (int64_t)s * W + lane * T);
+          }
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            const int s = s0 + u0 + u;
+            if (u0 + u < U && s < s_end) {
+              vecT v;
+#pragma unroll
+              for (int a = 0; a < A; ++a) {
+                vecT acc;
+#pragma unroll
+                for (int j = 0; j < T; ++j) acc[j] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                  const int e = (u * A + a) * K + k;
+                  const float coef = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cval), u0 * AK + e));
+#pragma unroll
+                  for (int j = 0; j < T; ++j) acc[j] = __fadd_rn(acc[j], __fmul_rn(coef, x[e][j]));
+                }
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                  const float q = __fadd_rn(-1.0f, __fmul_rn(t.gamma, acc[j]));
+                  v[j] = (a == 0) ? q : fmaxf(v[j], q);
+                }
+              }
+#pragma unroll
+              for (int j = 0; j < T; ++j) {
+                if (s == target_row[j]) v[j] = __fadd_rn(0.0f, __fmul_rn(t.gamma, __fadd_rn(0.0f, __fmul_rn(1.0f, vo[u][j]))));
+                dmax[j] = fmaxf(dmax[j], fabsf(vo[u][j] - v[j]));
+                vmin[j] = fminf(vmin[j], v[j]);
+              }
+              *reinterpret_cast<vecT*>(Vnew + (int64_t)s * W + lane * T) = v;
+            }
+          }
+        }
+        ccol = ncol;
+        cval = nval;
+      }
+    }
+    const int par = (int)(it & 1);
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      red_d[par][wave][lane * T + j] = dmax[j];
+      red_m[par][wave][lane * T + j] = vmin[j];
+    }
+    __syncthreads();
+    float* tmp = Vold; Vold = Vnew; Vnew = tmp;
+    bool all_done = true;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      float diff = 0.0f, mn = 3.0e38f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        diff = fmaxf(diff, red_d[par][w][lane * T + j]);
+        mn = fminf(mn, red_m[par][w][lane * T + j]);
+      }
+      if (!done[j] && (double)diff < t.eps) {
+        done[j] = true;
+        result[j] = -mn;
+        status[j] = 0;
+      }
+      all_done = all_done && done[j];
+    }
+    if (__all(all_done)) break;
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < T; ++j)
+      if (active[j]) {
+        t.per_target[soff + target[j]] = result[j];
+        t.status[soff + target[j]] = status[j];
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Calibration of the rollout kernels' latency floor (cmdp_calibrate; no reference counterpart): one wavefront per
 // workgroup, every lane follows its own uint16 successor table in LDS for `steps` DEPENDENT reads.
 //   CHAIN = 0: ds_read_u16 -> mask -> address, nothing else (the bare dependent LDS read);

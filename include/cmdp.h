@@ -218,7 +218,11 @@ enum { CMDP_STAT_DP_KERNEL_MS = 1, CMDP_STAT_DP_KERNEL = 2,
        CMDP_STAT_REWARD_FILL_MS = 8,   /* CMDP_FLAG_REWARD_CACHE: host wall time spent drawing blocks (all host threads together
                                           count once: the time the calling thread waited for the draws)                       */
        CMDP_STAT_REWARD_ROUND_MS = 9   /* ... and wall time of the park rounds as a whole: copy of the park list, draws, install,
-                                          up to the relaunch                                                                  */ };
+                                          up to the relaunch                                                                  */,
+       CMDP_STAT_DIAMETER_CLUSTER_LAUNCHES = 10,  /* diameter solves of this handle that ran on K5C (clusters of workgroups per
+                                                     group of 64 targets, k_diam_cluster)                                     */
+       CMDP_STAT_DIAMETER_CLUSTER_FALLBACKS = 11  /* ... and K5C launches given up because a cluster's workgroups were not all
+                                                     resident within the time limit (the targets were then solved by K5S)      */ };
 int cmdp_stat(cmdp_t* h, int which, double* out);
 /* Latency floor of the LDS-resident rollout kernels, measured on the current device: one wavefront per CU follows
    per-lane uint16 tables in LDS for n_steps dependent reads.  CMDP_CALIB_LDS_READ: the bare dependent ds_read_u16

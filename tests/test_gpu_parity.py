@@ -693,10 +693,27 @@ def test_diameter_lanes_kernel_equals_workgroup_kernel_and_oracle(need_gpu):
         np.testing.assert_array_equal(per1, per0)
         np.testing.assert_array_equal(diam1, diam0)
         dp.set_option(L.OPT_DIAMETER_RELABEL_MIN_STATES, 1)  # rows stored in the locality order of the states (C5's default)
-        diam2, per2 = dp.diameter(1e-3, L.SCHEME_JACOBI)
-        np.testing.assert_array_equal(per2, per0)
-        np.testing.assert_array_equal(diam2, diam0)
-        np.testing.assert_array_equal(dp.diameter_range(3, len(per0) - 2), per0[3:-2])  # a target range (the multi-GPU split)
+        # ... which is also where K5C takes over (clusters of workgroups per target group, one barrier per sweep); then K5S
+        # alone (CMDP_K5C=0), then K5C with a barrier time limit of one tick: every cluster gives up and K5S repeats the solve
+        import ctypes
+        import os
+
+        def stat(which):
+            v = ctypes.c_double()
+            L.check(L.load().cmdp_stat(dp.handle, which, ctypes.byref(v)))
+            return int(v.value)
+
+        for env, launches, fallbacks in (({}, 2, 0), ({"CMDP_K5C": "0"}, 2, 0), ({"CMDP_K5C_TIMEOUT_TICKS": "1"}, 2, 2)):
+            os.environ.update(env)
+            try:
+                diam2, per2 = dp.diameter(1e-3, L.SCHEME_JACOBI)
+                np.testing.assert_array_equal(per2, per0)
+                np.testing.assert_array_equal(diam2, diam0)
+                np.testing.assert_array_equal(dp.diameter_range(3, len(per0) - 2), per0[3:-2])  # a target range (the multi-GPU split)
+            finally:
+                for k in env:
+                    os.environ.pop(k)
+            assert (stat(L.STAT_DIAMETER_CLUSTER_LAUNCHES), stat(L.STAT_DIAMETER_CLUSTER_FALLBACKS)) == (launches, fallbacks), env
         dp.set_option(L.OPT_DIAMETER_RELABEL_MIN_STATES, 1 << 40)
         dp.set_option(L.OPT_DP_KERNEL, 4)  # generic CSR walker instead of the fixed-width-row variant
         np.testing.assert_array_equal(dp.diameter(1e-3, L.SCHEME_JACOBI)[1], per0)
