@@ -2245,18 +2245,16 @@ static int diameter_lanes(cmdp_t* h, DpTables t, int64_t unit_lo, int64_t unit_h
   hipStream_t st = h->stream;
   std::vector<int32_t> inst, t0, cnt;
   std::vector<int64_t> vfl;  // floats per group
-  // targets per lane: 2 on the fixed-width-row kernel (k_diam_lanes_ell_t: rows of 128 values, the row walk paid once per 128
-  // targets), 1 elsewhere; CMDP_K5S_T = 1 | 2 overrides (tuning aid)
-  static const int tpl_env = std::getenv("CMDP_K5S_T") ? std::atoi(std::getenv("CMDP_K5S_T")) : 0;
   const int K_ell = h->max_row_nnz <= 2 ? 2 : (h->max_row_nnz <= 4 ? 4 : (h->max_row_nnz <= 8 ? 8 : 0));
   const bool ell_ok = K_ell && h->dp_kernel != 4 && h->dp_kernel != 6 && h->A >= 2 && h->A <= 4 && h->A * K_ell <= 32;
-  const int TPL = (ell_ok && tpl_env == 2) ? 2 : 1;   // measured at C5: 2.47 s against 1.79 s -- the wider rows halve the L2 window
+  // (two targets per lane -- value rows of 128 floats, the row walk paid once per 128 targets -- measured 2.47 s against
+  // 1.79 s at C5: the wider rows halve every group's window in L2; not kept)
   // K5C: clusters of workgroups per group (k_diam_cluster) for instances large enough for the value rows to overflow the L2s;
   // CMDP_K5C = 0 switches it off, = CL (8 | 16 | 32) chooses the cluster size (tuning aid)
   const int k5c_env = std::getenv("CMDP_K5C") ? std::atoi(std::getenv("CMDP_K5C")) : -1;   // read per call: the tests switch it
   const int CLs = k5c_env > 0 ? k5c_env : 16;
-  const bool use_cluster = ell_ok && TPL == 1 && k5c_env != 0 && h->cus % (8 * CLs) == 0 && h->max_S >= h->relabel_min_states;
-  const int64_t GW = 64 * TPL;  // targets per group
+  const bool use_cluster = ell_ok && k5c_env != 0 && h->cus % (8 * CLs) == 0 && h->max_S >= h->relabel_min_states;
+  const int64_t GW = 64;  // targets per group
   for (int b = 0; b < h->B; ++b) {
     const int64_t so = h->state_off[b], S = h->state_off[b + 1] - so;
     const int64_t lo = std::max<int64_t>(unit_lo, so) - so, hi = std::min<int64_t>(unit_hi, so + S) - so;
@@ -2386,14 +2384,7 @@ static int diameter_lanes(cmdp_t* h, DpTables t, int64_t unit_lo, int64_t unit_h
       // wants it -- C5 1.83 -> 1.75 s)
       const int k5s_nw = k5s_env ? k5s_env : (((int64_t)n <= (int64_t)h->cus || h->ell_relabelled) ? 16 : 8);
 #define ELL_CASE(AT, KT)                                                                                          \
-  if (A == AT && K == KT && TPL == 2) {                                                                           \
-    if (k5s_nw == 16)                                                                                             \
-      hipLaunchKernelGGL((k_diam_lanes_ell_t<16, AT, KT, 2>), dim3((unsigned)n), dim3(1024), 0, st, t, g, \
-                         h->d_ell_col.p, h->d_ell_val.p, new_of);                                                 \
-    else                                                                                                          \
-      hipLaunchKernelGGL((k_diam_lanes_ell_t<8, AT, KT, 2>), dim3((unsigned)n), dim3(512), 0, st, t, g, \
-                         h->d_ell_col.p, h->d_ell_val.p, new_of);                                                 \
-  } else if (A == AT && K == KT) {                                                                                \
+  if (A == AT && K == KT) {                                                                                       \
     if (k5s_nw == 16)                                                                                             \
       hipLaunchKernelGGL((k_diam_lanes_ell<16, AT, KT>), dim3((unsigned)n), dim3(1024), 0, st, t, g, \
                          h->d_ell_col.p, h->d_ell_val.p, new_of);                                                 \

@@ -2740,152 +2740,6 @@ __global__ void __launch_bounds__(1024) k_diam_cluster(DpTables t, DiamLanesArgs
   }
 }
 
-// K5S with T targets per lane (round 3).  The value rows become 64 * T floats wide -- `V[state][lane * T + j]`, one
-// `global_load_dwordx2` per lane and gather for T = 2 -- so the walk over the fixed-width rows, the `v_readlane` broadcasts
-// and the address arithmetic are paid once per 128 targets instead of once per 64, and the memory pipeline moves 512-byte rows.
-// Arithmetic per target is the T = 1 kernel's, term for term (same products, same order): bit-equal results.  The U states
-// of a chunk are consumed in sub-batches of UB states (UB * A * K * T gathered values in registers at a time).
-template <int NW, int A, int K, int T>
-__global__ void __launch_bounds__(NW * 64) k_diam_lanes_ell_t(DpTables t, DiamLanesArgs g, const int32_t* __restrict__ ecol,
-                                                             const float* __restrict__ eval_, const int32_t* __restrict__ new_of) {
-  constexpr int AK = A * K, U = 64 / AK, W = 64 * T;
-  constexpr int UB = (32 / AK) >= 1 ? ((32 / AK) < U ? (32 / AK) : U) : 1;
-  static_assert(U >= 1, "A*K must not exceed 64");
-  typedef float vecT __attribute__((ext_vector_type(T)));
-  __shared__ float red_d[2][NW][W];
-  __shared__ float red_m[2][NW][W];
-  const int grp = blockIdx.x;
-  const int b = g.grp_inst[grp];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t soff = t.state_off[b];
-  const int S = (int)(t.state_off[b + 1] - soff);
-  const int32_t* ec = ecol + soff * AK;
-  const float* ev = eval_ + soff * AK;
-  int target[T], target_row[T];
-  bool active[T], done[T];
-  float result[T];
-  int status[T];
-#pragma unroll
-  for (int j = 0; j < T; ++j) {
-    target[j] = g.grp_target0[grp] + lane * T + j;
-    active[j] = lane * T + j < g.grp_count[grp];
-    target_row[j] = (new_of && active[j]) ? new_of[soff + target[j]] : (active[j] ? target[j] : -1);
-    done[j] = !active[j];
-    result[j] = 0.0f;
-    status[j] = active[j] ? -5 : 0;
-  }
-  float* Vold = g.vbuf + g.grp_voff[grp];
-  float* Vnew = Vold + (int64_t)S * W;
-  for (int64_t i = threadIdx.x; i < (int64_t)S * W * 2; i += NW * 64) Vold[i] = 0.0f;
-  __syncthreads();
-  const int s_begin = wave * U;
-  const int s_end = S;
-  constexpr int STRIDE = NW * U;
-
-  int64_t it = 0;
-  while (it < t.max_sweeps) {
-    ++it;
-    float dmax[T], vmin[T];
-#pragma unroll
-    for (int j = 0; j < T; ++j) { dmax[j] = 0.0f; vmin[j] = 3.0e38f; }
-    if (s_begin < s_end) {
-      const int sl = lane / AK;
-      int ccol = (s_begin + sl < S) ? ec[(int64_t)s_begin * AK + lane] : 0;
-      float cval = ev[(int64_t)s_begin * AK + lane];
-      for (int s0 = s_begin; s0 < s_end; s0 += STRIDE) {
-        const int sn = (s0 + STRIDE < s_end) ? s0 + STRIDE : s0;
-        const int ncol = (sn + sl < S) ? ec[(int64_t)sn * AK + lane] : 0;
-        const float nval = ev[(int64_t)sn * AK + lane];
-#pragma unroll
-        for (int u0 = 0; u0 < U; u0 += UB) {
-          vecT x[UB * AK], vo[UB];
-#pragma unroll
-          for (int e = 0; e < UB * AK; ++e) {
-            const int ee = u0 * AK + e;
-            if (ee < U * AK) {
-              const int c = __builtin_amdgcn_readlane(ccol, ee);
-              x[e] = *reinterpret_cast<const vecT*>(Vold + (int64_t)c * W + lane * T);
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < UB; ++u) {
-            const int s = (u0 + u < U && s0 + u0 + u < s_end) ? s0 + u0 + u : s0;
-            vo[u] = *reinterpret_cast<const vecT*>(Vold + (int64_t)s * W + lane * T);
-          }
-#pragma unroll
-          for (int u = 0; u < UB; ++u) {
-            const int s = s0 + u0 + u;
-            if (u0 + u < U && s < s_end) {
-              vecT v;
-#pragma unroll
-              for (int a = 0; a < A; ++a) {
-                vecT acc;
-#pragma unroll
-                for (int j = 0; j < T; ++j) acc[j] = 0.0f;
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                  const int e = (u * A + a) * K + k;
-                  const float coef = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cval), u0 * AK + e));
-#pragma unroll
-                  for (int j = 0; j < T; ++j) acc[j] = __fadd_rn(acc[j], __fmul_rn(coef, x[e][j]));
-                }
-#pragma unroll
-                for (int j = 0; j < T; ++j) {
-                  const float q = __fadd_rn(-1.0f, __fmul_rn(t.gamma, acc[j]));
-                  v[j] = (a == 0) ? q : fmaxf(v[j], q);
-                }
-              }
-#pragma unroll
-              for (int j = 0; j < T; ++j) {
-                if (s == target_row[j]) v[j] = __fadd_rn(0.0f, __fmul_rn(t.gamma, __fadd_rn(0.0f, __fmul_rn(1.0f, vo[u][j]))));
-                dmax[j] = fmaxf(dmax[j], fabsf(vo[u][j] - v[j]));
-                vmin[j] = fminf(vmin[j], v[j]);
-              }
-              *reinterpret_cast<vecT*>(Vnew + (int64_t)s * W + lane * T) = v;
-            }
-          }
-        }
-        ccol = ncol;
-        cval = nval;
-      }
-    }
-    const int par = (int)(it & 1);
-#pragma unroll
-    for (int j = 0; j < T; ++j) {
-      red_d[par][wave][lane * T + j] = dmax[j];
-      red_m[par][wave][lane * T + j] = vmin[j];
-    }
-    __syncthreads();
-    float* tmp = Vold; Vold = Vnew; Vnew = tmp;
-    bool all_done = true;
-#pragma unroll
-    for (int j = 0; j < T; ++j) {
-      float diff = 0.0f, mn = 3.0e38f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        diff = fmaxf(diff, red_d[par][w][lane * T + j]);
-        mn = fminf(mn, red_m[par][w][lane * T + j]);
-      }
-      if (!done[j] && (double)diff < t.eps) {
-        done[j] = true;
-        result[j] = -mn;
-        status[j] = 0;
-      }
-      all_done = all_done && done[j];
-    }
-    if (__all(all_done)) break;
-  }
-  if (wave == 0) {
-#pragma unroll
-    for (int j = 0; j < T; ++j)
-      if (active[j]) {
-        t.per_target[soff + target[j]] = result[j];
-        t.status[soff + target[j]] = status[j];
-      }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Calibration of the rollout kernels' latency floor (cmdp_calibrate; no reference counterpart): one wavefront per
 // workgroup, every lane follows its own uint16 successor table in LDS for `steps` DEPENDENT reads.

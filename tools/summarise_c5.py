@@ -1,4 +1,4 @@
-"""python tools/summarise_c5.py TAG: profiles/r02_c5_diameter_pmc.json + kernel stats from gpurun_out/TAG_c5_* (tools/prof_c5.sh)."""
+"""python tools/summarise_c5.py TAG: profiles/r03_c5_diameter_pmc.json + kernel stats from gpurun_out/TAG_c5_* (tools/prof_c5.sh)."""
 import csv
 import glob
 import json
@@ -15,7 +15,7 @@ def counter(kind, name):
     tot, kern = 0.0, None
     for f in glob.glob(f"{out}/{tag}_c5_{kind}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Kernel_Name"].startswith("void k_diam_lanes") and r["Counter_Name"] == name:
+            if r["Kernel_Name"].startswith(("void k_diam_lanes", "void k_diam_cluster")) and r["Counter_Name"] == name:
                 tot += float(r["Counter_Value"])
                 kern = r["Kernel_Name"]
     return tot, kern
@@ -24,8 +24,8 @@ def counter(kind, name):
 fetch_kb, kern = counter("fetch", "FETCH_SIZE")
 write_kb, _ = counter("write", "WRITE_SIZE")
 stats = glob.glob(f"{out}/{tag}_c5_stats/**/*kernel_stats.csv", recursive=True)[0]
-shutil.copy(stats, f"{prof}/r02_c5_diameter_kernel_stats.csv")
-kernel_ns = sum(float(r["TotalDurationNs"]) for r in csv.DictReader(open(stats)) if r["Name"].startswith("void k_diam_lanes"))
+shutil.copy(stats, f"{prof}/r03_c5_diameter_kernel_stats.csv")
+kernel_ns = sum(float(r["TotalDurationNs"]) for r in csv.DictReader(open(stats)) if r["Name"].startswith(("void k_diam_lanes", "void k_diam_cluster")))
 run = json.loads(open(f"{out}/{tag}_c5_line.json").read().strip().splitlines()[-1])
 rd, wr = fetch_kb * 1024 * 2, write_kb * 1024
 alg = 2 * wr
@@ -48,5 +48,5 @@ if sq:
                    wave_cycles_issue_stalled_frac=sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"],
                    valu_insts_per_state_and_group_sweep=sq["SQ_INSTS_VALU"] / (wr / 256.0),
                    salu_insts_per_state_and_group_sweep=sq["SQ_INSTS_SALU"] / (wr / 256.0))
-json.dump(j, open(f"{prof}/r02_c5_diameter_pmc.json", "w"), indent=1)
+json.dump(j, open(f"{prof}/r03_c5_diameter_pmc.json", "w"), indent=1)
 print({k: v for k, v in j.items() if k != "run"})
