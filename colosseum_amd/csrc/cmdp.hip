@@ -144,6 +144,11 @@ struct cmdp {
   hipEvent_t ev_row[2] = {nullptr, nullptr};      // logged loop: policy + state snapshot taken | evaluation of the row complete
   DevBuf<int32_t> d_cur_snap;                     // logged loop: current states at the row (the solve runs beside the next interval)
   int last_dp_kernel = 0;     // CMDP_STAT_DP_KERNEL: 1 K2, 2 K2R, 5 K2U, 6 K3 (Gauss-Seidel)
+  float *zc_Q = nullptr, *zc_V = nullptr;   // discounted(): device aliases of page-locked result arrays (run_sweeps)
+  int64_t* zc_sweeps = nullptr;
+  bool zc_used = false;
+  PinnedBuf<int32_t> pin_status;   // ... and the per-instance status words of such a solve (read after the stream has drained)
+  size_t pin_status_n = 0;
   int dp_kernel = 0;  // 0 auto, 1 LDS/global-CSR workgroup kernel, 2 register-resident kernel K2R, 5 its distinct-successor form K2U (3, 4: diameter only)
 
   DevBuf<int64_t> d_state_off, d_entry_base, d_start_off, d_csr_ptr;
@@ -1726,7 +1731,17 @@ int run_sweeps(cmdp_t* h, int mode, bool diam, int scheme, DpTables t, int64_t u
   hipStream_t st = h->stream;
   if (units > 0x7fffffffLL) return fail(CMDP_ERR_INVALID, "too many work items");
   const size_t v_bytes = sizeof(float) * (size_t)h->max_S;
+  const DpTables t_dev = t;
+  h->zc_used = false;
   if (scheme == CMDP_SCHEME_JACOBI && !diam && h->dp_kernel != 1) {
+    // The register-resident kernels touch Q, V and the sweep counts exactly once, when an instance has converged: if the
+    // caller's result arrays are page-locked (BatchedMDP.dp_buffers), the kernels store into them directly -- the results of
+    // the instances that converge early cross PCIe under the sweeps of the rest, and no copy follows the kernel
+    if (h->zc_V) {
+      t.Q = h->zc_Q; t.V = h->zc_V;
+      if (h->zc_sweeps) t.sweeps = h->zc_sweeps;
+      if (h->pin_status.p && h->pin_status_n >= (size_t)units) t.status = h->pin_status.p;
+    }
     // register-resident CSR (K2R) when the shapes fit one of the compiled instantiations
     const int A = h->A, K = h->max_row_nnz <= 4 ? 4 : (h->max_row_nnz <= 8 ? 8 : 0);
     const int spt = h->max_S <= 256 ? 1 : (h->max_S <= 512 ? 2 : (h->max_S <= 1024 ? 4 : 0));
@@ -1764,6 +1779,7 @@ int run_sweeps(cmdp_t* h, int mode, bool diam, int scheme, DpTables t, int64_t u
       if (done) {
         HIP_TRY(hipGetLastError());
         h->last_dp_kernel = 7;
+        h->zc_used = h->zc_V != nullptr;
         return CMDP_OK;
       }
       if (h->dp_kernel == 7) return fail(CMDP_ERR_UNSUPPORTED, "no one-wavefront instantiation for A=%d", A);
@@ -1787,6 +1803,7 @@ int run_sweeps(cmdp_t* h, int mode, bool diam, int scheme, DpTables t, int64_t u
       if (done) {
         HIP_TRY(hipGetLastError());
         h->last_dp_kernel = 5;
+        h->zc_used = h->zc_V != nullptr;
         return CMDP_OK;
       }
       if (h->dp_kernel == 5)
@@ -1808,10 +1825,12 @@ int run_sweeps(cmdp_t* h, int mode, bool diam, int scheme, DpTables t, int64_t u
     if (launched) {
       HIP_TRY(hipGetLastError());
       h->last_dp_kernel = 2;
+      h->zc_used = h->zc_V != nullptr;
       return CMDP_OK;
     }
     if (h->dp_kernel == 2) return fail(CMDP_ERR_UNSUPPORTED, "no register-resident instantiation for A=%d, %d non-zeros/row, %d states", A, h->max_row_nnz, h->max_S);
   }
+  t = t_dev;   // the workgroup / wavefront kernels below keep their working values in the device arrays
   if (scheme == CMDP_SCHEME_JACOBI) {
     const size_t base = 2 * v_bytes + sizeof(float) * 4 * (kDpBlock / 64);
     const size_t csr = sizeof(int32_t) * ((size_t)h->max_S * h->A + 1) + 8 * (size_t)h->max_inst_nnz +
@@ -1893,12 +1912,42 @@ int discounted(cmdp_t* h, int mode, const float* pi, float gamma, double eps, in
     HIP_TRY(hipEventCreate(&h->ev_dp0));
     HIP_TRY(hipEventCreate(&h->ev_dp1));
   }
+  // device-visible aliases of page-locked result arrays (null for pageable memory): see run_sweeps
+  auto alias = [](void* p) -> void* {
+    hipPointerAttribute_t a{};
+    if (p && hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer) return a.devicePointer;
+    (void)hipGetLastError();   // pageable memory is reported as an error by some runtime versions
+    return nullptr;
+  };
+  static const bool zc_env = !(std::getenv("CMDP_DP_ZERO_COPY") && std::atoi(std::getenv("CMDP_DP_ZERO_COPY")) == 0);
+  h->zc_Q = zc_env ? static_cast<float*>(alias(Q)) : nullptr;
+  h->zc_V = (zc_env && h->zc_Q) ? static_cast<float*>(alias(V)) : nullptr;
+  h->zc_sweeps = (h->zc_V && sweeps) ? static_cast<int64_t*>(alias(sweeps)) : nullptr;
+  if (!h->zc_V) h->zc_Q = nullptr;
+  if (h->zc_V && h->pin_status_n < (size_t)h->B) {
+    if (h->pin_status.p) { (void)hipHostFree(h->pin_status.p); h->pin_status.p = nullptr; }
+    if (int rc = h->pin_status.alloc((size_t)h->B)) return rc;
+    h->pin_status_n = (size_t)h->B;
+  }
   HIP_TRY(hipEventRecord(h->ev_dp0, st));
-  if (int rc = run_sweeps(h, mode, false, sch, t, h->B)) return rc;
+  const int rc_run = run_sweeps(h, mode, false, sch, t, h->B);
+  const bool zc = h->zc_used, zc_sw = zc && h->zc_sweeps;
+  h->zc_Q = h->zc_V = nullptr; h->zc_sweeps = nullptr; h->zc_used = false;
+  if (rc_run) return rc_run;
   HIP_TRY(hipEventRecord(h->ev_dp1, st));
-  HIP_TRY(hipMemcpyAsync(Q, h->d_Q.p, sizeof(float) * R, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(V, h->d_V.p, sizeof(float) * NS, hipMemcpyDeviceToHost, st));
-  if (sweeps) HIP_TRY(hipMemcpyAsync(sweeps, h->d_sweeps.p, sizeof(int64_t) * h->B, hipMemcpyDeviceToHost, st));
+  if (!zc) {
+    HIP_TRY(hipMemcpyAsync(Q, h->d_Q.p, sizeof(float) * R, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(V, h->d_V.p, sizeof(float) * NS, hipMemcpyDeviceToHost, st));
+  }
+  if (sweeps && !zc_sw) HIP_TRY(hipMemcpyAsync(sweeps, h->d_sweeps.p, sizeof(int64_t) * h->B, hipMemcpyDeviceToHost, st));
+  if (zc) {   // the kernels wrote the status words into page-locked memory as well: nothing left to copy
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int64_t u = 0; u < h->B; ++u) {
+      if (h->pin_status.p[u] == CMDP_ERR_MAX_ITER) return fail(CMDP_ERR_MAX_ITER, "work item %lld did not converge within max_sweeps", (long long)u);
+      if (h->pin_status.p[u] == CMDP_ERR_MAX_VALUE) return fail(CMDP_ERR_MAX_VALUE, "work item %lld exceeded max_abs_value", (long long)u);
+    }
+    return CMDP_OK;
+  }
   return check_status(h, h->B);
 }
 

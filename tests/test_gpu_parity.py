@@ -896,3 +896,41 @@ def test_value_iteration_into_pinned_buffers(need_gpu):
         np.testing.assert_array_equal(sw, sw0)
         Q[:] = -1.0
     dp.close()
+
+
+def test_dp_results_stored_straight_into_page_locked_buffers(need_gpu):
+    """`BatchedMDP.dp_buffers()` hands out page-locked arrays; the register-resident sweep kernels (K2W / K2U / K2R) then store
+    Q, V and the sweep counts into them directly (no copy after the kernel).  Same numbers as through pageable arrays, for
+    value iteration and policy evaluation, on batches that take each of the three kernels; the LDS / Gauss-Seidel kernels keep
+    the copy."""
+    cases = [[make_model("FrozenLakeContinuous", seed=s, size=20, p_frozen=0.9, p_rand=0.1) for s in range(6)],   # K2W (400 states)
+             [make_model("FrozenLakeContinuous", seed=s, size=12, p_frozen=0.85, p_lazy=0.1) for s in range(5)],  # K2U
+             [make_model("DeepSeaContinuous", seed=s, size=14, p_rand=0.2) for s in range(4)],
+             [make_model("MiniGridEmptyContinuous", seed=s, size=6, p_rand=0.1) for s in range(3)]]
+    kernels = set()
+    for ms in cases:
+        dp = BatchedMDP(ms, with_env=False)
+        for scheme in (L.SCHEME_JACOBI, L.SCHEME_GAUSS_SEIDEL):
+            Q0, V0, s0 = dp.value_iteration(0.99, 1e-6, scheme=scheme)
+            bufs = dp.dp_buffers()
+            for b in bufs:
+                b[...] = 0
+            Q1, V1, s1 = dp.value_iteration(0.99, 1e-6, scheme=scheme, out=bufs)
+            np.testing.assert_array_equal(Q1, Q0)
+            np.testing.assert_array_equal(V1, V0)
+            np.testing.assert_array_equal(s1, s0)
+            if scheme == L.SCHEME_JACOBI:
+                import ctypes
+
+                v = ctypes.c_double()
+                L.check(L.load().cmdp_stat(dp.handle, L.STAT_DP_KERNEL, ctypes.byref(v)))
+                kernels.add(int(v.value))
+            pi = np.concatenate([np.full((m.n_states, m.n_actions), 1.0 / m.n_actions, np.float32).ravel() for m in ms])
+            P0 = dp.policy_evaluation(pi, 0.99, 1e-6, scheme=scheme)
+            for b in bufs:
+                b[...] = 0
+            P1 = dp.policy_evaluation(pi, 0.99, 1e-6, scheme=scheme, out=bufs)
+            for a, b in zip(P0, P1):
+                np.testing.assert_array_equal(b, a)
+        dp.close()
+    assert 7 in kernels and (5 in kernels or 2 in kernels), kernels
