@@ -1161,6 +1161,7 @@ int cmdp_set_reward_streams(cmdp_t* h, const uint32_t* mt_key, const int32_t* mt
     cmdp_rc::NumpyStream& rs = h->rc_streams[(size_t)b];
     std::memcpy(rs.key, mt_key + (size_t)b * 624, sizeof rs.key);
     rs.pos = mt_pos[b];
+    rs.out_valid = false;
     rs.has_gauss = has_gauss ? has_gauss[b] : 0;
     rs.gauss = cached_gaussian ? cached_gaussian[b] : 0.0;
   }
