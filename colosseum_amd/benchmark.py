@@ -127,6 +127,21 @@ def build_shard_models(instances: Sequence[Instance], rank: int = 0, world: int 
 def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_mode, device, max_time=np.inf,
                beta_rewards="reference"):
     L.check(L.load().cmdp_set_device(device))
+    env, agent, loop, exact, t0, t1 = _setup_group(models, seeds, agent_cls, agent_kwargs, n_steps, rng_mode, beta_rewards)
+    rows = loop.run(n_steps, log_every, max_time)
+    t2 = time.time()
+    for b, table in enumerate(rows):  # what MDPLoop.run returns first: where the time limit froze training (-1: it did not)
+        table.last_training_step = int(loop.last_training_step[b])
+    if exact and rows:
+        rows[0].reward_cache_stats = env.reward_cache_stats()
+    agent.close()
+    env.close()
+    if rows:
+        rows[0].phase_seconds = (t1 - t0, t2 - t1, time.time() - t2)   # tables + baselines + agent | the interaction | release
+    return rows
+
+
+def _setup_group(models, seeds, agent_cls, agent_kwargs, n_steps, rng_mode, beta_rewards):
     stochastic = any(not m.deterministic_rewards for m in models)
     # Beta rewards, "reference": the reference's own per-triple caches of 5000 samples from the MDP's numpy stream
     # (CMDP_FLAG_REWARD_CACHE: blocks in HBM, drawn by the library on the host whenever an instance needs one), next to
@@ -143,18 +158,7 @@ def _run_group(models, seeds, agent_cls, agent_kwargs, n_steps, log_every, rng_m
     else:
         agent = BatchedQLearningContinuous(env, seeds, optimization_horizon=n_steps, **agent_kwargs)
         loop = BatchedContinuousLoop(env, agent)
-    t1 = time.time()
-    rows = loop.run(n_steps, log_every, max_time)
-    t2 = time.time()
-    for b, table in enumerate(rows):  # what MDPLoop.run returns first: where the time limit froze training (-1: it did not)
-        table.last_training_step = int(loop.last_training_step[b])
-    if exact and rows:
-        rows[0].reward_cache_stats = env.reward_cache_stats()
-    agent.close()
-    env.close()
-    if rows:
-        rows[0].phase_seconds = (t1 - t0, t2 - t1, time.time() - t2)   # tables + baselines + agent | the interaction | release
-    return rows
+    return env, agent, loop, exact, t0, time.time()
 
 
 def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, rank: int = 0, world: int = 1,
@@ -221,7 +225,14 @@ def run_instances(instances: Sequence[Instance], n_steps: int, log_every: int, r
         n_parts = -(-len(idx) // max(1, max_batch))
         size = -(-len(idx) // n_parts)
         parts += [idx[i:i + size] for i in range(0, len(idx), size)]
-    order = sorted(parts, key=lambda idx: -len(idx) * models[idx[0]].n_states * max(models[idx[0]].n_states, 64))
+    # longest first.  A batch's time is rows x (dependent kernel time per row), which hardly depends on the number of
+    # instances: per row the episodic loop evaluates a policy over H x S (state, time) pairs, the continuous one solves a
+    # chain of S states (measured on C4: ~1.5 s per 1 000 for either measure)
+    def expected(idx):
+        m = models[idx[0]]
+        return (m.H * m.n_states if m.is_episodic else 6 * m.n_states) * (1.0 + len(idx) / 400.0)
+
+    order = sorted(parts, key=lambda idx: -expected(idx))
     import sys
 
     old_interval = sys.getswitchinterval()
@@ -260,7 +271,7 @@ def _write_slice(task):
     return len(paths)
 
 
-def submit_group_logs(pool, folder: str, instances: Sequence[Instance], idx: Sequence[int], rows, chunk: int = 16):
+def submit_group_logs(pool, folder: str, instances: Sequence[Instance], idx: Sequence[int], rows, chunk: int = 8):
     """Hands the log files of ONE finished device batch to `pool` (a concurrent.futures executor of spawned processes:
     the float -> text conversion is Python-level work that must not hold the GIL of the threads driving the other
     batches).  Returns the futures.  Files are written as their batch finishes, so an interrupted benchmark resumes from
