@@ -216,9 +216,6 @@ struct cmdp {
   DevBuf<int32_t> d_dl_inst, d_dl_t0, d_dl_cnt;
   DevBuf<int64_t> d_dl_voff;
   DevBuf<float> d_k5c_red;          // K5C: the clusters' partial reductions
-  DevBuf<uint32_t> d_ell_pack;      // K5C, rows in LDS: (coefficient code << 16 | column) per entry
-  DevBuf<float> d_ell_dict;         // ... and the distinct coefficients
-  int ell_n_dict = 0;
   DevBuf<unsigned int> d_k5c_bar;   // K5C: barrier counters + error flag
   int64_t k5c_launches = 0, k5c_timeouts = 0;
   bool k5c_agent_scope = false;     // K5C: a cluster was found spread over XCDs once -- agent-scope barriers from then on
@@ -2111,31 +2108,6 @@ static int build_ell_relabelled(cmdp_t* h, int K, int cluster) {
       }
     }
   }
-  // K5C's LDS-resident form of the rows: (coefficient code << 16 | column) per entry and a dictionary of the distinct
-  // coefficient bit patterns -- possible when every instance has < 65 536 states and the batch few distinct coefficients
-  h->ell_n_dict = 0;
-  if (h->max_S <= 65535) {
-    std::unordered_map<uint32_t, uint32_t> code;
-    std::vector<float> dict;
-    std::vector<uint32_t> pack(ecol.size(), 0u);
-    bool ok = true;
-    for (size_t i = 0; i < ecol.size() && ok; ++i) {
-      uint32_t bits;
-      std::memcpy(&bits, &eval_[i], 4);
-      auto it = code.find(bits);
-      if (it == code.end()) {
-        if (dict.size() >= 1024) { ok = false; break; }
-        it = code.emplace(bits, (uint32_t)dict.size()).first;
-        dict.push_back(eval_[i]);
-      }
-      pack[i] = (it->second << 16) | (uint32_t)ecol[i];
-    }
-    if (ok) {
-      HIP_TRY(h->d_ell_pack.upload(pack.data(), pack.size(), st));
-      HIP_TRY(h->d_ell_dict.upload(dict.data(), dict.size(), st));
-      h->ell_n_dict = (int)dict.size();
-    }
-  }
   HIP_TRY(h->d_ell_col.upload(ecol.data(), ecol.size(), st));
   HIP_TRY(h->d_ell_val.upload(eval_.data(), eval_.size(), st));
   HIP_TRY(h->d_ell_newof.upload(new_of.data(), new_of.size(), st));
@@ -2373,26 +2345,10 @@ static int diameter_lanes(cmdp_t* h, DpTables t, int64_t unit_lo, int64_t unit_h
     for (int pass = (agent_env || h->k5c_agent_scope) ? 1 : 0; pass < 2; ++pass) {
       HIP_TRY(h->d_k5c_bar.zero(st));   // counters, error flag, XCC ids
       bool launched = true;
-      // rows resident in LDS when the relabelled form has its packed twin and a wavefront's chunks fit (C5: 20 chunks of 256 B
-      // per wavefront = 80 KB per workgroup); CMDP_K5C_LDS_ROWS = 0 keeps them in L2 / HBM
-      const int U_k5c = 64 / (A * K);
-      int max_chunks = 0;
-      for (size_t q = 0; q < G; ++q) {
-        const int64_t Sq = h->state_off[inst[q] + 1] - h->state_off[inst[q]];
-        max_chunks = std::max(max_chunks, (int)((Sq + U_k5c - 1) / U_k5c));
-      }
-      const int cpw = (max_chunks + CLs * 16 - 1) / (CLs * 16);
-      const size_t lds_rows = sizeof(uint32_t) * ((size_t)((h->ell_n_dict + 63) & ~63) + (size_t)16 * cpw * 64);
-      const bool lds_env = !(std::getenv("CMDP_K5C_LDS_ROWS") && std::atoi(std::getenv("CMDP_K5C_LDS_ROWS")) == 0);
-      const bool lds_rows_ok = pass == 0 && lds_env && h->ell_relabelled && h->ell_n_dict > 0 && lds_rows <= (size_t)kLdsBudget - 8704;
-      ca.pack = h->d_ell_pack.p; ca.dict = h->d_ell_dict.p; ca.n_dict = h->ell_n_dict; ca.cpw = cpw;
 #define K5C_CASE(CLT, AT, KT)                                                                                       \
   if (CLs == CLT && A == AT && K == KT) {                                                                           \
-    if (lds_rows_ok) {                                                                                              \
-      if (int rc = set_lds(k_diam_cluster<CLT, AT, KT, true, true>, lds_rows)) return rc;                            \
-      hipLaunchKernelGGL((k_diam_cluster<CLT, AT, KT, true, true>), dim3(grid), dim3(1024), lds_rows, st, t, g, ca, h->d_ell_col.p, h->d_ell_val.p, new_of); \
-    } else if (pass == 0) hipLaunchKernelGGL((k_diam_cluster<CLT, AT, KT, true, false>), dim3(grid), dim3(1024), 0, st, t, g, ca, h->d_ell_col.p, h->d_ell_val.p, new_of); \
-    else hipLaunchKernelGGL((k_diam_cluster<CLT, AT, KT, false, false>), dim3(grid), dim3(1024), 0, st, t, g, ca, h->d_ell_col.p, h->d_ell_val.p, new_of); \
+    if (pass == 0) hipLaunchKernelGGL((k_diam_cluster<CLT, AT, KT, true>), dim3(grid), dim3(1024), 0, st, t, g, ca, h->d_ell_col.p, h->d_ell_val.p, new_of); \
+    else hipLaunchKernelGGL((k_diam_cluster<CLT, AT, KT, false>), dim3(grid), dim3(1024), 0, st, t, g, ca, h->d_ell_col.p, h->d_ell_val.p, new_of); \
   } else
 #define K5C_SHAPES(CLT) K5C_CASE(CLT, 2, 2) K5C_CASE(CLT, 2, 4) K5C_CASE(CLT, 2, 8) K5C_CASE(CLT, 3, 2) K5C_CASE(CLT, 3, 4) \
                         K5C_CASE(CLT, 3, 8) K5C_CASE(CLT, 4, 2) K5C_CASE(CLT, 4, 4) K5C_CASE(CLT, 4, 8)

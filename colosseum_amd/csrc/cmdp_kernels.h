@@ -2558,12 +2558,6 @@ struct DiamClusterArgs {
   int* err;                   // 1: a barrier timed out; 2: a cluster's workgroups are not on one XCD
   int* xcc;                   // [n_clusters][CL] XCC id of every member (XCD-scope barriers only)
   long long timeout_ticks;    // wall_clock64 ticks (100 MHz)
-  // LDSELL form: a wavefront walks the SAME chunks of states in every sweep of every group, so its slice of the fixed-width
-  // rows lives in LDS for the whole launch -- entries packed as (coefficient code << 16 | column), the coefficients in a
-  // dictionary (S <= 65 535, a few distinct coefficients: build_ell_relabelled)
-  const uint32_t* pack;       // [(n_rows + pad) * K] packed entries, laid out like ecol
-  const float* dict;          // [n_dict] distinct coefficients (bit patterns; +0.0 first)
-  int n_dict, cpw;            // chunks per wavefront the dynamic LDS holds
 };
 
 // XCD = true: the members have verified (HW_REG_XCC_ID) that they share an XCD, i.e. one L2.  Stores are complete when
@@ -2600,21 +2594,13 @@ __device__ __forceinline__ bool cluster_barrier(unsigned int* bar, unsigned int&
   return ok_s != 0;
 }
 
-template <int CL, int A, int K, bool XCD, bool LDSELL>
+template <int CL, int A, int K, bool XCD>
 __global__ void __launch_bounds__(1024) k_diam_cluster(DpTables t, DiamLanesArgs g, DiamClusterArgs ca, const int32_t* __restrict__ ecol,
                                                       const float* __restrict__ eval_, const int32_t* __restrict__ new_of) {
   constexpr int NW = 16, AK = A * K, U = 64 / AK, XCDS = 8;
   static_assert(U >= 1, "A*K must not exceed 64");
   __shared__ float red_d[NW][64];
   __shared__ float red_m[NW][64];
-  extern __shared__ __align__(16) uint32_t k5c_lds[];   // LDSELL: [n_dict rounded up to 64] dictionary, then [NW][cpw][64] entries
-  const int dict_words = LDSELL ? ((ca.n_dict + 63) & ~63) : 0;
-  uint32_t* my_rows = k5c_lds + dict_words + (int64_t)(threadIdx.x >> 6) * ca.cpw * 64;
-  int b_loaded = -1;
-  if (LDSELL) {
-    for (int i = threadIdx.x; i < ca.n_dict; i += 1024) k5c_lds[i] = __float_as_uint(ca.dict[i]);
-    __syncthreads();
-  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int xcd = blockIdx.x % XCDS, idx = blockIdx.x / XCDS;
@@ -2657,20 +2643,10 @@ __global__ void __launch_bounds__(1024) k_diam_cluster(DpTables t, DiamLanesArgs
     float* Vnew = vbase + (int64_t)S * 64;
     // zero both arrays, the members' slices interleaved
     for (int64_t i = (int64_t)member * 1024 + threadIdx.x; i < (int64_t)S * 128; i += (int64_t)CL * 1024) Vold[i] = 0.0f;
-    const int s_begin = cw * U;
-    constexpr int STRIDE = CW * U;
-    if (LDSELL && b != b_loaded) {   // this wavefront's chunks of the instance's rows (wave-private LDS: no barrier needed)
-      const uint32_t* pk = ca.pack + soff * AK;
-      const int sl = lane / AK;
-      int i = 0;
-      for (int s0 = s_begin; s0 < S; s0 += STRIDE, ++i) {
-        const uint32_t w = pk[(int64_t)s0 * AK + lane];
-        my_rows[i * 64 + lane] = (s0 + sl < S) ? w : (w & 0xffff0000u);   // past the last state: column 0 (discarded gathers)
-      }
-      b_loaded = b;
-    }
     if (!cluster_barrier<CL, XCD>(bar, epoch, ca.err, ca.timeout_ticks)) return;
 
+    const int s_begin = cw * U;
+    constexpr int STRIDE = CW * U;
     bool done = !active;
     float result = 0.0f;
     int status = active ? -5 : 0;
@@ -2680,31 +2656,12 @@ __global__ void __launch_bounds__(1024) k_diam_cluster(DpTables t, DiamLanesArgs
       float dmax = 0.0f, vmin = 3.0e38f;
       if (s_begin < S) {
         const int sl = lane / AK;
-        int ccol;
-        float cval;
-        int ci = 0;   // LDSELL: index of the chunk in this wavefront's slice
-        if (LDSELL) {
-          const uint32_t w = my_rows[lane];
-          ccol = (int)(w & 0xffffu);
-          cval = __uint_as_float(k5c_lds[w >> 16]);
-        } else {
-          ccol = (s_begin + sl < S) ? ec[(int64_t)s_begin * AK + lane] : 0;
-          cval = ev[(int64_t)s_begin * AK + lane];
-        }
+        int ccol = (s_begin + sl < S) ? ec[(int64_t)s_begin * AK + lane] : 0;
+        float cval = ev[(int64_t)s_begin * AK + lane];
         for (int s0 = s_begin; s0 < S; s0 += STRIDE) {
           const int sn = (s0 + STRIDE < S) ? s0 + STRIDE : s0;
-          int ncol;
-          float nval;
-          if (LDSELL) {
-            const int ni = (s0 + STRIDE < S) ? ci + 1 : ci;
-            const uint32_t w = my_rows[ni * 64 + lane];
-            ncol = (int)(w & 0xffffu);
-            nval = __uint_as_float(k5c_lds[w >> 16]);
-            ++ci;
-          } else {
-            ncol = (sn + sl < S) ? ec[(int64_t)sn * AK + lane] : 0;
-            nval = ev[(int64_t)sn * AK + lane];
-          }
+          const int ncol = (sn + sl < S) ? ec[(int64_t)sn * AK + lane] : 0;
+          const float nval = ev[(int64_t)sn * AK + lane];
           float x[U * AK], vo[U];
 #pragma unroll
           for (int e = 0; e < U * AK; ++e) {
