@@ -400,7 +400,10 @@ def main():
 
     # ---- HBM traffic of the headline and dense kernels, measured now (child runs under rocprofv3 --pmc; N = 1 only) ------
     global LIVE_PMC
-    if world == 1 and not args.no_live_pmc and not dense_headline:
+    # (not when this run is itself profiled: the profiler's preload has initialised the GPU before main(), and the GPU boxes
+    # refuse a fork + exec from such a process -- the committed summary is used then)
+    under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROFILER_", "ROCPROF_")) for k in os.environ)
+    if world == 1 and not args.no_live_pmc and not dense_headline and not under_profiler:
         t_pmc = time.time()
         LIVE_PMC = live_pmc(["--instances", str(B), "--size", str(args.size), "--launch-steps", str(args.launch_steps),
                              "--dense-instances", str(args.dense_instances), "--dense-launch-steps", str(args.dense_launch_steps),

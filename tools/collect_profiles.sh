@@ -13,9 +13,9 @@ export TMPDIR=/tmp
 echo "start $(date +%T)"
 python3 $R/bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench.err
 echo "bench done" | tee -a $OUT/${TAG}_progress.txt
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats --output-format csv -- python3 $R/bench.py --no-cpu --sustained-seconds 0 > $OUT/${TAG}_bench_line_under_rocprof.json 2> $OUT/${TAG}_rocprof.err
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats --output-format csv -- python3 $R/bench.py --no-cpu --no-live-pmc --sustained-seconds 0 > $OUT/${TAG}_bench_line_under_rocprof.json 2> $OUT/${TAG}_rocprof.err
 echo "stats done" | tee -a $OUT/${TAG}_progress.txt
-PROF_ARGS="--no-cpu --steps 6 --warmup 2 --dense-steps 4 --sustained-seconds 0 --strong-share 0"
+PROF_ARGS="--no-cpu --no-live-pmc --steps 6 --warmup 2 --dense-steps 4 --sustained-seconds 0 --strong-share 0"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_fetch --output-format csv -- python3 $R/bench.py $PROF_ARGS > /dev/null 2> $OUT/${TAG}_fetch.err
 echo "fetch done" | tee -a $OUT/${TAG}_progress.txt
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_write --output-format csv -- python3 $R/bench.py $PROF_ARGS > /dev/null 2> $OUT/${TAG}_write.err
