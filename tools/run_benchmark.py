@@ -17,7 +17,7 @@ import yaml
 # Device batches are driven concurrently, one stream each; the HIP runtime multiplexes streams onto 4 hardware queues by
 # default, which serialises the (small, latency-bound) kernels of different batches.  16 queues: 89 s -> 55 s for the
 # four default suites on one MI355X.  Read by the runtime at its first call, so it is set before anything touches HIP.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")   # two streams per continuous batch, 16 batches in flight
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # many host threads, one device batch each: they sleep while they wait for the device instead of spinning on a core apiece
