@@ -18,6 +18,8 @@
 #include <unordered_map>
 #include <vector>
 
+extern char** environ;
+
 #include "cmdp_kernels.h"
 #include "cmdp_tracker.h"
 #include "cmdp_k1s.h"
@@ -3591,7 +3593,16 @@ int cmdp_qlearning_run_logged(cmdp_agent_t* a, const cmdp_loop_desc* d, int64_t 
   // all ~0 cannot freeze anything, and the host knows that BEFORE the row; (b) the time limit -- rows closer than a few
   // seconds to it are not run ahead.  Rows that could change the mask are processed in order, as before: the results are
   // the same either way (tests/test_gpu_mdploop.py holds both against the step-by-step loop).
-  static const bool pipeline_env = !(std::getenv("CMDP_LOGGED_PIPELINE") && std::atoi(std::getenv("CMDP_LOGGED_PIPELINE")) == 0);
+  // CMDP_LOGGED_PIPELINE = 0 | 1 decides; unset: on, except under rocprofv3 (its tool library in LD_PRELOAD or its ROCPROF*
+  // variables in the environment), whose queue interception faults on a stream that never drains
+  static const bool pipeline_env = [] {
+    if (const char* e = std::getenv("CMDP_LOGGED_PIPELINE")) return std::atoi(e) != 0;
+    const char* pre = std::getenv("LD_PRELOAD");
+    if (pre && std::strstr(pre, "rocprof")) return false;
+    for (char** ev = environ; ev && *ev; ++ev)
+      if (!std::strncmp(*ev, "ROCPROF", 7)) return false;
+    return true;
+  }();
   static const bool block_env = std::getenv("CMDP_SYNC_MODE") && !std::strcmp(std::getenv("CMDP_SYNC_MODE"), "block");
   // CMDP_LOGGED_DRAIN_EVERY = n: the stream is drained completely every n rows (0: never).  Only for runs under rocprofv3,
   // whose queue interception faulted in hipLaunchKernel's argument copy once a stream stayed busy long enough for the
