@@ -36,6 +36,7 @@ DP_REGISTER_WAVEFRONT = 7  # K2W: K2U's tables with one wavefront per instance (
 ROLLOUT_AUTO, ROLLOUT_GLOBAL, ROLLOUT_LDS, ROLLOUT_LDS_STOCHASTIC = 0, 1, 2, 3
 ROLLOUT_LDS_TEMPLATE = 4  # K1T: K1P with one successor table per workgroup (batches of action-permuted copies of one MDP)
 ROLLOUT_LDS_TEMPLATE_STREAM = 5  # K1U: K1T with the trace streamed to HBM and histogrammed afterwards (256 instances per CU)
+ROLLOUT_EPISODE_PARALLEL = 6  # K1E: lane = (instance, episode): episodic batches with two actions walk their episodes in parallel
 
 EXPORTS = [
     "cmdp_version", "cmdp_build_id", "cmdp_last_error", "cmdp_device_count", "cmdp_set_device", "cmdp_create", "cmdp_destroy",

@@ -211,7 +211,7 @@ class BatchedMDP:
         plan = np.zeros(4, np.int32)
         L.check(self._lib.cmdp_lds_plan(self._h, L.ptr(plan)))
         return dict(eligible=bool(plan[0]), kernel={0: "k_rollout_lds", 1: "k_rollout_pipe", 2: "k_rollout_stoch", 3: "k_rollout_tmpl",
-                                                       4: "k_rollout_tmpl_stream"}[int(plan[1])],
+                                                       4: "k_rollout_tmpl_stream", 5: "k_rollout_epi"}[int(plan[1])],
                     instances_per_workgroup=int(plan[2]), chunk=int(plan[3]))
 
     def set_option(self, option: int, value: int):

@@ -25,6 +25,7 @@ extern char** environ;
 #include "cmdp_k1s.h"
 #include "cmdp_k1t.h"
 #include "cmdp_k1u.h"
+#include "cmdp_k1e.h"
 #include "cmdp_agent.h"
 #include "cmdp_chain.h"
 
@@ -203,6 +204,13 @@ struct cmdp {
   bool ev_hist_used[2] = {false, false}, k1u_last_overlap = false;
   int64_t k1u_seq = 0;
   hipEvent_t ev_k1u[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // CMDP_STAT_ROLLOUT_KERNEL_MS / _HIST_KERNEL_MS of the last segment
+  // K1E: the episode-parallel rollout (cmdp_k1e.h): lane = (instance, episode), private {successor | count} tables in LDS
+  bool k1e_ok = false;
+  K1ePlan k1e{};
+  size_t k1e_lds = 0;
+  DevBuf<uint32_t> d_etab;
+  DevBuf<uint2> d_k1e_codes;
+  DevBuf<int32_t> d_k1e_h0;
   DevBuf<float> d_gp_q, d_gp_p;  // cmdp_greedy_policy_episodic workspace
   // K5S workspace (large-instance diameter)
   DevBuf<float> d_dl_v, d_ell_val;
@@ -952,6 +960,40 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
             }
           }
         }
+        // K1E (cmdp_k1e.h): episodic batches with two actions and at most four distinct rewards walk their EPISODES in
+        // parallel (private {successor word | count} tables of 32 instances per workgroup): throughput- instead of
+        // latency-bound, and the tables need not be action-permuted copies of one MDP.
+        static const int k1e_env = std::getenv("CMDP_K1E") ? std::atoi(std::getenv("CMDP_K1E")) : -1;   // tuning aid: 0 off
+        if (A == 2 && h->H > 0 && vals.size() <= 4 && k1e_env != 0) {
+          K1ePlan e{};
+          e.S = max_S;
+          e.H = h->H;
+          int slot = 16;
+          while (slot < ((max_S + 15) & ~15) * 8) slot <<= 1;
+          e.slot_bytes = slot;
+          e.n_codes = (int)vals.size();
+          e.nch = (h->H + 31) / 32;
+          const int64_t pass_bits = (int64_t)K1E_EPP * h->H;
+          int rb = 4;
+          while (rb < (pass_bits + 127) / 128 + 1) rb <<= 1;
+          e.ring_blocks = rb;
+          if (slot <= 65536 && k1e_lds_bytes(e) <= (size_t)kLdsBudget) {
+            std::vector<uint32_t> et((size_t)B * max_S);
+            for (int64_t sidx = 0; sidx < (int64_t)B * max_S; ++sidx) {
+              const RowDesc& r0 = rows[(size_t)(2 * sidx)];
+              const RowDesc& r1 = rows[(size_t)(2 * sidx + 1)];
+              const uint32_t w0 = ((uint32_t)r0.next_if_det << 3) | codes[(size_t)(2 * sidx)];
+              const uint32_t w1 = ((uint32_t)r1.next_if_det << 3) | codes[(size_t)(2 * sidx + 1)];
+              et[(size_t)sidx] = w0 | (w1 << 16);
+            }
+            HIP_TRY(h->d_etab.upload(et.data(), et.size(), st));
+            HIP_TRY(hipStreamSynchronize(st));
+            e.etab = h->d_etab.p;
+            h->k1e = e;
+            h->k1e_lds = k1e_lds_bytes(e);
+            h->k1e_ok = true;
+          }
+        }
         if (best_cap >= 8) {
           // 16 bytes of slack in front of and behind both element arrays: the staging loads are 16-byte wide
           // from the aligned-down address of a group's first element
@@ -968,10 +1010,12 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
           h->lds_ok = true;
           h->tmpl_plan.rvals = p.rvals;
           h->k1u.rvals = p.rvals;
+          h->k1e.rvals = p.rvals;
           HIP_TRY(hipStreamSynchronize(st));  // staging vectors die with this scope
         }
       }
     }
+    if (!h->lds_ok) h->k1e_ok = false;   // (its reward values are uploaded with the K1L tables)
     if (!h->lds_ok)
       if (int rc = build_k1s(h, d)) return rc;
     if (h->n_slots) {
@@ -1303,6 +1347,41 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
   if (h->rollout_kernel == 5 && !(lds_eligible && h->k1u_ok))
     return fail(CMDP_ERR_UNSUPPORTED, "the streamed-trace rollout K1U needs a batch eligible for the shared-table rollout K1T (CMDP_OPT_ROLLOUT_KERNEL 4) "
                                       "and room for 64 instances per workgroup");
+  if (h->rollout_kernel == 6 && !(lds_eligible && h->k1e_ok))
+    return fail(CMDP_ERR_UNSUPPORTED, "the episode-parallel rollout K1E needs a batch eligible for the LDS-resident kernels (CMDP_OPT_ROLLOUT_KERNEL 2) "
+                                      "that is episodic, has two actions, at most four distinct reward values and at most 512 states per instance");
+  const bool take_k1e = lds_eligible && h->k1e_ok && n_steps > 0 && (h->rollout_kernel == 6 || (h->rollout_kernel == 0 && n_steps >= 64));
+  if (take_k1e) {
+    // K1E: per segment of <= K1E_SEG transitions (16-bit counts in the table dwords; the code buffer) the walk kernel, then
+    // the reward scan over the code words it left in HBM
+    if (int rc = k1u_join(h)) return rc;
+    if (!h->ev_k1u[0])
+      for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&h->ev_k1u[i]));
+    K1ePlan e = h->k1e;
+    // segment length: the code words of a segment (8 bytes per episode chunk and instance) stay within ~1.5 GB
+    const int64_t budget_words = std::max<int64_t>(4, (int64_t)((1536ll << 20) / (8 * (int64_t)h->B * e.nch)));
+    const int64_t seg = std::max<int64_t>(e.H, std::min<int64_t>(K1E_SEG, (budget_words - 2) * e.H));
+    const int64_t epi_cap = k1e_max_episodes(std::min<int64_t>(n_steps, seg), e.H);
+    const size_t need = (size_t)epi_cap * (size_t)e.nch * (size_t)h->B;
+    if (h->d_k1e_codes.n < need) HIP_TRY(h->d_k1e_codes.alloc(need));
+    if (h->d_k1e_h0.n < (size_t)h->B) HIP_TRY(h->d_k1e_h0.alloc(h->B));
+    e.codes = h->d_k1e_codes.p;
+    e.seg_h0 = h->d_k1e_h0.p;
+    if (int rc = set_lds(k_rollout_epi, h->k1e_lds)) return rc;
+    for (int64_t s0 = 0; s0 < n_steps; s0 += seg) {
+      const int64_t n = std::min<int64_t>(seg, n_steps - s0);
+      e.n_pass = (int)((k1e_max_episodes(n, e.H) + K1E_EPP - 1) / K1E_EPP);
+      const bool last = s0 + seg >= n_steps;
+      if (last) HIP_TRY(hipEventRecord(h->ev_k1u[0], st));
+      hipLaunchKernelGGL(k_rollout_epi, dim3(grid_for(h->B, K1E_NI)), dim3(K1E_THREADS), h->k1e_lds, st, t, e, n, d_last);
+      if (last) HIP_TRY(hipEventRecord(h->ev_k1u[1], st));
+      hipLaunchKernelGGL(k_reward_scan, dim3(grid_for(h->B, K1R_THREADS)), dim3(K1R_THREADS), 0, st, t, e, n, d_rsum, s0 > 0 ? 1 : 0);
+      if (last) HIP_TRY(hipEventRecord(h->ev_k1u[2], st));
+    }
+    h->k1u_last_overlap = false;
+    HIP_TRY(hipGetLastError());
+    return CMDP_OK;
+  }
   const bool take_k1u = lds_eligible && h->k1u_ok && (h->rollout_kernel == 5 || (h->rollout_kernel == 0 && h->k1u_auto && n_steps >= 64));
   if (!take_k1u) {
     if (int rc = k1u_join(h)) return rc;   // every other kernel updates the visit counters itself
@@ -1503,7 +1582,7 @@ int cmdp_rollout_async(cmdp_t* h, int policy, int64_t n_steps) {
 
 int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
   if (!h) return fail(CMDP_ERR_INVALID, "null handle");
-  if (option == CMDP_OPT_ROLLOUT_KERNEL && value >= 0 && value <= 5) {
+  if (option == CMDP_OPT_ROLLOUT_KERNEL && value >= 0 && value <= 6) {
     h->rollout_kernel = (int)value;
     return CMDP_OK;
   }
@@ -1548,11 +1627,12 @@ int cmdp_set_option(cmdp_t* h, int option, int64_t value) {
 int cmdp_lds_plan(cmdp_t* h, int32_t plan[4]) {
   if (!h || !plan) return fail(CMDP_ERR_INVALID, "bad argument");
   plan[0] = (h->lds_ok || h->k1s_ok) ? 1 : 0;
-  const bool k1u = h->lds_ok && h->k1u_ok && (h->rollout_kernel == 5 || (h->rollout_kernel == 0 && h->k1u_auto));
-  const bool k1t = !k1u && h->lds_ok && h->tmpl_ok && (h->rollout_kernel == 4 || (h->rollout_kernel == 0 && h->tmpl_auto));   // what a launch takes
-  plan[1] = k1u ? 4 : k1t ? 3 : (h->lds_ok ? h->lds_plan.pipe : (h->k1s_ok ? 2 : 0));
-  plan[2] = k1u ? h->k1u.G : k1t ? h->tmpl_plan.G : (h->lds_ok ? h->lds_plan.G : (h->k1s_ok ? h->k1s.G : 0));
-  plan[3] = k1u ? h->k1u.ch : k1t ? h->tmpl_plan.ch : (h->lds_ok ? h->lds_plan.ch : (h->k1s_ok ? h->k1s.ch : 0));
+  const bool k1e = h->lds_ok && h->k1e_ok && (h->rollout_kernel == 6 || h->rollout_kernel == 0);
+  const bool k1u = !k1e && h->lds_ok && h->k1u_ok && (h->rollout_kernel == 5 || (h->rollout_kernel == 0 && h->k1u_auto));
+  const bool k1t = !k1e && !k1u && h->lds_ok && h->tmpl_ok && (h->rollout_kernel == 4 || (h->rollout_kernel == 0 && h->tmpl_auto));   // what a launch takes
+  plan[1] = k1e ? 5 : k1u ? 4 : k1t ? 3 : (h->lds_ok ? h->lds_plan.pipe : (h->k1s_ok ? 2 : 0));
+  plan[2] = k1e ? K1E_NI : k1u ? h->k1u.G : k1t ? h->tmpl_plan.G : (h->lds_ok ? h->lds_plan.G : (h->k1s_ok ? h->k1s.G : 0));
+  plan[3] = k1e ? K1E_EPP : k1u ? h->k1u.ch : k1t ? h->tmpl_plan.ch : (h->lds_ok ? h->lds_plan.ch : (h->k1s_ok ? h->k1s.ch : 0));
   return CMDP_OK;
 }
 

@@ -9,7 +9,11 @@
 // Philox-4x32-10.  Counter (n_lo, n_hi, domain, 0), key = the instance's 64-bit key.
 // domain 0, n = transition index      : w0,w1 = 53-bit transition uniform (stochastic rows only)
 // domain 1, n = reset index           : w0,w1 = start-state uniform (several start states only)
-// domain 2, n = transition index >> 2 : word (index & 3) = random-policy action, a = (word * A) >> 32
+// domain 2, random-policy actions (build-defined stream; round 4: every bit of a block is used when A allows it)
+//           A in {2, 4, 16, 256} (lg = log2 A divides 32): PACKED -- a block holds apb = 128 / lg actions;
+//           transition n -> block n / apb, k = n % apb, a = (word[k / (32 / lg)] >> (lg * (k % (32 / lg)))) & (A - 1)
+//           (A = 2: 128 one-bit actions per block, least significant bit of word 0 first);
+//           any other A: block n >> 2, word (n & 3), a = (word * A) >> 32 (four actions per block).
 // domain 3, n = transition index, c3 = draw counter : Beta reward of the transition (philox_beta below)
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
@@ -27,6 +31,31 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     k1 += 0xBB67AE85u;
   }
   w[0] = c0; w[1] = c1; w[2] = c2; w[3] = c3;
+}
+
+// log2 A when the random-policy stream is packed (A in {2, 4, 16, 256}), else 0
+__host__ __device__ __forceinline__ int philox_act_lg(int A) { return A == 2 ? 1 : A == 4 ? 2 : A == 16 ? 4 : A == 256 ? 8 : 0; }
+
+// The four random-policy actions of transitions 4 g .. 4 g + 3 (g = the absolute group of four: every producer of the
+// chain kernels works in these groups).  Packed stream: the four sit side by side in one word of block g / (32 / lg).
+__device__ __forceinline__ void philox_act4(unsigned long long g, uint2 key, int A, int lg, uint32_t (&act)[4]) {
+  uint32_t w[4];
+  if (lg) {
+    const int gpb_sh = lg == 1 ? 5 : lg == 2 ? 4 : lg == 4 ? 3 : 2;   // groups per block = 32 / lg
+    const unsigned long long q = g >> gpb_sh;
+    philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), 2u, 0u, key.x, key.y, w);
+    const int gi = (int)(g & ((1ull << gpb_sh) - 1));   // group inside the block
+    const int wi = gi >> (gpb_sh - 2);                  // its word: a word holds 32 / lg actions = (32 / lg) / 4 groups
+    const uint32_t word = wi == 0 ? w[0] : wi == 1 ? w[1] : wi == 2 ? w[2] : w[3];
+    const int off = (gi & ((1 << (gpb_sh - 2)) - 1)) * 4 * lg;
+    const uint32_t m = (uint32_t)A - 1u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) act[j] = (word >> (off + j * lg)) & m;
+  } else {
+    philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), 2u, 0u, key.x, key.y, w);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) act[j] = (uint32_t)(((uint64_t)w[j] * (uint64_t)A) >> 32);
+  }
 }
 
 __device__ __forceinline__ double u53(uint32_t w0, uint32_t w1) {

@@ -153,9 +153,7 @@ __global__ void __launch_bounds__(K1S_THREADS) k_rollout_stoch(EnvTables t, K1sP
       uint32_t w[4];
       philox4x32_10((uint32_t)n, (uint32_t)(n >> 32), 0u, 0u, key.x, key.y, w);
       reinterpret_cast<double*>(ring_u)[((size_t)buf * p.G + slot) * CH + j] = u53(w[0], w[1]);
-      const unsigned long long q = n >> 2;
-      philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), 2u, 0u, key.x, key.y, w);
-      ring_a[((size_t)buf * p.G + slot) * CH + j] = (unsigned char)(((uint64_t)w[n & 3] * (uint64_t)A) >> 32);
+      ring_a[((size_t)buf * p.G + slot) * CH + j] = (unsigned char)philox_action(n, key, A);
     }
   };
 

@@ -126,10 +126,8 @@ __global__ void __launch_bounds__(K1T_THREADS) k_rollout_tmpl(EnvTables t, TmplP
     unsigned char* dst = ring + ((size_t)buf * p.G + li) * AS;
     for (int qi = pidx; qi < nblk; qi += K1T_NPROD) {
       const unsigned long long q = q0 + (unsigned long long)qi;
-      uint32_t w[4], act[4];
-      philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), 2u, 0u, my_key.x, my_key.y, w);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) act[j] = w[j] >> 31;   // floor(w * 2 / 2^32)
+      uint32_t act[4];
+      philox_act4(q, my_key, 2, 1, act);   // A = 2: the packed stream, 128 one-bit actions per block
       const int pos0 = 4 * qi - rel0;
       if (rel0 == 0 && pos0 + 4 <= len) {
         *reinterpret_cast<uint32_t*>(dst + pos0) = act[0] | (act[1] << 8) | (act[2] << 16) | (act[3] << 24);

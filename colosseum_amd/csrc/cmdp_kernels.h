@@ -71,13 +71,12 @@ __global__ void k_mt_seed(uint32_t* __restrict__ mt, int32_t* __restrict__ mt_po
   mt_pos[i] = 0;
 }
 
-// random-policy action of transition n: word (n & 3) of the domain-2 Philox block n >> 2
+// random-policy action of transition n (the domain-2 stream of cmdp_device.h: packed when A is 2, 4, 16 or 256)
 __device__ __forceinline__ int philox_action(unsigned long long n, uint2 key, int A) {
-  uint32_t w[4];
-  philox4x32_10((uint32_t)(n >> 2), (uint32_t)(n >> 34), 2u, 0u, key.x, key.y, w);
+  uint32_t act[4];
+  philox_act4(n >> 2, key, A, philox_act_lg(A), act);
   const int j = (int)(n & 3);
-  const uint32_t word = (j == 0) ? w[0] : (j == 1) ? w[1] : (j == 2) ? w[2] : w[3];
-  return (int)(((uint64_t)word * (uint64_t)A) >> 32);
+  return (int)((j == 0) ? act[0] : (j == 1) ? act[1] : (j == 2) ? act[2] : act[3]);
 }
 
 // BaseMDP.reset (reference colosseum/mdp/base.py:1268-1277) for one instance
@@ -524,6 +523,7 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
   __syncthreads();
 
   // producer: fills ring buffer `buf` with the actions of transitions [first, first + len) of every instance
+  const int act_lg = philox_act_lg(A);
   auto produce = [&](int buf, int64_t first, int len) {
     const int ptid = tid - 64;  // 0..191
     const int per_slot = CH / 4 + 1;  // Philox blocks that can overlap a chunk window (unaligned start)
@@ -534,12 +534,12 @@ __global__ void __launch_bounds__(K1L_THREADS) k_rollout_lds(EnvTables t, LdsPla
       const unsigned long long q = (n0 >> 2) + (unsigned long long)qi;
       const uint2 key = keys[slot];
       uint32_t w[4];
-      philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), 2u, 0u, key.x, key.y, w);
+      philox_act4(q, key, A, act_lg, w);
       unsigned char* dst = ring + ((size_t)buf * p.G + slot) * CH;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const long long pos = (long long)(4 * q + j) - (long long)n0;
-        if (pos >= 0 && pos < len) dst[pos] = (unsigned char)(((uint64_t)w[j] * (uint64_t)A) >> 32);
+        if (pos >= 0 && pos < len) dst[pos] = (unsigned char)w[j];
       }
     }
   };
@@ -775,8 +775,7 @@ __global__ void __launch_bounds__(K1P_THREADS) k_rollout_pipe(EnvTables t, LdsPl
   // producer state: the lane's key, transition counter and ring row stay in registers
   const uint2 my_key = t.philox_key[b];
   const unsigned long long my_ntr = t.n_trans[b];
-  const bool a_pow2 = A > 1 && (A & (A - 1)) == 0;
-  const int a_shift = 32 - (31 - __clz(A | 1));  // A = 2^k: floor(w * A / 2^32) = w >> (32 - k)
+  const int act_lg = philox_act_lg(A);
   __syncthreads();
 
   // actions of transitions [first, first + len) of this lane's instance, Philox blocks pidx, pidx + K1P_NPROD, ...
@@ -789,11 +788,8 @@ __global__ void __launch_bounds__(K1P_THREADS) k_rollout_pipe(EnvTables t, LdsPl
     unsigned char* dst = ring + ((size_t)buf * p.G + lane) * AS;
     for (int qi = pidx; qi < nblk; qi += K1P_NPROD) {
       const unsigned long long q = q0 + (unsigned long long)qi;
-      uint32_t w[4], act[4];
-      philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), 2u, 0u, my_key.x, my_key.y, w);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        act[j] = a_pow2 ? (w[j] >> a_shift) : (uint32_t)(((uint64_t)w[j] * (uint64_t)A) >> 32);
+      uint32_t act[4];
+      philox_act4(q, my_key, A, act_lg, act);
       const int pos0 = 4 * qi - rel0;
       if (rel0 == 0 && pos0 + 4 <= len) {
         *reinterpret_cast<uint32_t*>(dst + pos0) = act[0] | (act[1] << 8) | (act[2] << 16) | (act[3] << 24);
@@ -1170,10 +1166,10 @@ __global__ void __launch_bounds__(256) k_rollout_dense(EnvTables t, DenseArgs dn
       x.u_lane = u53(r4[0], r4[1]);
       if (POLICY == 0) {
         const unsigned long long q = (x.base >> 2) + (unsigned long long)lane;
-        philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), 2u, 0u, x.key.x, x.key.y, r4);
+        philox_act4(q, x.key, t.A, philox_act_lg(t.A), r4);
         x.acts_lane = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x.acts_lane |= (uint32_t)(((uint64_t)r4[j] * (uint64_t)t.A) >> 32) << (8 * j);
+        for (int j = 0; j < 4; ++j) x.acts_lane |= r4[j] << (8 * j);
       }
     }
     // wave-uniform lane indices: v_readlane (scalar result, no LDS round trip) instead of a shuffle

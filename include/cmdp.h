@@ -50,8 +50,12 @@ enum {
   CMDP_RNG_MT_COMPAT = 0,
   /* Philox-4x32-10 keyed by the instance (counter-based, nothing stored per sampler):
      counter (n, domain): domain 0, n = transition index -> 53-bit transition uniform (stochastic rows);
-     domain 1, n = reset index -> start-state uniform; domain 2, n = transition index >> 2 -> word
-     (index & 3) gives the random-policy action (word * A) >> 32. */
+     domain 1, n = reset index -> start-state uniform; domain 2 -> random-policy actions (the reference's
+     RandomActor, colosseum/agent/actors/random.py:34-47, draws numpy blocks of 50 000; this is the
+     throughput stream): for A in {2, 4, 16, 256} the PACKED form -- block n / apb holds apb = 128 / log2(A)
+     actions, action k = n % apb in bits [lg (k % apw), +lg) of word k / apw, apw = 32 / lg (A = 2: 128
+     one-bit actions per block, least significant bit of word 0 first); for any other A, block n >> 2,
+     word (n & 3), a = (word * A) >> 32. */
   CMDP_RNG_PHILOX = 1
 };
 
@@ -245,7 +249,14 @@ int cmdp_calibrate(int what, int64_t n_steps, double* ns_per_step);
    instance, 128 instances per CU at config C2 instead of 52; taken automatically when eligible, 2 keeps K1L / K1P),
    5 = K1U, K1T's chain with the 16-bit trace streamed to HBM and histogrammed by a second kernel instead of 8-bit count
    deltas in LDS: up to 256 instances per CU resident at once (taken automatically when that saves a round of workgroups
-   over K1T -- config C2: one round instead of two; 4 keeps K1T).
+   over K1T -- config C2: one round instead of two; 4 keeps K1T),
+   6 = K1E, the EPISODE-PARALLEL rollout (a batch eligible for 2 that is episodic, has two actions, at most four distinct
+   reward values and at most 512 states per instance): lane = (instance, episode) -- under the random policy the episodes
+   of an instance are independent (fixed horizon, one start state: colosseum/mdp/base.py:1268-1277,1310-1317; the action
+   of transition n is a function of (key, n)), so a launch is walked as H-step chains, 4 096 of them per CU, against
+   private {successor | count} tables in LDS; the float64 reward sums are added in transition order by a second kernel
+   from 2-bit reward codes.  Taken automatically when eligible (launches of >= 64 transitions); 5 / 4 / 2 keep the
+   chain kernels.
    For 3: the automatic choice takes it while the batch is small enough that
    the HBM-table kernel's rate, which grows with the batch, stays below it -- FrozenLake 20x20: up to ~35 000 instances).
    CMDP_OPT_DP_KERNEL (Jacobi sweeps): 0 = automatic, 1 = workgroup kernel with the CSR in LDS or HBM,

@@ -38,19 +38,28 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def random_actions(keys, n0, n_steps, A):
-    """[n_steps, B] actions of transitions n0 .. n0+n_steps-1: word (n & 3) of the domain-2 block n >> 2, (word * A) >> 32
-    (include/cmdp.h, CMDP_RNG_PHILOX)."""
+    """[n_steps, B] actions of transitions n0 .. n0+n_steps-1 (Philox domain 2, include/cmdp.h CMDP_RNG_PHILOX): for A in
+    {2, 4, 16, 256} the PACKED stream -- block n // apb with apb = 128 / log2 A actions per block, action k = n % apb in bits
+    [lg * (k % apw), +lg) of word k // apw (apw = 32 / lg); otherwise word (n & 3) of block n >> 2, (word * A) >> 32."""
     keys = np.asarray(keys, np.uint64)
     k0, k1 = (keys & _LO).astype(np.uint32), (keys >> np.uint64(32)).astype(np.uint32)
     n = np.arange(n0, n0 + n_steps, dtype=np.uint64)
-    blocks = np.unique(n >> np.uint64(2))
+    lg = {2: 1, 4: 2, 16: 4, 256: 8}.get(int(A), 0)
+    apb = np.uint64(128 // lg if lg else 4)
+    blocks = np.unique(n // apb)
     B, nb = len(keys), len(blocks)
     blk = np.repeat(blocks[:, None], B, 1)
     w = philox4x32_10((blk & _LO).astype(np.uint32), (blk >> np.uint64(32)).astype(np.uint32), np.full((nb, B), 2, np.uint32),
                       np.zeros((nb, B), np.uint32), np.broadcast_to(k0, (nb, B)), np.broadcast_to(k1, (nb, B)))
     words = np.stack(w, 1)  # [nb, 4, B]
-    bi = ((n >> np.uint64(2)) - blocks[0]).astype(np.int64)
-    sel = words[bi, (n & np.uint64(3)).astype(np.int64)]  # [n_steps, B]
+    bi = (n // apb - blocks[0]).astype(np.int64)
+    k = n % apb
+    if lg:
+        apw = np.uint64(32 // lg)
+        sel = words[bi, (k // apw).astype(np.int64)].astype(np.uint64)  # [n_steps, B]
+        sh = (np.uint64(lg) * (k % apw))[:, None]
+        return ((sel >> sh) & np.uint64(A - 1)).astype(np.int64)
+    sel = words[bi, k.astype(np.int64)]
     return ((sel.astype(np.uint64) * np.uint64(A)) >> np.uint64(32)).astype(np.int64)
 
 

@@ -168,15 +168,25 @@ def test_lds_resident_rollout_equals_global_kernel_and_oracle(need_gpu):
     # horizon 5 < 8: several episode ends inside one group of 8 transitions; horizon 3: a row is arrived at every twelfth
     # transition, so K1T's 8-bit deltas wrap before its flush period is over (its overflow list is used)
     for size, n2 in ((12, 70_000), (5, 9_000), (3, 9_000)):
-        _check_lds_rollout(75, size, 50, n2, expect_k1t=True, k1t_g=50)   # K1T: groups of 50 and 25
+        _check_lds_rollout(75, size, 50, n2, expect_k1t=True, k1t_g=50, expect_k1e=True)   # K1T: groups of 50 and 25; K1E: 32 + 32 + 11
     # K1T with both halves of a workgroup in use (100 instances per group, the last group holds 61: half 1 empty)
-    _check_lds_rollout(261, 9, 50, 8_000, expect_k1t=True, k1t_g=100)
+    _check_lds_rollout(261, 9, 50, 8_000, expect_k1t=True, k1t_g=100, expect_k1e=True)
     # K1U with all four quarters of a workgroup in use (250 per group, the last group holds 97: quarters 2, 3 empty / ragged)
-    _check_lds_rollout(597, 7, 50, 4_000, expect_k1t=True, k1t_g=250)
+    _check_lds_rollout(597, 7, 50, 4_000, expect_k1t=True, k1t_g=250, expect_k1e=True)
+    # horizon 40 > 32: two code words per episode (K1E walks an episode in 32-step chunks)
+    _check_lds_rollout(70, 40, 77, 3_001, expect_k1e=False, k1t_g=35)   # 820 states: no room for 32 private tables -- K1E must refuse
+    t45 = deepsea_episodic_tables(np.arange(1000, 1070), 20)
+    t45["H"] = 45   # DeepSea-20's graph (the bottom row leads back to the start) under a horizon of 45: K1E's second code word
+    _check_lds_rollout(70, None, 77, 5_003, tables=t45, expect_k1e=True, k1t_g=35)
+    t33 = deepsea_episodic_tables(np.arange(1000, 1033), 9)
+    t33["H"] = 64   # exactly two full code words per episode; one full workgroup and one instance in the next
+    _check_lds_rollout(33, None, 64, 6_400, tables=t33, expect_k1e=True, k1t_g=20)
+    _check_lds_rollout(40, 31, 77, 9_001, expect_k1t=True, k1t_g=40, expect_k1e=True)
 
 
-def _check_lds_rollout(B, size, n1, n2, tables=None, models=None, expect_k1t=None, k1t_g=128):
-    """expect_k1t: True = the shared-table kernel must take the batch, False = it must refuse it, None = either."""
+def _check_lds_rollout(B, size, n1, n2, tables=None, models=None, expect_k1t=None, k1t_g=128, expect_k1e=None):
+    """expect_k1t: True = the shared-table kernel must take the batch, False = it must refuse it, None = either;
+    expect_k1e likewise for the episode-parallel kernel."""
     import os
 
     from colosseum_amd.mdp.fast_batch import deepsea_episodic_tables
@@ -195,9 +205,11 @@ def _check_lds_rollout(B, size, n1, n2, tables=None, models=None, expect_k1t=Non
     # pipeline K1T (CMDP_K1T_G: instances per workgroup, so that small batches exercise both halves and ragged groups)
     # ... and as K1U, K1T's chain with the trace streamed to HBM and histogrammed by a second kernel (CMDP_K1U_G likewise;
     # a launch longer than 32 768 transitions runs as several segments)
-    TMPL = (L.ROLLOUT_LDS_TEMPLATE, L.ROLLOUT_LDS_TEMPLATE_STREAM)
+    # ... and, for episodic two-action batches, as the episode-parallel kernel K1E (lane = (instance, episode); a launch
+    # longer than 61 440 transitions runs as several segments)
+    TMPL = (L.ROLLOUT_LDS_TEMPLATE, L.ROLLOUT_LDS_TEMPLATE_STREAM, L.ROLLOUT_EPISODE_PARALLEL)
     for which, pipe in ((L.ROLLOUT_GLOBAL, None), (L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1"), (L.ROLLOUT_LDS_TEMPLATE, "1"),
-                        (L.ROLLOUT_LDS_TEMPLATE_STREAM, "1")):
+                        (L.ROLLOUT_LDS_TEMPLATE_STREAM, "1"), (L.ROLLOUT_EPISODE_PARALLEL, "1")):
         saved = os.environ.pop("CMDP_K1L_PIPE", None)
         if pipe is not None:
             os.environ["CMDP_K1L_PIPE"] = pipe
@@ -220,9 +232,12 @@ def _check_lds_rollout(B, size, n1, n2, tables=None, models=None, expect_k1t=Non
         try:
             a = env.rollout(n1)  # odd transition count: the next launch starts mid Philox block and mid episode
         except L.CmdpError as e:  # K1T exists for A = 2 and action-permuted copies of one MDP; it must say so otherwise
-            assert which in TMPL and e.code == L.ERR_UNSUPPORTED and not expect_k1t, e
+            assert which in TMPL and e.code == L.ERR_UNSUPPORTED and not (expect_k1e if which == L.ROLLOUT_EPISODE_PARALLEL else expect_k1t), e
             env.close()
             continue
+        if which == L.ROLLOUT_EPISODE_PARALLEL:
+            plan = env.lds_plan()
+            assert expect_k1e is not False and plan["kernel"] == "k_rollout_epi" and plan["instances_per_workgroup"] == 32, plan
         if which == L.ROLLOUT_LDS_TEMPLATE:
             plan = env.lds_plan()
             assert expect_k1t is not False and plan["kernel"] == "k_rollout_tmpl" and plan["instances_per_workgroup"] == min(k1t_g, 128), plan
@@ -237,8 +252,11 @@ def _check_lds_rollout(B, size, n1, n2, tables=None, models=None, expect_k1t=Non
         env.close()
     if expect_k1t:
         assert (L.ROLLOUT_LDS_TEMPLATE, "1") in res and (L.ROLLOUT_LDS_TEMPLATE_STREAM, "1") in res
+    if expect_k1e:
+        assert (L.ROLLOUT_EPISODE_PARALLEL, "1") in res
     g = res[(L.ROLLOUT_GLOBAL, None)]
-    for key in ((L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1"), (L.ROLLOUT_LDS_TEMPLATE, "1"), (L.ROLLOUT_LDS_TEMPLATE_STREAM, "1")):
+    for key in ((L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1"), (L.ROLLOUT_LDS_TEMPLATE, "1"), (L.ROLLOUT_LDS_TEMPLATE_STREAM, "1"),
+                (L.ROLLOUT_EPISODE_PARALLEL, "1")):
         if key not in res:
             continue
         l = res[key]
@@ -262,7 +280,7 @@ def test_lds_rollout_continuous_and_other_families(need_gpu):
     for cls, kw, k1t in (("DeepSeaContinuous", dict(size=9), True), ("SimpleGridContinuous", dict(size=7), False),
                          ("MiniGridEmptyEpisodic", dict(size=6), False), ("RiverSwimEpisodic", dict(size=40), None)):
         models = [make_model(cls, seed=1000 + i, **kw) for i in range(B)]
-        _check_lds_rollout(B, None, 13, 9_001, models=models, expect_k1t=k1t, k1t_g=40)
+        _check_lds_rollout(B, None, 13, 9_001, models=models, expect_k1t=k1t, k1t_g=40, expect_k1e=False if "Continuous" in cls or cls.startswith("MiniGrid") else None)
 
 
 def test_lds_rollout_with_per_instance_episode_phase(need_gpu):
@@ -278,7 +296,7 @@ def test_lds_rollout_with_per_instance_episode_phase(need_gpu):
     n1, n2 = 13, 6_007
     res = {}
     for which, pipe in ((L.ROLLOUT_GLOBAL, None), (L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1"), (L.ROLLOUT_LDS_TEMPLATE, "1"),
-                        (L.ROLLOUT_LDS_TEMPLATE_STREAM, "1")):
+                        (L.ROLLOUT_LDS_TEMPLATE_STREAM, "1"), (L.ROLLOUT_EPISODE_PARALLEL, "1")):
         saved = os.environ.pop("CMDP_K1L_PIPE", None)
         if pipe is not None:
             os.environ["CMDP_K1L_PIPE"] = pipe
@@ -302,7 +320,8 @@ def test_lds_rollout_with_per_instance_episode_phase(need_gpu):
         res[(which, pipe)] = (out["last_obs"], out["reward_sum"], vs, vsa) + tuple(env.state())
         env.close()
     g = res[(L.ROLLOUT_GLOBAL, None)]
-    for key in ((L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1"), (L.ROLLOUT_LDS_TEMPLATE, "1"), (L.ROLLOUT_LDS_TEMPLATE_STREAM, "1")):
+    for key in ((L.ROLLOUT_LDS, "0"), (L.ROLLOUT_LDS, "1"), (L.ROLLOUT_LDS_TEMPLATE, "1"), (L.ROLLOUT_LDS_TEMPLATE_STREAM, "1"),
+                (L.ROLLOUT_EPISODE_PARALLEL, "1")):
         for x, y in zip(g, res[key]):
             np.testing.assert_array_equal(x, y)
     off = np.concatenate([[0], np.cumsum([m.n_states for m in models])])
