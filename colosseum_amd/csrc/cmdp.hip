@@ -210,6 +210,11 @@ struct cmdp {
   size_t k1e_lds = 0;
   DevBuf<uint32_t> d_etab;
   DevBuf<uint2> d_k1e_codes;
+  DevBuf<uint32_t> d_k1e_cnts;
+  DevBuf<int2> d_k1e_dep;          // departure counts of the K1E launches since the last fold (k_epi_fold)
+  DevBuf<int32_t> d_k1e_dep_res, d_vis_ovf;
+  bool k1e_pending = false;        // d_k1e_dep holds counts the visit counters do not have yet
+  int64_t k1e_pending_steps = 0;   // transitions per instance since the last fold (the departure image is int32)
   DevBuf<int32_t> d_k1e_h0;
   DevBuf<float> d_gp_q, d_gp_p;  // cmdp_greedy_policy_episodic workspace
   // K5S workspace (large-instance diameter)
@@ -279,10 +284,17 @@ int k1u_join(cmdp_t* h) {
   return CMDP_OK;
 }
 
+// ... and the departure counts the episode-parallel rollout K1E has accumulated are turned into the visit counters
+int k1e_fold(cmdp_t* h);
+int visits_join(cmdp_t* h) {
+  if (int rc = k1u_join(h)) return rc;
+  return k1e_fold(h);
+}
+
 int bind(cmdp_t* h, bool join = true) {
   if (!h) return fail(CMDP_ERR_INVALID, "null handle");
   HIP_TRY(hipSetDevice(h->device));
-  if (join) return k1u_join(h);
+  if (join) return visits_join(h);
   return CMDP_OK;
 }
 
@@ -298,6 +310,20 @@ template <typename K>
 int set_lds(K kernel, size_t bytes) {
   if (bytes > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return CMDP_OK;
+}
+
+int k1e_fold(cmdp_t* h) {
+  if (!h->k1e_pending) return CMDP_OK;
+  K1ePlan e = h->k1e;
+  e.dep = h->d_k1e_dep.p;
+  e.dep_res = h->d_k1e_dep_res.p;
+  const size_t lds = k1e_fold_lds_bytes(e);
+  if (int rc = set_lds(k_epi_fold, lds)) return rc;
+  hipLaunchKernelGGL(k_epi_fold, dim3(grid_for(h->B, K1E_NI)), dim3(K1E_THREADS), lds, h->stream, h->env(), e, h->d_vis_ovf.p);
+  HIP_TRY(hipGetLastError());
+  h->k1e_pending = false;
+  h->k1e_pending_steps = 0;
   return CMDP_OK;
 }
 
@@ -968,24 +994,29 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
           K1ePlan e{};
           e.S = max_S;
           e.H = h->H;
-          int slot = 16;
-          while (slot < ((max_S + 15) & ~15) * 8) slot <<= 1;
-          e.slot_bytes = slot;
           e.n_codes = (int)vals.size();
           e.nch = (h->H + 31) / 32;
           const int64_t pass_bits = (int64_t)K1E_EPP * h->H;
           int rb = 4;
           while (rb < (pass_bits + 127) / 128 + 1) rb <<= 1;
           e.ring_blocks = rb;
-          if (slot <= 65536 && k1e_lds_bytes(e) <= (size_t)kLdsBudget) {
-            std::vector<uint32_t> et((size_t)B * max_S);
-            for (int64_t sidx = 0; sidx < (int64_t)B * max_S; ++sidx) {
-              const RowDesc& r0 = rows[(size_t)(2 * sidx)];
-              const RowDesc& r1 = rows[(size_t)(2 * sidx + 1)];
-              const uint32_t w0 = ((uint32_t)r0.next_if_det << 3) | codes[(size_t)(2 * sidx)];
-              const uint32_t w1 = ((uint32_t)r1.next_if_det << 3) | codes[(size_t)(2 * sidx + 1)];
-              et[(size_t)sidx] = w0 | (w1 << 16);
-            }
+          e.ash = 7;
+          while ((1 << (e.ash - 7)) < max_S) ++e.ash;   // action stride: states padded to a power of two, 128 B per state
+          if (const char* de = std::getenv("CMDP_K1E_DEBUG")) {   // timing experiments: phases switched off
+            e.debug = std::atoi(de);
+            if (e.debug) std::fprintf(stderr, "libcmdp: CMDP_K1E_DEBUG=%d switches phases of k_rollout_epi off -- results are INVALID (timing experiments only)\n", e.debug);
+          }
+          if (max_S <= 512 && k1e_lds_bytes(e) <= (size_t)kLdsBudget) {
+            // interleaved by instance like the LDS image: [group of 32][state][instance in group]
+            const int64_t groups = ((int64_t)B + K1E_NI - 1) / K1E_NI;
+            std::vector<uint32_t> et((size_t)groups * max_S * K1E_NI, 0u);
+            for (int64_t b2 = 0; b2 < B; ++b2)
+              for (int s2 = 0; s2 < max_S; ++s2) {
+                const int64_t sidx = b2 * max_S + s2;
+                const uint32_t w0 = ((uint32_t)rows[(size_t)(2 * sidx)].next_if_det << 7) | codes[(size_t)(2 * sidx)];
+                const uint32_t w1 = ((uint32_t)rows[(size_t)(2 * sidx + 1)].next_if_det << 7) | codes[(size_t)(2 * sidx + 1)];
+                et[(size_t)((b2 / K1E_NI) * max_S + s2) * K1E_NI + (size_t)(b2 % K1E_NI)] = w0 | (w1 << 16);
+              }
             HIP_TRY(h->d_etab.upload(et.data(), et.size(), st));
             HIP_TRY(hipStreamSynchronize(st));
             e.etab = h->d_etab.p;
@@ -1294,6 +1325,11 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
   const dim3 grid(grid_for(h->B, 256)), block(256);
   const bool trace = d_tobs || d_trew || d_ttype;
   EnvTables t = h->env();
+  // K1E accumulates DEPARTURE counts over its launches (cmdp_k1e.h); every other kernel updates the visit counters itself,
+  // so the image is folded into them first
+  const bool take_k1e = !h->reward_cache && policy == CMDP_POLICY_RANDOM && h->layout != CMDP_LAYOUT_DENSE && h->lds_ok && !trace &&
+                        h->k1e_ok && n_steps > 0 && (h->rollout_kernel == 6 || (h->rollout_kernel == 0 && n_steps >= 64));
+  if (!take_k1e) { if (int rc = k1e_fold(h)) return rc; }
   if (h->reward_cache) {  // reference-exact reward caches: the lane-per-instance kernel with the park protocol
     const RewardCache rc = h->rcache();
 #define ROLL_RC(P, TR) \
@@ -1349,8 +1385,7 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
                                       "and room for 64 instances per workgroup");
   if (h->rollout_kernel == 6 && !(lds_eligible && h->k1e_ok))
     return fail(CMDP_ERR_UNSUPPORTED, "the episode-parallel rollout K1E needs a batch eligible for the LDS-resident kernels (CMDP_OPT_ROLLOUT_KERNEL 2) "
-                                      "that is episodic, has two actions, at most four distinct reward values and at most 512 states per instance");
-  const bool take_k1e = lds_eligible && h->k1e_ok && n_steps > 0 && (h->rollout_kernel == 6 || (h->rollout_kernel == 0 && n_steps >= 64));
+                                      "that is episodic, has two actions, at most four distinct reward values, at most 512 states per instance and a horizon whose action bits for 128 episodes fit LDS");
   if (take_k1e) {
     // K1E: per segment of <= K1E_SEG transitions (16-bit counts in the table dwords; the code buffer) the walk kernel, then
     // the reward scan over the code words it left in HBM
@@ -1358,14 +1393,28 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
     if (!h->ev_k1u[0])
       for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&h->ev_k1u[i]));
     K1ePlan e = h->k1e;
+    if (!h->d_k1e_dep.p) {
+      const size_t nd = (size_t)grid_for(h->B, K1E_NI) * (size_t)e.S * K1E_NI;
+      HIP_TRY(h->d_k1e_dep.alloc(nd));
+      HIP_TRY(h->d_k1e_dep.zero(st));
+      HIP_TRY(h->d_k1e_dep_res.alloc(h->B));
+      HIP_TRY(h->d_k1e_dep_res.zero(st));
+      HIP_TRY(h->d_vis_ovf.alloc(1));
+      HIP_TRY(h->d_vis_ovf.zero(st));
+    }
+    if (h->k1e_pending_steps + n_steps > 0x7fff0000LL) { if (int rc = k1e_fold(h)) return rc; }   // the departure image is int32
+    e.dep = h->d_k1e_dep.p;
+    e.dep_res = h->d_k1e_dep_res.p;
     // segment length: the code words of a segment (8 bytes per episode chunk and instance) stay within ~1.5 GB
-    const int64_t budget_words = std::max<int64_t>(4, (int64_t)((1536ll << 20) / (8 * (int64_t)h->B * e.nch)));
+    const int64_t budget_words = std::max<int64_t>(4, (int64_t)((1536ll << 20) / (12 * (int64_t)h->B * e.nch)));
     const int64_t seg = std::max<int64_t>(e.H, std::min<int64_t>(K1E_SEG, (budget_words - 2) * e.H));
     const int64_t epi_cap = k1e_max_episodes(std::min<int64_t>(n_steps, seg), e.H);
     const size_t need = (size_t)epi_cap * (size_t)e.nch * (size_t)h->B;
     if (h->d_k1e_codes.n < need) HIP_TRY(h->d_k1e_codes.alloc(need));
+    if (h->d_k1e_cnts.n < need) HIP_TRY(h->d_k1e_cnts.alloc(need));
     if (h->d_k1e_h0.n < (size_t)h->B) HIP_TRY(h->d_k1e_h0.alloc(h->B));
     e.codes = h->d_k1e_codes.p;
+    e.cnts = h->d_k1e_cnts.p;
     e.seg_h0 = h->d_k1e_h0.p;
     if (int rc = set_lds(k_rollout_epi, h->k1e_lds)) return rc;
     for (int64_t s0 = 0; s0 < n_steps; s0 += seg) {
@@ -1373,12 +1422,14 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
       e.n_pass = (int)((k1e_max_episodes(n, e.H) + K1E_EPP - 1) / K1E_EPP);
       const bool last = s0 + seg >= n_steps;
       if (last) HIP_TRY(hipEventRecord(h->ev_k1u[0], st));
-      hipLaunchKernelGGL(k_rollout_epi, dim3(grid_for(h->B, K1E_NI)), dim3(K1E_THREADS), h->k1e_lds, st, t, e, n, d_last);
+      hipLaunchKernelGGL(k_rollout_epi, dim3(grid_for(h->B, K1E_NI)), dim3(K1E_THREADS), h->k1e_lds, st, t, e, (int)n, d_last);
       if (last) HIP_TRY(hipEventRecord(h->ev_k1u[1], st));
       hipLaunchKernelGGL(k_reward_scan, dim3(grid_for(h->B, K1R_THREADS)), dim3(K1R_THREADS), 0, st, t, e, n, d_rsum, s0 > 0 ? 1 : 0);
       if (last) HIP_TRY(hipEventRecord(h->ev_k1u[2], st));
     }
     h->k1u_last_overlap = false;
+    h->k1e_pending = true;
+    h->k1e_pending_steps += n_steps;
     HIP_TRY(hipGetLastError());
     return CMDP_OK;
   }
@@ -1514,7 +1565,7 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
 
 int cmdp_rollout(cmdp_t* h, int policy, const void* policy_arg, int64_t n_steps, int32_t* last_obs, double* reward_sum,
                  int32_t* trace_obs, double* trace_reward, uint8_t* trace_type) {
-  if (int rc = bind(h)) return rc;
+  if (int rc = bind(h, false)) return rc;   // (launch_rollout joins what the kernel it takes needs joined)
   if (!h->has_env) return fail(CMDP_ERR_INVALID, "handle was created without the sampler half");
   if (n_steps < 0) return fail(CMDP_ERR_INVALID, "n_steps < 0");
   if (policy != CMDP_POLICY_RANDOM && policy != CMDP_POLICY_HOST_ACTIONS && policy != CMDP_POLICY_GREEDY_Q)

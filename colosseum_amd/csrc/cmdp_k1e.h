@@ -11,66 +11,88 @@
 //     (reference RandomActor, colosseum/agent/actors/random.py:34-47, is a seeded stream as well).
 // So transition n0 + e H + j of an instance can be walked without its predecessors: lane = (instance, episode), a chain is
 // H steps long, and a launch of 65 536 x 30 000 transitions is 65.5 M independent chains of 30 instead of 65 536 of 30 000.
-// The kernel is then bound by instruction and LDS THROUGHPUT, not by latency.
+// The kernel is then bound by instruction THROUGHPUT, not by latency (the integer VALU instructions of the step issue at
+// 4.4-4.8 cycles per wavefront, tools/calib/valu_int_rate.hip: the step is written to need four of them).
 //
 // k_rollout_epi -- one 1024-thread workgroup owns NI = 32 instances for the whole segment:
-//   LDS   per instance a PRIVATE table of S x 2 dwords {successor word : 16 | visit count : 16} in a slot of 2^k bytes, so
-//         that the address of the next read is ONE v_and_or_b32 of the word just read: (word & MASK) | (action << 2 | slot).
-//         The successor word is the byte offset of the successor's row pair inside the slot with the reward code in its two
-//         low bits.  The count of the ARRIVAL row under the action taken (base.py:1302-1303) is a no-return ds_add_u32 of
-//         0x10000 on the dword at that same address pattern.  States are stored at s ^ (i & 15) and actions at a ^ (i >> 4)
-//         (i = the instance's slot): the 32 lanes of an LDS lane group are 32 DIFFERENT instances -- no two lanes of a group
-//         ever add to the same dword -- and while they all sit at the same logical row (the first steps of an episode) they
-//         hit 32 different banks.
-//   lanes lane = (instance l & 31, half l >> 5); pass p gives every instance its episodes 64 p .. 64 p + 63: wavefront w,
-//         half s, chain c in {0, 1} walks episode 64 p + 4 w + 2 s + c -- two independent chains per lane, interleaved.
-//   bits  the action bits of a pass (64 H per instance) come from a ring of Philox blocks in LDS that all wavefronts fill
-//         for pass p + 1 before they walk pass p (one barrier per pass); a chain fetches its 32 bits with one funnel shift.
-//         Every bit of every block is used (cmdp_device.h: the packed domain-2 stream) -- 0.8 VALU instructions per
-//         transition instead of the 25 a whole block per four one-bit actions cost K1U.
-//   step  v_bfe (action bit) . v_lshl_or (| slot) . v_and_or (address) . ds_read_u16 . v_and_or . ds_add_u32 . v_alignbit
-//         (reward code into the episode's code word): 5 VALU + 2 LDS instructions, none of them waiting on another chain.
+//   LDS   every instance has a PRIVATE table of S x 2 dwords {visit count : 16 | successor word : 16}, and the 32 tables are
+//         INTERLEAVED dword by dword: row (s, a) of instance i lives at byte a * 2^ASH + s * 128 + 4 i.  The 32 lanes of an
+//         LDS lane group are the 32 instances, so lane i only ever touches bank i: every access of the walk is
+//         bank-conflict-free whatever the states are (a slot per instance measured 76 % of the LDS cycles as conflicts: 32
+//         random dwords over 32 banks collide 3.5-fold), and no two lanes ever add to the same dword.  The successor word
+//         is s' << 7 | reward code: the address of the next row is ONE v_and_or_b32, (word & 0xff80) | (action << ASH | 4 i).
+//   step  v_bfe (action bit) . v_lshl_or (| lane base) . v_and_or (address) . ds_add_rtn_u32 0x10000 . v_alignbit (reward
+//         code into the episode's code word): the returning atomic IS the table read -- it counts the row the chain LEAVES
+//         and hands back its successor word: 4 VALU + 1 LDS instruction per transition.
+//   lanes lane = (instance l & 31, half l >> 5); pass p gives every instance its episodes 128 p .. 128 p + 127: wavefront w,
+//         half s, chain c in {0 .. 3} walks episode 128 p + 8 w + 4 s + c -- four independent chains per lane, their reads
+//         issued together.
+//   bits  the action bits of a pass (128 H per instance) come from a ring of Philox blocks in LDS (interleaved like the
+//         tables) that all wavefronts fill before they walk the pass -- one block per thread; a chain fetches its 32 bits
+//         with one funnel shift.  Every bit of every block is used (cmdp_device.h: the packed domain-2 stream): 0.8 VALU
+//         instructions per transition instead of the 25 a whole block per four one-bit actions cost K1U.
+//   flush the reference counts the ARRIVAL state under the action taken (base.py:1302-1303): visits_sa[s'][a] is the sum of
+//         the departure counts of the rows (s, a) with successor s' -- formed per instance by LDS atomics into a scratch
+//         image (the ring's space), then added to visits_sa / visits_s (+ the resets of the start state) by coalesced
+//         read-modify-writes, a wavefront per instance.
 //   out   the reward codes of an episode (2 bits per step) go to HBM, 8 bytes per (episode, 32-step chunk), layout
-//         codes[episode][chunk][instance]; the counts are flushed into visits_sa / visits_s by coalesced read-modify-writes
-//         (+ the resets of the start state); state, in-episode time and the Philox counters are advanced as if the
-//         transitions had been taken one by one.
-// k_reward_scan -- lane = instance: the float64 reward sum in TRANSITION ORDER from the code words (sum += value[code], one
-//         add per transition, sequential: bit-equal to the oracle's and every other kernel's sum).
+//         codes[episode][chunk][instance], with the number of steps per code next to them; state, in-episode time and the
+//         Philox counters are advanced as if the transitions had been taken one by one.
+// k_reward_scan -- lane = instance: the float64 reward sum in TRANSITION ORDER from the code words (bit-equal to the
+//         oracle's and every other kernel's sequential sum).
 // Results: visit counts, final states, in-episode times, Philox counters and reward sums bit-equal to K1 / K1T / K1U and the
 // CPU oracle (tests/test_gpu_parity.py, tests/test_gpu_fullsize.py, tools/stress_k1t.py k1e, tools/fuzz_parity.py).
 #pragma once
 
 #define K1E_THREADS 1024
 #define K1E_NW (K1E_THREADS / 64)
-#define K1E_NI 32                          // instances per workgroup: the 32 lanes of an LDS lane group
+#define K1E_NI 32                          // instances per workgroup: the 32 lanes of an LDS lane group, one bank each
 #define K1E_EPL 4                          // chains (episodes) per lane
 #define K1E_EPP (K1E_NW * 2 * K1E_EPL)     // episodes of one instance per pass (128)
 #define K1E_SEG 61440                      // transitions per segment (< 65 536: the 16-bit counts in the table dwords)
-#define K1E_DUMMY 16                       // bytes behind the slots: the self-looping dummy row idle chains walk
+#define K1E_SMASK 0xff80u                  // the state field of a successor word (s' << 7; reward code in bits 1:0)
 
 struct K1ePlan {
   int32_t S, H;
-  int32_t slot_bytes;        // power of two >= roundup16(S) * 8
-  int32_t ring_blocks;       // power of two: Philox blocks of an instance's action-bit ring
+  int32_t ash;               // log2 of the action stride in bytes: 7 + log2(SP), SP = states padded to a power of two
+  int32_t ring_blocks;       // power of two: Philox blocks of an instance's action-bit ring (one pass)
   int32_t n_codes;           // <= 4 distinct reward values (2-bit codes)
   int32_t nch;               // 32-step chunks per episode, ceil(H / 32)
   int32_t n_pass;            // passes of this segment (uniform over the workgroups)
-  const uint32_t* etab;      // [B][S] one dword per state: successor words of action 0 (low) and 1 (high), s' * 8 | code
+  int32_t debug;             // CMDP_K1E_DEBUG (timing experiments, results INVALID): 1 no walk, 2 no flush, 4 no Philox, 8 no code stores
+  const uint32_t* etab;      // [group of 32 instances][S][32]: one dword per state, successor words of action 0 (low half)
+                             // and 1 (high half), s' << 7 | code; interleaved by instance like the LDS image
   const double* rvals;       // [n_codes]
-  uint2* codes;              // [episode][chunk][B]
+  uint2* codes;              // [episode][chunk][B] 2-bit reward codes of the chunk's steps, step j at bits 2 j
+  uint32_t* cnts;            // [episode][chunk][B] steps of the chunk with reward code 1 | code 2 << 8 | code 3 << 16
   int32_t* seg_h0;           // [B] in-episode time at the start of the segment (k_reward_scan decodes the episodes with it)
+  int2* dep;                 // [group][S][32] DEPARTURE counts (action 0, action 1) accumulated over launches, interleaved like
+                             // the LDS image; k_epi_fold turns them into the reference's arrival counts when they are needed
+  int32_t* dep_res;          // [B] episode resets not yet added to visits_s of the start state
 };
 
+// LDS: tables (2 actions x SP states x 32 instances x 4 B) | dummy rows (32 dwords) | ring (ring_blocks x 4 dwords x 32) |
+// meta (64 dwords)
+__host__ __device__ inline size_t k1e_tab_bytes(const K1ePlan& p) { return (size_t)2 << p.ash; }
 __host__ __device__ inline size_t k1e_lds_bytes(const K1ePlan& p) {
-  return (size_t)K1E_NI * (size_t)p.slot_bytes + K1E_DUMMY + (size_t)K1E_NI * (size_t)p.ring_blocks * 16 + 8 * K1E_NI;
+  return k1e_tab_bytes(p) + 128 + (size_t)p.ring_blocks * 512 + 8 * K1E_NI;
 }
+__host__ __device__ inline size_t k1e_fold_lds_bytes(const K1ePlan& p) { return (size_t)2 * K1E_NI * (size_t)p.S * 4; }
 __host__ __device__ inline int64_t k1e_max_episodes(int64_t n_steps, int H) { return (n_steps + 2 * (int64_t)H - 2) / H; }
 
-typedef __attribute__((address_space(3))) uint32_t* k1e_lds_u32;
-typedef const __attribute__((address_space(3))) uint16_t* k1e_lds_cu16;
-typedef const __attribute__((address_space(3))) uint32_t* k1e_lds_cu32;
+// steps of a code word (2-bit fields, unused fields zero) with code 1, 2, 3: n1 | n2 << 8 | n3 << 16
+__device__ __forceinline__ uint32_t k1e_code_counts(uint32_t lo, uint32_t hi) {
+  const uint32_t l0 = lo & 0x55555555u, l1 = (lo >> 1) & 0x55555555u;
+  const uint32_t h0 = hi & 0x55555555u, h1 = (hi >> 1) & 0x55555555u;
+  const uint32_t n3 = __popc(l0 & l1) + __popc(h0 & h1);
+  const uint32_t n1 = __popc(l0 & ~l1) + __popc(h0 & ~h1);
+  const uint32_t n2 = __popc(~l0 & l1) + __popc(~h0 & h1);
+  return n1 | (n2 << 8) | (n3 << 16);
+}
 
-__global__ void __launch_bounds__(K1E_THREADS) k_rollout_epi(EnvTables t, K1ePlan p, int64_t n_steps,
+typedef __attribute__((address_space(3))) uint32_t* k1e_lds_u32;
+
+__global__ void __launch_bounds__(K1E_THREADS) k_rollout_epi(EnvTables t, K1ePlan p, int n_steps,
                                                             int32_t* __restrict__ last_obs) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -81,139 +103,138 @@ __global__ void __launch_bounds__(K1E_THREADS) k_rollout_epi(EnvTables t, K1ePla
   const bool owner = inst < nb;
   const int b = g0 + (owner ? inst : 0);
   const int S = p.S, H = p.H;
-  const uint32_t slot = (uint32_t)p.slot_bytes;
-  const uint32_t MASK = slot - 8u;                       // the state field of a successor word (byte offset of the row pair)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;   // 0: no static LDS here
-  const uint32_t dummy = lds0 + K1E_NI * slot;           // aligned like a slot: (word & MASK) | x works on it too
-  const uint32_t RD = (uint32_t)p.ring_blocks * 4u;      // ring dwords per instance
+  const uint32_t tab_bytes = 2u << p.ash;
+  const uint32_t a_words = (1u << p.ash) >> 2;           // dwords between the two actions' images
   uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
-  uint32_t* ring = reinterpret_cast<uint32_t*>(smem + (size_t)K1E_NI * slot + K1E_DUMMY);
+  uint32_t* ring = reinterpret_cast<uint32_t*>(smem + tab_bytes + 128);
+  const uint32_t RD = (uint32_t)p.ring_blocks * 4u;      // ring dwords per instance
   int32_t* meta = reinterpret_cast<int32_t*>(ring + (size_t)K1E_NI * RD);   // [NI] episode resets of the segment, [NI] start states
-  const uint32_t swz = (uint32_t)inst & 15u, fa = (uint32_t)inst >> 4;
-  const uint32_t ibase = lds0 + (uint32_t)inst * slot;
+  const uint32_t lbase = lds0 + 4u * (uint32_t)inst;     // the lane's bank
+  const uint32_t dbase = lbase + tab_bytes;              // ... and its dummy row (word 0 -> itself; idle chains play action 0)
 
-  // ---- stage: private tables {successor word | count 0}, states at s ^ swz, actions at a ^ fa, words re-based likewise ----
-  const int64_t so0 = t.state_off[g0];
-  for (int k = tid; k < nb * S; k += K1E_THREADS) {
-    const int i = k / S, s = k - i * S;
-    const uint32_t pair = p.etab[(size_t)(g0 + i) * S + s];
-    const uint32_t sw = (uint32_t)i & 15u, f = (uint32_t)i >> 4;
-    const uint32_t w0 = (pair & 0xffffu) ^ (sw << 3), w1 = (pair >> 16) ^ (sw << 3);
-    uint32_t* row = tab + (size_t)i * (slot / 4) + (((uint32_t)s ^ sw) << 1);
-    row[f] = w0;
-    row[f ^ 1u] = w1;
-  }
-  if (tid < K1E_DUMMY / 4) tab[(size_t)K1E_NI * (slot / 4) + tid] = 0u;
-  if (tid < nb) {
-    meta[tid] = (int32_t)(((int64_t)t.hstep[g0 + tid] + n_steps) / H);
-    meta[K1E_NI + tid] = t.start_state[t.start_off[g0 + tid]];
+  // ---- stage: {count 0 | successor word}; the HBM image is interleaved like the LDS one: coalesced, conflict-free ----
+  {
+    const uint32_t* src = p.etab + (size_t)blockIdx.x * (size_t)S * K1E_NI;
+    for (int k = tid; k < S * K1E_NI; k += K1E_THREADS) {   // k = s * 32 + i
+      const uint32_t pair = src[k];
+      tab[k] = pair & 0xffffu;
+      tab[a_words + k] = pair >> 16;
+    }
+    if (tid < 32) tab[2 * a_words + tid] = 0u;
+    if (tid < nb) {
+      meta[tid] = (int32_t)(((int64_t)t.hstep[g0 + tid] + n_steps) / H);
+      meta[K1E_NI + tid] = t.start_state[t.start_off[g0 + tid]];
+    }
   }
 
   const uint2 key = t.philox_key[b];
   const unsigned long long ntr = t.n_trans[b];
+  const uint32_t ntr_lo = (uint32_t)ntr;
   const int h0 = t.hstep[b];
   const int32_t cur0 = t.cur[b];
   const int32_t start = t.start_state[t.start_off[b]];
-  const uint32_t ring_i = (uint32_t)inst * RD;   // dword index of the instance's ring
+  const unsigned long long blk0 = ntr >> 7;               // first Philox block of the segment
+  const int off0 = (int)(ntr & 127ull);
 
-  // last Philox block (index) needed by the episodes of passes 0 .. q; the blocks of pass q are (lastblk(q-1), lastblk(q)]
-  auto lastblk = [&](int q) -> long long {
-    const int64_t e_end = (int64_t)(q + 1) * K1E_EPP;               // first episode behind pass q
-    int64_t end = e_end * H - h0;                                    // its first transition
-    if (end > n_steps) end = n_steps;
-    return (long long)((ntr + (unsigned long long)end - 1ull) >> 7);   // n_steps >= 1
+  // last Philox block (relative to blk0) needed by the episodes of passes 0 .. q; pass q's new blocks are (lastblk(q-1), lastblk(q)]
+  auto lastblk = [&](int q) -> int {
+    const int end = min(n_steps, (q + 1) * K1E_EPP * H - h0);   // first transition behind pass q (n_steps <= K1E_SEG: int)
+    return (off0 + end - 1) >> 7;
   };
+  // ring dword d of the instance lives at ring[d * 32 + inst]: the producers' stores and the chains' fetches stay in bank i
   auto produce = [&](int q) {
     if (!owner) return;
-    const long long lo = q == 0 ? (long long)(ntr >> 7) : lastblk(q - 1) + 1, hi = lastblk(q);
-    for (long long blk = lo + (tid >> 5); blk <= hi; blk += K1E_THREADS / 32) {
+    // (a pass may start inside block lastblk(q - 1): it is still in the ring -- the ring holds a pass's blocks plus one)
+    const int lo = q == 0 ? 0 : lastblk(q - 1) + 1, hi = lastblk(q);
+    for (int rb = lo + (tid >> 5); rb <= hi; rb += K1E_THREADS / 32) {
+      const unsigned long long blk = blk0 + (unsigned long long)rb;
       uint32_t w[4];
-      philox4x32_10((uint32_t)blk, (uint32_t)((unsigned long long)blk >> 32), 2u, 0u, key.x, key.y, w);
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-      u32x4 v;
-      v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
-      *reinterpret_cast<u32x4*>(ring + ring_i + (((uint32_t)blk & ((uint32_t)p.ring_blocks - 1u)) << 2)) = v;
+      philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), 2u, 0u, key.x, key.y, w);
+      const uint32_t d0 = ((uint32_t)blk & ((uint32_t)p.ring_blocks - 1u)) << 2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ring[(size_t)(d0 + j) * K1E_NI + inst] = w[j];
     }
   };
-  // the 32 action bits from absolute transition `a0` on (already in the slot's action polarity)
-  auto fetch_bits = [&](unsigned long long a0) -> uint32_t {
-    const uint32_t di = (uint32_t)(a0 >> 5) & (RD - 1u);
-    const uint32_t d0 = ring[ring_i + di], d1 = ring[ring_i + ((di + 1u) & (RD - 1u))];
-    const uint32_t bits = __builtin_amdgcn_alignbit(d1, d0, (uint32_t)a0 & 31u);
-    return fa ? ~bits : bits;
+  // the 32 action bits from transition `rel` of the segment on
+  auto fetch_bits = [&](int rel) -> uint32_t {
+    const uint32_t a0 = ntr_lo + (uint32_t)rel;
+    const uint32_t di = (a0 >> 5) & (RD - 1u);
+    const uint32_t d0 = ring[di * K1E_NI + inst], d1 = ring[((di + 1u) & (RD - 1u)) * K1E_NI + inst];
+    return __builtin_amdgcn_alignbit(d1, d0, a0 & 31u);
   };
 
+  const int nch = p.nch;
+  const uint32_t ash = (uint32_t)p.ash;
   for (int pass = 0; pass < p.n_pass; ++pass) {
     // the action bits of this pass (the ring holds ONE pass: fill, barrier, walk, barrier -- the fill is one Philox block
-    // per thread, the same for every wavefront)
-    produce(pass);
+    // per thread, the same work for every wavefront)
+    if (!(p.debug & 4)) produce(pass);
     __syncthreads();
-    // ---- the lane's chains of this pass ----
-    int64_t first[K1E_EPL];
-    int hs[K1E_EPL], len[K1E_EPL];
+    // ---- the lane's chains of this pass (everything relative to the segment fits an int: n_steps <= K1E_SEG) ----
+    int first[K1E_EPL], len[K1E_EPL];
     bool valid[K1E_EPL], full[K1E_EPL];
     uint32_t w[K1E_EPL], x0[K1E_EPL];
-    const int64_t e0 = (int64_t)pass * K1E_EPP + (int64_t)((wave * 2 + sub) * K1E_EPL);
+    const int e0 = pass * K1E_EPP + (wave * 2 + sub) * K1E_EPL;
 #pragma unroll
     for (int c = 0; c < K1E_EPL; ++c) {
-      const int64_t e = e0 + c;
+      const int e = e0 + c;
       first[c] = e == 0 ? 0 : e * H - h0;
       valid[c] = owner && first[c] < n_steps;
-      hs[c] = e == 0 ? h0 : 0;
-      const int64_t room = n_steps - first[c];
-      len[c] = valid[c] ? (int)min((int64_t)(H - hs[c]), room) : 0;
-      full[c] = valid[c] && len[c] == H;
-      const uint32_t s_from = (uint32_t)(e == 0 ? cur0 : start);
-      // a chain that is not walked at full length in the fast loop idles on the dummy row (word 0 -> itself)
-      w[c] = full[c] ? ((s_from ^ swz) << 3) : 0u;
-      x0[c] = full[c] ? ibase : dummy;
+      len[c] = valid[c] ? min(e == 0 ? H - h0 : H, n_steps - first[c]) : 0;
+      full[c] = len[c] == H;
+      // a chain that is not walked at full length in the fast loop idles on the lane's dummy row
+      w[c] = full[c] ? ((uint32_t)(e == 0 ? cur0 : start) << 7) : 0u;
+      x0[c] = full[c] ? lbase : dbase;
     }
     bool any_full = false;
 #pragma unroll
     for (int c = 0; c < K1E_EPL; ++c) any_full |= full[c];
 
     // ---- fast loop: full episodes, uniform trip counts; lanes without any full chain are masked off as a whole ----
-    if (any_full) {
-      for (int ch = 0; ch < p.nch; ++ch) {
+    if (any_full && !(p.debug & 1)) {
+      for (int ch = 0; ch < nch; ++ch) {
         const int L = min(32, H - 32 * ch);
         uint32_t bits[K1E_EPL], clo[K1E_EPL], chi[K1E_EPL];
 #pragma unroll
         for (int c = 0; c < K1E_EPL; ++c) {
-          bits[c] = fetch_bits(ntr + (unsigned long long)(first[c] + 32 * ch));
+          const uint32_t fb = fetch_bits(first[c] + 32 * ch);
+          bits[c] = full[c] ? fb : 0u;
           clo[c] = 0u; chi[c] = 0u;
         }
-        // one step of all the lane's chains: the reads of all chains are issued before the first is waited for
+        // one step of all the lane's chains: the atomics of all chains are issued before the first is waited for
         auto steps = [&](int j, uint32_t (&cw)[K1E_EPL]) {
-          uint32_t x[K1E_EPL], ra[K1E_EPL];
+          uint32_t ra[K1E_EPL];
 #pragma unroll
           for (int c = 0; c < K1E_EPL; ++c) {
             const uint32_t a = __builtin_amdgcn_ubfe(bits[c], (uint32_t)j, 1u);
-            x[c] = (a << 2) | x0[c];
-            ra[c] = (w[c] & MASK) | x[c];
+            ra[c] = (w[c] & K1E_SMASK) | ((a << ash) | x0[c]);
           }
 #pragma unroll
-          for (int c = 0; c < K1E_EPL; ++c) w[c] = (uint32_t)*(k1e_lds_cu16)(uintptr_t)ra[c];
+          for (int c = 0; c < K1E_EPL; ++c)   // counts the row the chain leaves, returns {old count | successor word}
+            w[c] = __hip_atomic_fetch_add((k1e_lds_u32)(uintptr_t)ra[c], 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-          for (int c = 0; c < K1E_EPL; ++c) {
-            const uint32_t ca = (w[c] & MASK) | x[c];   // arrival row under the action taken (base.py:1302-1303)
-            (void)__hip_atomic_fetch_add((k1e_lds_u32)(uintptr_t)ca, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            cw[c] = __builtin_amdgcn_alignbit(w[c], cw[c], 2u);
-          }
+          for (int c = 0; c < K1E_EPL; ++c) cw[c] = __builtin_amdgcn_alignbit(w[c], cw[c], 2u);
         };
         const int L0 = min(L, 16);
 #pragma unroll 2
         for (int j = 0; j < L0; ++j) steps(j, clo);
 #pragma unroll 2
         for (int j = 16; j < L; ++j) steps(j, chi);
+        if (!(p.debug & 8)) {
+          uint32_t wi = ((uint32_t)e0 * (uint32_t)nch + (uint32_t)ch) * (uint32_t)t.B + (uint32_t)b;
 #pragma unroll
-        for (int c = 0; c < K1E_EPL; ++c) {
-          if (full[c]) {
-            const uint32_t lo = L0 < 16 ? clo[c] >> (32 - 2 * L0) : clo[c];
-            const uint32_t hi = L > 16 ? (L < 32 ? chi[c] >> (32 - 2 * (L - 16)) : chi[c]) : 0u;
-            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-            u32x2 v;
-            v.x = lo; v.y = hi;
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(p.codes) + ((size_t)(e0 + c) * p.nch + ch) * (size_t)t.B + b);
+          for (int c = 0; c < K1E_EPL; ++c) {
+            if (full[c]) {
+              const uint32_t lo = L0 < 16 ? clo[c] >> (32 - 2 * L0) : clo[c];
+              const uint32_t hi = L > 16 ? (L < 32 ? chi[c] >> (32 - 2 * (L - 16)) : chi[c]) : 0u;
+              typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+              u32x2 v;
+              v.x = lo; v.y = hi;
+              __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(p.codes) + wi);
+              __builtin_nontemporal_store(k1e_code_counts(lo, hi), p.cnts + wi);
+            }
+            wi += (uint32_t)nch * (uint32_t)t.B;
           }
         }
       }
@@ -222,21 +243,20 @@ __global__ void __launch_bounds__(K1E_THREADS) k_rollout_epi(EnvTables t, K1ePla
 #pragma unroll
     for (int c = 0; c < K1E_EPL; ++c) {
       if (valid[c] && !full[c]) {
-        uint32_t ws = ((uint32_t)((e0 + c) == 0 ? cur0 : start) ^ swz) << 3;
+        uint32_t ws = (uint32_t)((e0 + c) == 0 ? cur0 : start) << 7;
         for (int j0 = 0; j0 < len[c]; j0 += 32) {
           const int L = min(32, len[c] - j0);
-          const uint32_t bits = fetch_bits(ntr + (unsigned long long)(first[c] + j0));
+          const uint32_t bits = fetch_bits(first[c] + j0);
           uint32_t lo = 0u, hi = 0u;
           for (int j = 0; j < L; ++j) {
             const uint32_t a = (bits >> j) & 1u;
-            const uint32_t x = (a << 2) | ibase;
-            const uint32_t ra = (ws & MASK) | x;
-            ws = (uint32_t)*(k1e_lds_cu16)(uintptr_t)ra;
-            const uint32_t ca = (ws & MASK) | x;
-            (void)__hip_atomic_fetch_add((k1e_lds_u32)(uintptr_t)ca, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t ra = (ws & K1E_SMASK) | ((a << ash) | lbase);
+            ws = __hip_atomic_fetch_add((k1e_lds_u32)(uintptr_t)ra, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (j < 16) lo |= (ws & 3u) << (2 * j); else hi |= (ws & 3u) << (2 * (j - 16));
           }
-          p.codes[((size_t)(e0 + c) * p.nch + (j0 >> 5)) * (size_t)t.B + b] = make_uint2(lo, hi);
+          const uint32_t wi = ((uint32_t)(e0 + c) * (uint32_t)nch + (uint32_t)(j0 >> 5)) * (uint32_t)t.B + (uint32_t)b;
+          p.codes[wi] = make_uint2(lo, hi);
+          p.cnts[wi] = k1e_code_counts(lo, hi);
         }
         w[c] = ws;
       }
@@ -245,9 +265,9 @@ __global__ void __launch_bounds__(K1E_THREADS) k_rollout_epi(EnvTables t, K1ePla
 #pragma unroll
     for (int c = 0; c < K1E_EPL; ++c) {
       if (valid[c] && first[c] + len[c] == n_steps) {
-        const int hend = hs[c] + len[c];
+        const int hend = ((e0 + c) == 0 ? h0 : 0) + len[c];
         const bool term = hend >= H;
-        const int32_t cur = term ? start : (int32_t)(((w[c] & MASK) >> 3) ^ swz);
+        const int32_t cur = term ? start : (int32_t)((w[c] & K1E_SMASK) >> 7);
         t.cur[b] = cur;
         t.hstep[b] = term ? 0 : hend;
         if (last_obs) last_obs[b] = cur;
@@ -256,76 +276,251 @@ __global__ void __launch_bounds__(K1E_THREADS) k_rollout_epi(EnvTables t, K1ePla
     __syncthreads();
   }
 
-  // ---- flush: counts of the slots into visits_sa / visits_s (+ the resets of the start state) ----
   if (wave == 0 && sub == 0 && owner) {
     t.n_trans[b] = ntr + (unsigned long long)n_steps;
     t.n_reset[b] += (unsigned long long)(((int64_t)h0 + n_steps) / H);
     p.seg_h0[b] = h0;
   }
-  for (int k = tid; k < nb * S; k += K1E_THREADS) {
-    const int i = k / S, s = k - i * S;
-    const uint32_t sw = (uint32_t)i & 15u, f = (uint32_t)i >> 4;
-    const uint32_t* row = tab + (size_t)i * (slot / 4) + (((uint32_t)s ^ sw) << 1);
-    const uint32_t c0 = row[f] >> 16, c1 = row[f ^ 1u] >> 16;
-    int32_t add_s = (int32_t)(c0 + c1);
-    if (s == meta[K1E_NI + i]) add_s += meta[i];
-    if (add_s) t.visits_s[so0 + k] += add_s;
-    if (c0 | c1) {
-      int2* sa = reinterpret_cast<int2*>(t.visits_sa + (so0 + k) * 2);
-      int2 v = *sa;
-      v.x += (int32_t)c0;
-      v.y += (int32_t)c1;
-      *sa = v;
+  if (p.debug & 2) return;
+  // ---- flush.  The table dwords hold DEPARTURE counts (row (s, a) left); they are added to the launch-spanning departure
+  // image in HBM, which has the layout of the LDS image: a straight coalesced, conflict-free pass.  The reference's ARRIVAL
+  // counts (base.py:1302-1303) are a linear function of them, formed by k_epi_fold when somebody needs the counters ----
+  {
+    int2* dep = p.dep + (size_t)blockIdx.x * (size_t)S * K1E_NI;
+    for (int k = tid; k < S * K1E_NI; k += K1E_THREADS) {
+      const uint32_t c0 = tab[k] >> 16, c1 = tab[a_words + k] >> 16;
+      if (c0 | c1) {
+        int2 v = dep[k];
+        v.x += (int32_t)c0;
+        v.y += (int32_t)c1;
+        dep[k] = v;
+      }
     }
+    if (tid < nb) p.dep_res[g0 + tid] += meta[tid];
   }
 }
 
-// The float64 reward sums of a segment, in transition order: lane = instance, one add per transition (sequential by
-// definition of the sum: float64 addition does not associate and the oracle adds reward by reward).  An episode's code word
-// holds the 2-bit reward codes of its steps, step j of a 32-step chunk at bits 2 j of the 64-bit word.
+// Departure counts -> the reference's visit counters.  BaseMDP.step counts the ARRIVAL node under the action taken
+// (colosseum/mdp/base.py:1302-1303): visits_sa[s'][a] += sum of the departures of the rows (s, a) whose successor is s',
+// visits_s[s'] += both actions' arrivals (+ the resets, which count the start state: base.py:1268-1277).  One workgroup per
+// group of 32 instances; arrival images [action][instance][state] in LDS filled by atomics, then coalesced read-modify-writes
+// (a wavefront per instance); the departure image is cleared.  Counters saturate at INT32_MAX and raise *overflow.
+__global__ void __launch_bounds__(K1E_THREADS) k_epi_fold(EnvTables t, K1ePlan p, int32_t* __restrict__ overflow) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t* arr0 = reinterpret_cast<uint32_t*>(smem);
+  const int S = p.S;
+  uint32_t* arr1 = arr0 + (size_t)K1E_NI * S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g0 = blockIdx.x * K1E_NI;
+  const int nb = min(K1E_NI, t.B - g0);
+  for (int k = tid; k < 2 * K1E_NI * S; k += K1E_THREADS) arr0[k] = 0u;
+  __syncthreads();
+  int2* dep = p.dep + (size_t)blockIdx.x * (size_t)S * K1E_NI;
+  const uint32_t* et = p.etab + (size_t)blockIdx.x * (size_t)S * K1E_NI;
+  for (int k = tid; k < S * K1E_NI; k += K1E_THREADS) {   // k = s * 32 + i
+    const int2 c = dep[k];
+    if (c.x | c.y) {
+      const uint32_t pair = et[k];
+      const int i = k & 31;
+      if (c.x) atomicAdd(&arr0[i * S + (int)((pair & K1E_SMASK) >> 7)], (uint32_t)c.x);
+      if (c.y) atomicAdd(&arr1[i * S + (int)(((pair >> 16) & K1E_SMASK) >> 7)], (uint32_t)c.y);
+      dep[k] = make_int2(0, 0);
+    }
+  }
+  __syncthreads();
+  const int64_t so0 = t.state_off[g0];
+  bool ovf = false;
+  auto sat_add = [&](int32_t old, uint32_t add) -> int32_t {
+    const int64_t v = (int64_t)old + (int64_t)add;
+    if (v > 0x7fffffffLL) { ovf = true; return 0x7fffffff; }
+    return (int32_t)v;
+  };
+  for (int i = wave; i < nb; i += K1E_NW) {
+    const int bi = g0 + i;
+    const int32_t s_start = t.start_state[t.start_off[bi]];
+    const uint32_t n_res = (uint32_t)p.dep_res[bi];
+    const int64_t gs0 = so0 + (int64_t)i * S;
+    for (int s = lane; s < S; s += 64) {
+      const uint32_t c0 = arr0[i * S + s], c1 = arr1[i * S + s];
+      const uint32_t add_s = c0 + c1 + (s == s_start ? n_res : 0u);
+      if (add_s) t.visits_s[gs0 + s] = sat_add(t.visits_s[gs0 + s], add_s);
+      if (c0 | c1) {
+        int2* sa = reinterpret_cast<int2*>(t.visits_sa + (gs0 + s) * 2);
+        int2 v = *sa;
+        v.x = sat_add(v.x, c0);
+        v.y = sat_add(v.y, c1);
+        *sa = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) p.dep_res[bi] = 0;
+  }
+  if (ovf) atomicOr(overflow, 1);
+}
+
+// The float64 reward sums of a segment, in TRANSITION ORDER: lane = instance.  The sum is sequential by definition (float64
+// addition does not associate and the oracle adds reward by reward), but almost all of it can be done EXACTLY in integers:
+// while the running sum S stays inside one binade [2^k, 2^(k+1)) its spacing is u = 2^(k-52), S = m u with an integer m, and
+// for a reward v >= 0 the IEEE sum is fl(S + v) = (m + q) u with q = round-to-nearest(v / u) -- an integer that depends on v
+// and k only -- unless v / u lies exactly half way between two integers (ties-to-even then looks at m).  Integer addition
+// associates, so an episode chunk with n_c steps of reward code c advances m by sum_c n_c q_c, whatever the order: valid
+// as long as no code present is a tie case in this binade and m stays below 2^53 (q >= 0: every partial sum then stayed in
+// the binade too).  Otherwise -- a binade is crossed (~15 times per 30 000 transitions), S is zero or subnormal, a reward is
+// negative or a tie case -- the chunk is added step by step in float64, exactly as the oracle does, and (k, m, q) are
+// re-derived from the result.  An episode's code word holds the 2-bit reward codes of its steps, step j of a 32-step
+// chunk at bits 2 j of the 64-bit word (unused fields zero).
 #define K1R_THREADS 64
-#define K1R_PF 4   // code words in flight per lane
+#define K1R_T 16   // code words per tile: the next tile's loads are in flight while a tile is summed
 __global__ void __launch_bounds__(K1R_THREADS) k_reward_scan(EnvTables t, K1ePlan p, int64_t n_steps,
                                                             double* __restrict__ reward_sum, int accumulate) {
-  __shared__ double rv[4];
-  const int b = blockIdx.x * K1R_THREADS + threadIdx.x;
-  if (threadIdx.x < 4) rv[threadIdx.x] = (int)threadIdx.x < p.n_codes ? p.rvals[threadIdx.x] * t.rscale - t.rmin : 0.0;
-  __syncthreads();
-  if (b >= t.B) return;
+  // the tile being summed: lane-private columns (lane i = bank i), read back with a run-time index by the rolled loop below
+  __shared__ uint32_t tile_n[K1R_T][K1R_THREADS];
+  __shared__ uint32_t tile_lo[K1R_T][K1R_THREADS], tile_hi[K1R_T][K1R_THREADS];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * K1R_THREADS + lane;
+  if (b >= t.B) return;   // (no barrier below: every lane works on its own columns)
+  double rv[4];
+  bool bulk_allowed = true;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    rv[c] = c < p.n_codes ? p.rvals[c] * t.rscale - t.rmin : 0.0;
+    bulk_allowed = bulk_allowed && rv[c] >= 0.0 && rv[c] < 1.0e300;
+  }
   const int H = p.H, h0 = p.seg_h0[b], nch = p.nch;
-  double sum = accumulate ? reward_sum[b] : 0.0;
+  double S = accumulate ? reward_sum[b] : 0.0;
   const int64_t E = ((int64_t)h0 + n_steps + H - 1) / H;
   const int64_t W = E * nch;   // code words of this instance, in order
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-  const u32x2* src = reinterpret_cast<const u32x2*>(p.codes) + b;
-  auto word_len = [&](int64_t wi) -> int {   // steps the code word wi holds
-    const int64_t e = wi / nch;
-    const int ch = (int)(wi - e * nch);
-    const int64_t first = e == 0 ? 0 : e * H - h0;
-    const int64_t len = min((int64_t)(H - (e == 0 ? h0 : 0)), n_steps - first);
-    return (int)min((int64_t)32, len - 32 * ch);
-  };
-  auto add_word = [&](u32x2 c, int L) {
-    const int L0 = min(L, 16);
-#pragma unroll 4
-    for (int j = 0; j < L0; ++j) sum += rv[(c.x >> (2 * j)) & 3u];
-#pragma unroll 4
-    for (int j = 16; j < L; ++j) sum += rv[(c.y >> (2 * (j - 16))) & 3u];
-  };
-  u32x2 q[K1R_PF];
+  const u32x2* csrc = reinterpret_cast<const u32x2*>(p.codes) + b;
+  const uint32_t* nsrc = p.cnts + b;
+  // integer form of the sum, valid while `kvalid`: S = m * 2^(kb - 1075) with 2^52 <= m < 2^53 (kb = biased exponent);
+  // q[c] = round(rv[c] / spacing) as (low, high) halves, dmax >= the advance of m over one code word
+  bool kvalid = false;
+  int kb = 0;
+  unsigned long long m = 0ull, dmax = 0ull;
+  uint32_t qlo[4] = {0u, 0u, 0u, 0u}, qhi[4] = {0u, 0u, 0u, 0u};
+  uint32_t tie = 0u;
+  const unsigned long long M52 = (1ull << 52) - 1ull, B52 = 1ull << 52;
+  auto rebase = [&]() {
+    kvalid = false;
+    if (!bulk_allowed || !(S >= 2.2250738585072014e-308) || !(S < 1.0e300)) return;
+    const unsigned long long sb = (unsigned long long)__double_as_longlong(S);
+    kb = (int)(sb >> 52);
+    m = (sb & M52) | B52;
+    tie = 0u;
+    unsigned long long qmax = 0ull;
 #pragma unroll
-  for (int k = 0; k < K1R_PF; ++k) q[k] = k < W ? __builtin_nontemporal_load(&src[(size_t)k * t.B]) : u32x2{0u, 0u};
-  for (int64_t w0 = 0; w0 < W; w0 += K1R_PF) {
-    u32x2 cur[K1R_PF];
-#pragma unroll
-    for (int k = 0; k < K1R_PF; ++k) {
-      cur[k] = q[k];
-      const int64_t nx = w0 + K1R_PF + k;
-      q[k] = nx < W ? __builtin_nontemporal_load(&src[(size_t)nx * t.B]) : u32x2{0u, 0u};
+    for (int c = 0; c < 4; ++c) {
+      const unsigned long long vb = (unsigned long long)__double_as_longlong(rv[c]);
+      const int eb = (int)(vb >> 52);
+      unsigned long long qq = 0ull;
+      if (rv[c] != 0.0) {
+        if (eb == 0) tie |= 1u << c;   // subnormal reward: leave it to the float64 path
+        else {
+          const unsigned long long mv = (vb & M52) | B52;
+          const int d = kb - eb;
+          if (d < 0) qq = 1ull << 53;          // v >= 2^(k+1): the sum leaves the binade -- forces the float64 path
+          else if (d == 0) qq = mv;
+          else if (d < 55) {
+            const unsigned long long half = 1ull << (d - 1), rem = mv & ((1ull << d) - 1ull);
+            qq = (mv >> d) + (rem > half ? 1ull : 0ull);
+            if (rem == half) tie |= 1u << c;
+          }
+        }
+      }
+      qlo[c] = (uint32_t)qq;
+      qhi[c] = (uint32_t)(qq >> 32);
+      qmax = qq > qmax ? qq : qmax;
     }
+    dmax = qmax * 32ull;
+    kvalid = true;
+  };
+  rebase();
+  // Could a word among the next `words` leave the integer form?  Only then are its code words fetched as well (the counts
+  // always are): m advances by at most dmax per word, so below this bound every one of them is added in integers.
+  auto risky = [&](int words) -> bool {
+    return !kvalid || tie != 0u || dmax >= (1ull << 53) || m + dmax * (unsigned long long)words >= (1ull << 53);
+  };
+
+  // episode / chunk bookkeeping of the word about to be summed
+  int ch = 0;
+  int e_len = (int)min((int64_t)(H - h0), n_steps);   // steps of the current episode inside this segment
+  int ep_left = e_len;                                 // ... not yet covered by earlier chunks
+  int64_t tot_left = n_steps;                          // steps from the current episode's first one on
+
+  uint32_t rn[K1R_T];
+  u32x2 rc[K1R_T];
+  bool have_next = risky(K1R_T);
 #pragma unroll
-    for (int k = 0; k < K1R_PF; ++k)
-      if (w0 + k < W) add_word(cur[k], word_len(w0 + k));
+  for (int k = 0; k < K1R_T; ++k) {
+    rn[k] = k < W ? __builtin_nontemporal_load(&nsrc[(size_t)k * t.B]) : 0u;
+    rc[k] = (have_next && k < W) ? __builtin_nontemporal_load(&csrc[(size_t)k * t.B]) : u32x2{0u, 0u};
   }
-  reward_sum[b] = sum;
+  for (int64_t w0 = 0; w0 < W; w0 += K1R_T) {
+    const bool have = have_next;
+#pragma unroll
+    for (int k = 0; k < K1R_T; ++k) {
+      tile_n[k][lane] = rn[k];
+      tile_lo[k][lane] = rc[k].x;
+      tile_hi[k][lane] = rc[k].y;
+    }
+    // the next tile's loads: its words are at most 2 K1R_T words ahead of the state the bound is taken from
+    have_next = risky(2 * K1R_T);
+#pragma unroll
+    for (int k = 0; k < K1R_T; ++k) {
+      const int64_t nx = w0 + K1R_T + k;
+      rn[k] = nx < W ? __builtin_nontemporal_load(&nsrc[(size_t)nx * t.B]) : 0u;
+      rc[k] = (have_next && nx < W) ? __builtin_nontemporal_load(&csrc[(size_t)nx * t.B]) : u32x2{0u, 0u};
+    }
+    const int kmax = (int)min((int64_t)K1R_T, W - w0);
+    for (int k = 0; k < kmax; ++k) {
+      const int L = min(32, ep_left);   // <= 0: a chunk a partial episode does not reach (its words were never written)
+      if (L > 0) {
+        const uint32_t nw = tile_n[k][lane];
+        const uint32_t n1 = nw & 0xffu, n2 = (nw >> 8) & 0xffu, n3 = nw >> 16, n0 = (uint32_t)L - n1 - n2 - n3;
+        bool ok = kvalid;
+        unsigned long long m2 = 0ull;
+        if (ok) {
+          const uint32_t present = (n0 ? 1u : 0u) | (n1 ? 2u : 0u) | (n2 ? 4u : 0u) | (n3 ? 8u : 0u);
+          unsigned long long lo64 = (unsigned long long)n0 * qlo[0];
+          lo64 += (unsigned long long)n1 * qlo[1];
+          lo64 += (unsigned long long)n2 * qlo[2];
+          lo64 += (unsigned long long)n3 * qlo[3];
+          const uint32_t hi32 = n0 * qhi[0] + n1 * qhi[1] + n2 * qhi[2] + n3 * qhi[3];   // < 2^27: q < 2^54, n <= 32
+          m2 = m + lo64 + ((unsigned long long)hi32 << 32);
+          ok = (present & tie) == 0u && m2 < (1ull << 53);
+        }
+        if (ok) {
+          m = m2;
+        } else {   // float64, step by step, exactly as the oracle adds
+          u32x2 c;
+          if (have) { c.x = tile_lo[k][lane]; c.y = tile_hi[k][lane]; }
+          else c = csrc[(size_t)(w0 + k) * t.B];   // (never taken: `risky` is an upper bound; kept as the exact fallback)
+          if (kvalid) S = __longlong_as_double((long long)(((unsigned long long)kb << 52) | (m & M52)));
+          for (int j0 = 0; j0 < L; j0 += 8) {
+            const uint32_t cw = (j0 < 16 ? c.x >> (2 * j0) : c.y >> (2 * (j0 - 16)));
+            double v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const uint32_t code = (cw >> (2 * j)) & 3u;
+              const double a = (code & 1u) ? rv[1] : rv[0], bq = (code & 1u) ? rv[3] : rv[2];
+              v[j] = (j0 + j < L) ? ((code & 2u) ? bq : a) : 0.0;   // x + 0.0 == x (the sum is never -0.0)
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) S += v[j];
+          }
+          rebase();
+        }
+      }
+      ep_left -= 32;
+      if (++ch == nch) {
+        ch = 0;
+        tot_left -= e_len;
+        e_len = (int)min((int64_t)H, tot_left);
+        ep_left = e_len;
+      }
+    }
+  }
+  if (kvalid) S = __longlong_as_double((long long)(((unsigned long long)kb << 52) | (m & M52)));
+  reward_sum[b] = S;
 }
