@@ -64,7 +64,7 @@ struct K1ePlan {
                              // and 1 (high half), s' << 7 | code; interleaved by instance like the LDS image
   const double* rvals;       // [n_codes]
   uint2* codes;              // [episode][chunk][B] 2-bit reward codes of the chunk's steps, step j at bits 2 j
-  uint32_t* cnts;            // [episode][chunk][B] steps of the chunk with reward code 1 | code 2 << 8 | code 3 << 16
+  uint32_t* cnts;            // [episode][chunk][B] steps of the chunk with reward code 1 | code 2 << 11 | code 3 << 22
   int32_t* seg_h0;           // [B] in-episode time at the start of the segment (k_reward_scan decodes the episodes with it)
   int2* dep;                 // [group][S][32] DEPARTURE counts (action 0, action 1) accumulated over launches, interleaved like
                              // the LDS image; k_epi_fold turns them into the reference's arrival counts when they are needed
@@ -80,14 +80,15 @@ __host__ __device__ inline size_t k1e_lds_bytes(const K1ePlan& p) {
 __host__ __device__ inline size_t k1e_fold_lds_bytes(const K1ePlan& p) { return (size_t)2 * K1E_NI * (size_t)p.S * 4; }
 __host__ __device__ inline int64_t k1e_max_episodes(int64_t n_steps, int H) { return (n_steps + 2 * (int64_t)H - 2) / H; }
 
-// steps of a code word (2-bit fields, unused fields zero) with code 1, 2, 3: n1 | n2 << 8 | n3 << 16
+// steps of a code word (2-bit fields, unused fields zero) with code 1, 2, 3: n1 | n2 << 11 | n3 << 22 (11-bit fields: the
+// packed words of a 16-word tile add up without carries into the neighbouring field)
 __device__ __forceinline__ uint32_t k1e_code_counts(uint32_t lo, uint32_t hi) {
   const uint32_t l0 = lo & 0x55555555u, l1 = (lo >> 1) & 0x55555555u;
   const uint32_t h0 = hi & 0x55555555u, h1 = (hi >> 1) & 0x55555555u;
   const uint32_t n3 = __popc(l0 & l1) + __popc(h0 & h1);
   const uint32_t n1 = __popc(l0 & ~l1) + __popc(h0 & ~h1);
   const uint32_t n2 = __popc(~l0 & l1) + __popc(~h0 & h1);
-  return n1 | (n2 << 8) | (n3 << 16);
+  return n1 | (n2 << 11) | (n3 << 22);
 }
 
 typedef __attribute__((address_space(3))) uint32_t* k1e_lds_u32;
@@ -373,12 +374,14 @@ __global__ void __launch_bounds__(K1E_THREADS) k_epi_fold(EnvTables t, K1ePlan p
 #define K1R_T 16   // code words per tile: the next tile's loads are in flight while a tile is summed
 __global__ void __launch_bounds__(K1R_THREADS) k_reward_scan(EnvTables t, K1ePlan p, int64_t n_steps,
                                                             double* __restrict__ reward_sum, int accumulate) {
-  // the tile being summed: lane-private columns (lane i = bank i), read back with a run-time index by the rolled loop below
-  __shared__ uint32_t tile_n[K1R_T][K1R_THREADS];
+  // a tile that does not advance in one piece: lane-private columns (lane i = bank i) of the prefix sums of its words' packed
+  // counts and steps and of its code words, read back with a run-time index by the search below
+  __shared__ uint32_t tile_P[K1R_T][K1R_THREADS], tile_S[K1R_T][K1R_THREADS];
   __shared__ uint32_t tile_lo[K1R_T][K1R_THREADS], tile_hi[K1R_T][K1R_THREADS];
+  __shared__ double rvt[4];
   const int lane = threadIdx.x;
-  const int b = blockIdx.x * K1R_THREADS + lane;
-  if (b >= t.B) return;   // (no barrier below: every lane works on its own columns)
+  const int b = min(blockIdx.x * K1R_THREADS + lane, t.B - 1);   // (lanes past the batch repeat its last instance, unstored)
+  const bool mine = blockIdx.x * K1R_THREADS + lane < t.B;
   double rv[4];
   bool bulk_allowed = true;
 #pragma unroll
@@ -386,21 +389,33 @@ __global__ void __launch_bounds__(K1R_THREADS) k_reward_scan(EnvTables t, K1ePla
     rv[c] = c < p.n_codes ? p.rvals[c] * t.rscale - t.rmin : 0.0;
     bulk_allowed = bulk_allowed && rv[c] >= 0.0 && rv[c] < 1.0e300;
   }
+  if (lane < 4) rvt[lane] = rv[lane];
+  __syncthreads();
+  // per code: mantissa with the hidden bit and biased exponent of the reward (zero / subnormal rewards: eb = 0)
+  unsigned long long mv[4];
+  int eb[4];
+  const unsigned long long M52 = (1ull << 52) - 1ull, B52 = 1ull << 52;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const unsigned long long vb = (unsigned long long)__double_as_longlong(rv[c]);
+    eb[c] = (int)(vb >> 52) & 0x7ff;
+    mv[c] = (vb & M52) | B52;
+  }
   const int H = p.H, h0 = p.seg_h0[b], nch = p.nch;
   double S = accumulate ? reward_sum[b] : 0.0;
   const int64_t E = ((int64_t)h0 + n_steps + H - 1) / H;
-  const int64_t W = E * nch;   // code words of this instance, in order
+  const int W = (int)(E * nch);   // code words of this instance, in order (a segment: < 2^31)
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
   const u32x2* csrc = reinterpret_cast<const u32x2*>(p.codes) + b;
   const uint32_t* nsrc = p.cnts + b;
   // integer form of the sum, valid while `kvalid`: S = m * 2^(kb - 1075) with 2^52 <= m < 2^53 (kb = biased exponent);
-  // q[c] = round(rv[c] / spacing) as (low, high) halves, dmax >= the advance of m over one code word
+  // q[c] = round(rv[c] / spacing) as (low, high) halves; `tie`: codes whose presence forces the float64 path (a tie case in
+  // this binade, a subnormal reward, a reward at or above 2^(k+1)); dmax >= the advance of m over one code word
   bool kvalid = false;
   int kb = 0;
   unsigned long long m = 0ull, dmax = 0ull;
   uint32_t qlo[4] = {0u, 0u, 0u, 0u}, qhi[4] = {0u, 0u, 0u, 0u};
   uint32_t tie = 0u;
-  const unsigned long long M52 = (1ull << 52) - 1ull, B52 = 1ull << 52;
   auto rebase = [&]() {
     kvalid = false;
     if (!bulk_allowed || !(S >= 2.2250738585072014e-308) || !(S < 1.0e300)) return;
@@ -411,38 +426,43 @@ __global__ void __launch_bounds__(K1R_THREADS) k_reward_scan(EnvTables t, K1ePla
     unsigned long long qmax = 0ull;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const unsigned long long vb = (unsigned long long)__double_as_longlong(rv[c]);
-      const int eb = (int)(vb >> 52);
       unsigned long long qq = 0ull;
       if (rv[c] != 0.0) {
-        if (eb == 0) tie |= 1u << c;   // subnormal reward: leave it to the float64 path
-        else {
-          const unsigned long long mv = (vb & M52) | B52;
-          const int d = kb - eb;
-          if (d < 0) qq = 1ull << 53;          // v >= 2^(k+1): the sum leaves the binade -- forces the float64 path
-          else if (d == 0) qq = mv;
-          else if (d < 55) {
-            const unsigned long long half = 1ull << (d - 1), rem = mv & ((1ull << d) - 1ull);
-            qq = (mv >> d) + (rem > half ? 1ull : 0ull);
-            if (rem == half) tie |= 1u << c;
-          }
+        const int d = kb - eb[c];
+        if (eb[c] == 0 || d < 0) tie |= 1u << c;   // subnormal reward, or v >= 2^(k+1): the sum would leave the binade
+        else if (d == 0) qq = mv[c];
+        else if (d < 55) {
+          const unsigned long long half = 1ull << (d - 1), rem = mv[c] & ((1ull << d) - 1ull);
+          qq = (mv[c] >> d) + (rem > half ? 1ull : 0ull);
+          if (rem == half) tie |= 1u << c;
         }
       }
       qlo[c] = (uint32_t)qq;
       qhi[c] = (uint32_t)(qq >> 32);
       qmax = qq > qmax ? qq : qmax;
     }
-    dmax = qmax * 32ull;
+    dmax = qmax * 32ull;   // q < 2^54
     kvalid = true;
   };
   rebase();
   // Could a word among the next `words` leave the integer form?  Only then are its code words fetched as well (the counts
   // always are): m advances by at most dmax per word, so below this bound every one of them is added in integers.
-  auto risky = [&](int words) -> bool {
-    return !kvalid || tie != 0u || dmax >= (1ull << 53) || m + dmax * (unsigned long long)words >= (1ull << 53);
+  auto risky = [&](int words) -> bool { return !kvalid || tie != 0u || m + dmax * (unsigned long long)words >= (1ull << 53); };
+  // m + the advance of `steps` (<= 512) transitions with packed counts nw; true = the whole of it stays in the integer form
+  auto advance = [&](uint32_t nw, uint32_t steps, unsigned long long& m2) -> bool {
+    const uint32_t n1 = nw & 0x7ffu, n2 = (nw >> 11) & 0x7ffu, n3 = nw >> 22, n0 = steps - n1 - n2 - n3;
+    const uint32_t present = (n0 ? 1u : 0u) | (n1 ? 2u : 0u) | (n2 ? 4u : 0u) | (n3 ? 8u : 0u);
+    unsigned long long lo64 = (unsigned long long)n0 * qlo[0];
+    lo64 += (unsigned long long)n1 * qlo[1];
+    lo64 += (unsigned long long)n2 * qlo[2];
+    lo64 += (unsigned long long)n3 * qlo[3];
+    const uint32_t hi32 = n0 * qhi[0] + n1 * qhi[1] + n2 * qhi[2] + n3 * qhi[3];   // <= 512 * 2^22
+    m2 = m + lo64 + ((unsigned long long)hi32 << 32);
+    return kvalid && (present & tie) == 0u && m2 < (1ull << 53);
   };
+  auto compose = [&]() { return __longlong_as_double((long long)(((unsigned long long)kb << 52) | (m & M52))); };
 
-  // episode / chunk bookkeeping of the word about to be summed
+  // episode / chunk bookkeeping of the next word to be laid out
   int ch = 0;
   int e_len = (int)min((int64_t)(H - h0), n_steps);   // steps of the current episode inside this segment
   int ep_left = e_len;                                 // ... not yet covered by earlier chunks
@@ -456,71 +476,99 @@ __global__ void __launch_bounds__(K1R_THREADS) k_reward_scan(EnvTables t, K1ePla
     rn[k] = k < W ? __builtin_nontemporal_load(&nsrc[(size_t)k * t.B]) : 0u;
     rc[k] = (have_next && k < W) ? __builtin_nontemporal_load(&csrc[(size_t)k * t.B]) : u32x2{0u, 0u};
   }
-  for (int64_t w0 = 0; w0 < W; w0 += K1R_T) {
+  for (int w0 = 0; w0 < W; w0 += K1R_T) {
     const bool have = have_next;
+    // prefix sums of the tile's packed counts and steps (0 steps: a chunk a partial episode does not reach, or past the end)
+    uint32_t P[K1R_T], SP[K1R_T];
+    // interior tiles of single-chunk episodes (all lanes): every word holds H steps
+    const bool interior = nch == 1 && __all(w0 >= 1 && w0 + K1R_T <= W - 1);
+    if (interior) {
+      uint32_t acc = 0u;
 #pragma unroll
-    for (int k = 0; k < K1R_T; ++k) {
-      tile_n[k][lane] = rn[k];
-      tile_lo[k][lane] = rc[k].x;
-      tile_hi[k][lane] = rc[k].y;
+      for (int k = 0; k < K1R_T; ++k) { acc += rn[k]; P[k] = acc; SP[k] = (uint32_t)((k + 1) * H); }
+      tot_left -= (int64_t)K1R_T * H;   // sixteen full episodes on: the next one may be the segment's last, partial one
+      e_len = (int)min((int64_t)H, tot_left);
+      ep_left = e_len;
+    } else {
+      uint32_t acc = 0u, sacc = 0u;
+#pragma unroll
+      for (int k = 0; k < K1R_T; ++k) {
+        const int L = (w0 + k < W) ? max(0, min(32, ep_left)) : 0;
+        acc += L > 0 ? rn[k] : 0u;
+        sacc += (uint32_t)L;
+        P[k] = acc; SP[k] = sacc;
+        ep_left -= 32;
+        if (++ch == nch) {
+          ch = 0;
+          tot_left -= e_len;
+          e_len = (int)min((int64_t)H, tot_left);
+          ep_left = e_len;
+        }
+      }
+    }
+    const uint32_t Pt = P[K1R_T - 1], St = SP[K1R_T - 1];
+    unsigned long long m2;
+    const bool whole = advance(Pt, St, m2);
+    if (!__all(whole)) {   // some lane leaves the integer form inside this tile: lay the tile out for the search
+#pragma unroll
+      for (int k = 0; k < K1R_T; ++k) {
+        tile_P[k][lane] = P[k];
+        tile_S[k][lane] = SP[k];
+        tile_lo[k][lane] = rc[k].x;
+        tile_hi[k][lane] = rc[k].y;
+      }
     }
     // the next tile's loads: its words are at most 2 K1R_T words ahead of the state the bound is taken from
     have_next = risky(2 * K1R_T);
+    {
+      const uint32_t* nn = nsrc + (size_t)(w0 + K1R_T) * t.B;
+      const u32x2* cn = csrc + (size_t)(w0 + K1R_T) * t.B;
 #pragma unroll
-    for (int k = 0; k < K1R_T; ++k) {
-      const int64_t nx = w0 + K1R_T + k;
-      rn[k] = nx < W ? __builtin_nontemporal_load(&nsrc[(size_t)nx * t.B]) : 0u;
-      rc[k] = (have_next && nx < W) ? __builtin_nontemporal_load(&csrc[(size_t)nx * t.B]) : u32x2{0u, 0u};
+      for (int k = 0; k < K1R_T; ++k) {
+        const bool in = w0 + K1R_T + k < W;
+        rn[k] = in ? __builtin_nontemporal_load(&nn[(size_t)k * t.B]) : 0u;
+        rc[k] = (have_next && in) ? __builtin_nontemporal_load(&cn[(size_t)k * t.B]) : u32x2{0u, 0u};
+      }
     }
-    const int kmax = (int)min((int64_t)K1R_T, W - w0);
-    for (int k = 0; k < kmax; ++k) {
-      const int L = min(32, ep_left);   // <= 0: a chunk a partial episode does not reach (its words were never written)
-      if (L > 0) {
-        const uint32_t nw = tile_n[k][lane];
-        const uint32_t n1 = nw & 0xffu, n2 = (nw >> 8) & 0xffu, n3 = nw >> 16, n0 = (uint32_t)L - n1 - n2 - n3;
-        bool ok = kvalid;
-        unsigned long long m2 = 0ull;
-        if (ok) {
-          const uint32_t present = (n0 ? 1u : 0u) | (n1 ? 2u : 0u) | (n2 ? 4u : 0u) | (n3 ? 8u : 0u);
-          unsigned long long lo64 = (unsigned long long)n0 * qlo[0];
-          lo64 += (unsigned long long)n1 * qlo[1];
-          lo64 += (unsigned long long)n2 * qlo[2];
-          lo64 += (unsigned long long)n3 * qlo[3];
-          const uint32_t hi32 = n0 * qhi[0] + n1 * qhi[1] + n2 * qhi[2] + n3 * qhi[3];   // < 2^27: q < 2^54, n <= 32
-          m2 = m + lo64 + ((unsigned long long)hi32 << 32);
-          ok = (present & tie) == 0u && m2 < (1ull << 53);
-        }
-        if (ok) {
-          m = m2;
-        } else {   // float64, step by step, exactly as the oracle adds
-          u32x2 c;
-          if (have) { c.x = tile_lo[k][lane]; c.y = tile_hi[k][lane]; }
-          else c = csrc[(size_t)(w0 + k) * t.B];   // (never taken: `risky` is an upper bound; kept as the exact fallback)
-          if (kvalid) S = __longlong_as_double((long long)(((unsigned long long)kb << 52) | (m & M52)));
-          for (int j0 = 0; j0 < L; j0 += 8) {
-            const uint32_t cw = (j0 < 16 ? c.x >> (2 * j0) : c.y >> (2 * (j0 - 16)));
-            double v[8];
+    if (whole) { m = m2; continue; }
+    // ---- this lane: the first word that does not advance (binary search over the prefix sums: advancing is monotone --
+    // q >= 0, and a forcing code stays present), everything before it in one piece, that word in float64 step by step
+    // exactly as the oracle adds, then the rest of the tile again ----
+    uint32_t base_n = 0u, base_s = 0u;
+    int from = 0;
+    while (from < K1R_T) {
+      if (advance(Pt - base_n, St - base_s, m2)) { m = m2; break; }
+      int lo = from, hi = K1R_T - 1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const uint32_t code = (cw >> (2 * j)) & 3u;
-              const double a = (code & 1u) ? rv[1] : rv[0], bq = (code & 1u) ? rv[3] : rv[2];
-              v[j] = (j0 + j < L) ? ((code & 2u) ? bq : a) : 0.0;   // x + 0.0 == x (the sum is never -0.0)
-            }
+      for (int it = 0; it < 4; ++it) {   // 2^4 = K1R_T
+        const int mid = (lo + hi) >> 1;
+        const bool ok = advance(tile_P[mid][lane] - base_n, tile_S[mid][lane] - base_s, m2);
+        if (lo < hi) { if (ok) lo = mid + 1; else hi = mid; }
+      }
+      const int k = lo;
+      if (k > from && advance(tile_P[k - 1][lane] - base_n, tile_S[k - 1][lane] - base_s, m2)) m = m2;
+      const uint32_t Sk = tile_S[k][lane], Sk1 = k > 0 ? tile_S[k - 1][lane] : 0u;
+      const uint32_t L = Sk - Sk1;
+      if (L) {
+        u32x2 c;
+        if (have) { c.x = tile_lo[k][lane]; c.y = tile_hi[k][lane]; }
+        else c = csrc[(size_t)(w0 + k) * t.B];   // (never taken: `risky` is an upper bound; kept as the exact fallback)
+        if (kvalid) S = compose();
+        for (uint32_t j0 = 0; j0 < L; j0 += 8) {
+          const uint32_t cw = (j0 < 16 ? c.x >> (2 * j0) : c.y >> (2 * (j0 - 16)));
+          double v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) S += v[j];
-          }
-          rebase();
+          for (int j = 0; j < 8; ++j) v[j] = (j0 + j < L) ? rvt[(cw >> (2 * j)) & 3u] : 0.0;   // x + 0.0 == x (the sum is never -0.0)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) S += v[j];
         }
+        rebase();
       }
-      ep_left -= 32;
-      if (++ch == nch) {
-        ch = 0;
-        tot_left -= e_len;
-        e_len = (int)min((int64_t)H, tot_left);
-        ep_left = e_len;
-      }
+      base_n = tile_P[k][lane];
+      base_s = Sk;
+      from = k + 1;
     }
   }
-  if (kvalid) S = __longlong_as_double((long long)(((unsigned long long)kb << 52) | (m & M52)));
-  reward_sum[b] = S;
+  if (kvalid) S = compose();
+  if (mine) reward_sum[b] = S;
 }
