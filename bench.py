@@ -165,10 +165,38 @@ def sustained_leg(env, ev, launch_steps, seconds, B):
     }
 
 
-LIVE_PMC = None   # {kernel base name: {"read": bytes, "write": bytes, "launches": n}} measured by child runs under rocprofv3
+LIVE_PMC = None   # {kernel base name: {"read": bytes, "write": bytes, "launches": n, SQ counters...}} measured by child runs under rocprofv3
+# one SQ pass (8 counters): instructions issued, LDS pipe cycles and bank-conflict cycles, kernel cycles (GRBM, summed over 8 XCDs)
+SQ_COUNTERS = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT",
+               "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"]
+# cycles a wave64 instruction of K1E's step (v_bfe_u32, v_lshl_or_b32, v_and_or_b32, v_alignbit_b32) occupies a SIMD at 4-8
+# wavefronts per SIMD: measured, tools/calib/valu_int_rate.hip -> profiles/r04_valu_int_rate.txt (float32 v_fma: 2.7-3.0)
+VALU_INT_VOP3_CYCLES = 4.4
 
 
-def live_pmc(child_args, timeout=170):
+def sq_view(kernel, launch_s):
+    """Hardware-anchored fractions of one kernel from the SQ child pass of THIS run: VALU issue (wave-instructions issued x
+    cycles per instruction / SIMD-cycles of the launch) and LDS pipe (SQ_LDS_IDX_ACTIVE per CU-cycle); None without the pass."""
+    v = (LIVE_PMC or {}).get(kernel)
+    if not v or "SQ_INSTS_VALU" not in v or "GRBM_GUI_ACTIVE" not in v:
+        return None
+    cyc = v["GRBM_GUI_ACTIVE"] / 8.0   # rocprofv3 sums the 8 XCDs
+    out = {
+        "source": "this run: rocprofv3 --pmc %s child pass of bench.py, per-launch means" % " ".join(SQ_COUNTERS),
+        "kernel_cycles": cyc, "kernel_ms_under_profiler": cyc / CLOCK_HZ * 1e3,
+        "valu_wave_insts_per_launch": v["SQ_INSTS_VALU"], "lds_wave_insts_per_launch": v.get("SQ_INSTS_LDS"),
+        "salu_wave_insts_per_launch": v.get("SQ_INSTS_SALU"),
+        "valu_issue_frac_at_2_cycles": v["SQ_INSTS_VALU"] * VALU_CYCLES / (N_CUS * 4 * cyc),
+        "valu_issue_frac_at_measured_int_rate": v["SQ_INSTS_VALU"] * VALU_INT_VOP3_CYCLES / (N_CUS * 4 * cyc),
+        "lds_pipe_frac": v.get("SQ_LDS_IDX_ACTIVE", 0.0) / (N_CUS * cyc),
+        "lds_bank_conflict_frac_of_lds_cycles": v.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(v.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0),
+    }
+    if launch_s:
+        out["valu_G_wave_insts_per_s"] = v["SQ_INSTS_VALU"] / launch_s / 1e9
+    return out
+
+
+def live_pmc(child_args, timeout=240):
     """HBM traffic per launch MEASURED IN THIS RUN: two child runs of this script's headline and dense legs under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes: the two counters do not fit the TCC slots
     together; --kernel-trace is the only other option on the command line, the program comes directly after `--`), per-kernel
@@ -183,28 +211,38 @@ def live_pmc(child_args, timeout=170):
     if not exe:
         return None
     out = {}
-    for counter, scale, key in (("FETCH_SIZE", 2048.0, "read"), ("WRITE_SIZE", 1024.0, "write")):
+    passes = [(["FETCH_SIZE"], child_args), (["WRITE_SIZE"], child_args), (SQ_COUNTERS, child_args + ["--pmc-child-vi"])]
+    for counters, cargs in passes:
         d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
-        cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "--output-format", "csv", "--", sys.executable,
-               os.path.abspath(__file__), "--pmc-child"] + child_args
+        cmd = [exe, "--pmc"] + counters + ["--kernel-trace", "-d", d, "--output-format", "csv", "--", sys.executable,
+               os.path.abspath(__file__), "--pmc-child"] + cargs
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout,
                                stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
             files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
             if r.returncode != 0 or not files:
+                sys.stderr.write("bench.py: rocprofv3 --pmc %s child pass failed (rc %s): %s\n" % (" ".join(counters), r.returncode, r.stderr.decode(errors="replace")[-600:]))
+                if counters is SQ_COUNTERS:
+                    continue      # the traffic passes stand without the SQ pass
                 return None
             acc = {}
             for row in csv.DictReader(open(files[0])):
-                if row["Counter_Name"] == counter:
-                    acc.setdefault(row["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0], []).append(float(row["Counter_Value"]))
-            for k, v in acc.items():
-                out.setdefault(k, {})[key] = scale * sum(v) / len(v)
-                out[k]["launches"] = len(v)
-        except Exception:
+                name = row["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0]
+                acc.setdefault(name, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for k, cs in acc.items():
+                for c, v in cs.items():
+                    key, scale = {"FETCH_SIZE": ("read", 2048.0), "WRITE_SIZE": ("write", 1024.0)}.get(c, (c, 1.0))
+                    out.setdefault(k, {})[key] = scale * sum(v) / len(v)
+                    if key in ("read", "write") or c == "SQ_INSTS_VALU":
+                        out[k]["launches"] = len(v)
+        except Exception as e:
+            sys.stderr.write("bench.py: rocprofv3 --pmc %s child pass: %r\n" % (" ".join(counters), e))
+            if counters is SQ_COUNTERS:
+                continue
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return {k: v for k, v in out.items() if "read" in v and "write" in v}
+    return {k: v for k, v in out.items() if ("read" in v and "write" in v) or "SQ_INSTS_VALU" in v}
 
 
 def pmc_entry(kernel_prefix, units_per_launch, build_id):
@@ -212,7 +250,7 @@ def pmc_entry(kernel_prefix, units_per_launch, build_id):
     WRITE_SIZE` passes (their own rocprofv3 runs, tools/collect_profiles.sh).  Returned only when the summary was
     collected on the same workload; `current` says whether it was collected on THIS build of the library."""
     base = kernel_prefix.split("<")[0]
-    if LIVE_PMC and base in LIVE_PMC:   # measured in this run (child passes under rocprofv3)
+    if LIVE_PMC and base in LIVE_PMC and "read" in LIVE_PMC[base] and "write" in LIVE_PMC[base]:   # measured in this run (child passes under rocprofv3)
         v = LIVE_PMC[base]
         return dict(bytes=v["read"] + v["write"], read=v["read"], write=v["write"], current=True,
                     source="this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of bench.py, %d launches" % v["launches"],
@@ -247,7 +285,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (CPU rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: ranks share the visible GPUs (device = local_rank %% n_devices)")
     ap.add_argument("--lds-groups", type=int, default=0, help="K1L workgroups per CU (0: library default; needs CMDP_K1L_PIPE=0)")
-    ap.add_argument("--rollout-kernel", type=int, default=0, help="0 auto, 1 HBM tables, 2 LDS-resident K1L/K1P, 4 shared-table K1T")
+    ap.add_argument("--rollout-kernel", type=int, default=0, help="0 auto (K1E), 1 HBM tables, 2 LDS-resident K1L/K1P, 4 shared-table K1T, 5 K1U, 6 K1E")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): --instances per GPU; strong: --instances in TOTAL, rank r takes the contiguous block "
                          "[r*B/N, (r+1)*B/N) of SURVEY 8(e)")
@@ -256,13 +294,16 @@ def main():
     ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from the committed PMC summary instead of "
                     "measuring it in child runs under rocprofv3 (about 40 s)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the child run live_pmc() profiles
+    ap.add_argument("--pmc-child-vi", action="store_true", help=argparse.SUPPRESS)   # ... with the VI leg (the SQ pass)
     ap.add_argument("--layout", default="csr", choices=["csr", "dense"],
                     help="layout of the HEADLINE leg: csr (default, fastest) or dense (then --launch-steps applies to K1D)")
     args = ap.parse_args()
 
     if args.pmc_child:   # a few launches of the headline and dense kernels, nothing else, nothing printed
         args.steps, args.warmup, args.dense_steps = 3, 1, 2
-        args.no_cpu, args.no_live_pmc, args.vi_instances, args.sustained_seconds, args.strong_share = True, True, 0, 0.0, 0
+        args.no_cpu, args.no_live_pmc, args.sustained_seconds, args.strong_share = True, True, 0.0, 0
+        if not args.pmc_child_vi:
+            args.vi_instances = 0
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
@@ -372,6 +413,15 @@ def main():
     lds_kernel = plan["kernel"]
 
     elapsed, launch_ms = timed_launches(env, args.steps, args.launch_steps, args.warmup)
+    # the kernels of the LAST timed step (HIP events inside the library, on the stream the kernels run on, recorded while the
+    # steps ran back to back): parts of the step, so they add up to at most ms_per_step
+    timed_kernel_ms = {}
+    second_kernel = {"k_rollout_epi": "k_reward_scan", "k_rollout_tmpl_stream": "k_trace_hist"}.get(lds_kernel)
+    if second_kernel:
+        for name, which in ((lds_kernel, L.STAT_ROLLOUT_KERNEL_MS), (second_kernel, L.STAT_HIST_KERNEL_MS)):
+            v = C.c_double()
+            L.check(lib.cmdp_stat(env.handle, which, C.byref(v)))
+            timed_kernel_ms[name] = v.value
     elapsed = max_over_ranks(elapsed)
 
     # ---- final gather over RCCL (the only collective): per-instance episode counts = visits of the start state ----
@@ -407,7 +457,7 @@ def main():
         t_pmc = time.time()
         LIVE_PMC = live_pmc(["--instances", str(B), "--size", str(args.size), "--launch-steps", str(args.launch_steps),
                              "--dense-instances", str(args.dense_instances), "--dense-launch-steps", str(args.dense_launch_steps),
-                             "--rollout-kernel", str(args.rollout_kernel)])
+                             "--rollout-kernel", str(args.rollout_kernel), "--vi-instances", str(args.vi_instances)], timeout=240)
         t_pmc = time.time() - t_pmc
 
     units_per_launch = B * args.launch_steps
@@ -437,6 +487,54 @@ def main():
         hv = hbm_view(bytes_per_step, "SURVEY 8(d) dense-row figure (4*S+28 B/transition)", "k_rollout_dense", units_per_launch, avg_launch_s)
         roofline = {"bound": "hbm", "kernel": "k_rollout_dense<0,NV>", "achieved": hv["algorithmic_GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": hv["algorithmic_over_peak"], "traffic": hv["traffic"], "hbm": hv}
+    elif lds_kernel == "k_rollout_epi":
+        # K1E, the episode-parallel rollout: lane = (instance, episode), 4 096 independent 30-step chains per CU -- bound by
+        # instruction THROUGHPUT, not by a chain's latency.  Its roofline is hardware-anchored: wave-instructions issued
+        # (SQ_INSTS_VALU) and LDS-pipe cycles (SQ_LDS_IDX_ACTIVE) per launch from an SQ counter pass of THIS run, against the
+        # SIMDs' issue capacity and the CUs' LDS cycles over the kernel's duration.
+        hv = hbm_view(8 + 8 * 1 + 28, "SURVEY 8(d) CSR figure (8 + 8*nnz + 28 = 44 B/transition); the tables are LDS-resident, so "
+                      "these bytes never cross HBM -- reported as an equivalent rate, NOT a roofline fraction",
+                      "k_rollout_epi", units_per_launch, avg_launch_s)
+        k_ms = timed_kernel_ms.get("k_rollout_epi")
+        dom_s = (k_ms or avg_launch_s * 1e3) * 1e-3
+        sq = sq_view("k_rollout_epi", dom_s)
+        sq2 = sq_view("k_reward_scan", (timed_kernel_ms.get("k_reward_scan") or 0.0) * 1e-3)
+        episodes_pl = -(-args.launch_steps // int(env.H)) + 1
+        own_bytes = B * S * 4 + 12 * B * episodes_pl + 16 * B * S        # table image in, code + count words out, departure image RMW
+        scan_bytes = 12 * B * episodes_pl + 16 * B
+        pm_e, pm_r = pmc_entry("k_rollout_epi", units_per_launch, build_id), pmc_entry("k_reward_scan", units_per_launch, build_id)
+        peak2 = N_CUS * 4 * CLOCK_HZ / VALU_CYCLES / 1e9
+        roofline = {
+            "bound": "valu_issue", "kernel": "k_rollout_epi",
+            "unit": "G wave-instructions/s",
+            "achieved": sq["valu_G_wave_insts_per_s"] if sq else None, "peak": peak2,
+            "frac": sq["valu_G_wave_insts_per_s"] / peak2 if sq else None,
+            "model": "achieved = SQ_INSTS_VALU per launch (SQ pass of this run) / the kernel's duration in the timed region (HIP events "
+                     "inside the library); peak = %d CUs x 4 SIMDs x %.1f GHz / %d cycles per wave64 VALU instruction (MI355X_MICROARCH.md: "
+                     "the float32 figure)" % (N_CUS, CLOCK_HZ / 1e9, VALU_CYCLES),
+            "frac_at_measured_int_rate": sq["valu_G_wave_insts_per_s"] / (N_CUS * 4 * CLOCK_HZ / VALU_INT_VOP3_CYCLES / 1e9) if sq else None,
+            "int_rate_note": "the step's instructions (v_bfe_u32, v_lshl_or_b32, v_and_or_b32, v_alignbit_b32) occupy a SIMD for %.1f cycles "
+                             "per wavefront at 4-8 wavefronts per SIMD, not 2 (tools/calib/valu_int_rate.hip, profiles/r04_valu_int_rate.txt): "
+                             "against THAT issue rate the kernel is at frac_at_measured_int_rate" % VALU_INT_VOP3_CYCLES,
+            "transitions_per_s_in_kernel": units_per_launch / dom_s,
+            "valu_wave_insts_per_transition": sq["valu_wave_insts_per_launch"] * 64 / units_per_launch if sq else None,
+            "sq": sq, "lds_pipe_frac": sq["lds_pipe_frac"] if sq else None,
+            "kernel_ms": timed_kernel_ms, "kernel_ms_note": "of the last timed step, back to back with its neighbours: parts of ms_per_step",
+            "lds_plan": plan, "traffic": hv["traffic"],
+            "hbm": dict(hv, own_algorithmic_bytes_per_launch=own_bytes,
+                        own_accounting="k_rollout_epi itself: table image read once per workgroup (4 B per state), 12 B of reward-code + count words "
+                                       "written per episode, 16 B read-modify-write per state of the departure-count image",
+                        own_algorithmic_GBps=own_bytes / dom_s / 1e9,
+                        own_traffic_over_algorithmic=(pm_e["bytes"] / own_bytes) if pm_e else None),
+            "step": {
+                "what": "a step = k_rollout_epi (walk + departure counts) followed by k_reward_scan (float64 reward sums in transition order, "
+                        "added exactly in integers inside a binade); `achieved` / `frac` above are k_rollout_epi's over ITS duration",
+                "transitions_per_s": kernel_rate,
+                "reward_scan": {"kernel": "k_reward_scan", "bound": "latency (one wavefront per SIMD: 65 536 sequential sums)",
+                                "ms": timed_kernel_ms.get("k_reward_scan"), "sq": sq2,
+                                "algorithmic_bytes_per_launch": scan_bytes, "traffic": pm_r["bytes"] if pm_r else None},
+            },
+        }
     else:
         # The LDS-resident kernels: what bounds a launch is (instances / chains resident on the chip) x transitions x
         # the latency of the dependent LDS read chain of one transition.  The chain latency is measured in this run.
@@ -454,15 +552,7 @@ def main():
             footprint_txt = "swap bits per instance beside one shared %d-B table; capped by the 32 wavefronts of a CU and by the batch (B / %d CUs)" % (2 * S * A, N_CUS)
             # per-kernel times of a step (HIP events inside the library, on the stream the kernels run on): three more
             # launches outside the timed region, each read back
-            acc = {"k_rollout_tmpl_stream": [], "k_trace_hist": []}
-            for _ in range(3):
-                env.rollout_async(args.launch_steps)
-                env.synchronize()
-                for name, which in (("k_rollout_tmpl_stream", L.STAT_ROLLOUT_KERNEL_MS), ("k_trace_hist", L.STAT_HIST_KERNEL_MS)):
-                    v = C.c_double()
-                    L.check(lib.cmdp_stat(env.handle, which, C.byref(v)))
-                    acc[name].append(v.value)
-            kernel_ms = {k: float(np.mean(v)) for k, v in acc.items()}
+            kernel_ms = dict(timed_kernel_ms)   # of the last timed step (back to back): parts of ms_per_step
         elif shared_table:
             # K1T: ONE uint16 successor table per CU; a chain needs its 8-bit visit-count deltas and one swap bit per state
             min_footprint = S * A + (S + 7) // 8
@@ -561,9 +651,8 @@ def main():
             "ms_per_step": s_launch * 1e3, "env_steps_per_s_per_gpu": Bs * args.launch_steps / s_launch,
             "implied_value_at_n_gpus": args.strong_share * Bs * args.launch_steps / s_launch,
             "implied_speedup_vs_1_gpu": avg_launch_s / s_launch,
-            "note": "a launch lasts (rounds of workgroups) x (transitions) x (chain latency): with 1/8 of the instances a CU holds "
-                    "1/8 of the chains but the chain is as long, so the speed-up is far below 8 -- inherent to a latency-bound "
-                    "chain; weak scaling (65 536 per GPU, the default line) is what fills the chips",
+            "note": "K1E walks episodes, not instances: an eighth of the instances is an eighth of the workgroups and of the walk; "
+                    "what does not shrink is the reward scan (one sequential float64 sum per instance: latency-bound whatever the batch)",
         }
         senv.close()
 
@@ -635,8 +724,18 @@ def main():
               "model": "peak = %d CUs x 4 SIMDs x %.1f GHz / %d cycles per wave64 VALU instruction" % (N_CUS, CLOCK_HZ / 1e9, VALU_CYCLES),
               "hbm": {"bytes_per_sweep_csr_figure": 8 * nnz + 4 * (nS * 4 + 1) + 4 * nS * 4 + 8 * nS,
                       "note": "SURVEY 8(d) CSR figure; read from HBM once per SOLVE, not per sweep -- not a roofline"}}
+        live = (LIVE_PMC or {}).get(kname)
+        if live and "SQ_INSTS_VALU" in live and my_sweeps > 0:   # the SQ child pass of this run ran this very solve
+            per_sweep = live["SQ_INSTS_VALU"] / my_sweeps
+            vr["achieved"] = live["SQ_INSTS_VALU"] / (kms_dev.value * 1e-3) / 1e9
+            vr["frac"] = vr["achieved"] / vr["peak"]
+            vr["valu_wave_insts_per_workgroup_sweep"] = per_sweep
+            vr["lds_insts_per_sweep"] = live.get("SQ_INSTS_LDS", 0.0) / my_sweeps
+            vr["lds_bank_conflict_frac"] = live.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(live.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0)
+            vr["counter_source"] = "this run: rocprofv3 --pmc SQ child pass of bench.py (SQ_INSTS_VALU per launch / sweeps of the launch)"
+            vr["counters_measured_in_this_run"] = True
         try:
-            j = json.load(open(PMC_FILE))
+            j = json.load(open(PMC_FILE)) if vr["achieved"] is None else {}
             for k in j.get("kernels", []):
                 if k["kernel"].startswith(kname) and "valu_insts_per_sweep" in k:
                     inst = k["valu_insts_per_sweep"] * my_sweeps
