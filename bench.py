@@ -51,7 +51,7 @@ N_CUS = 256
 CLOCK_HZ = 2.4e9        # MI355X peak engine clock
 VALU_CYCLES = 2         # MI355X_MICROARCH.md, per-instruction constants: wave64 v_fma_f32 = 2 cycles per SIMD
 LDS_BYTES = 160 * 1024  # per CU
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
 
 
 class HipEvents:
@@ -174,25 +174,43 @@ SQ_COUNTERS = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "S
 VALU_INT_VOP3_CYCLES = 4.4
 
 
-def sq_view(kernel, launch_s):
-    """Hardware-anchored fractions of one kernel from the SQ child pass of THIS run: VALU issue (wave-instructions issued x
-    cycles per instruction / SIMD-cycles of the launch) and LDS pipe (SQ_LDS_IDX_ACTIVE per CU-cycle); None without the pass."""
-    v = (LIVE_PMC or {}).get(kernel)
-    if not v or "SQ_INSTS_VALU" not in v or "GRBM_GUI_ACTIVE" not in v:
+def sq_view(kernel, launch_s, units=None, build_id=None):
+    """Hardware-anchored fractions of one kernel: VALU issue (wave-instructions issued x cycles per instruction / SIMD-cycles
+    of the launch) and LDS pipe (SQ_LDS_IDX_ACTIVE per CU-cycle).  Counters from the SQ child pass of THIS run; without it
+    (N > 1, no rocprofv3, run under a profiler) from the committed summary of the same passes (profiles/r04_pmc.json,
+    tools/collect_profiles.sh), scaled to this launch's units -- instructions per transition belong to the build, which the
+    summary names.  The cycles are the launch's OWN duration in the timed region x the nominal clock."""
+    v, src, current = (LIVE_PMC or {}).get(kernel), None, True
+    if v and "SQ_INSTS_VALU" in v:
+        src = "this run: rocprofv3 --pmc %s child pass of bench.py, per-launch means" % " ".join(SQ_COUNTERS)
+    else:
+        v = None
+        try:
+            j = json.load(open(PMC_FILE))
+            for k in j.get("kernels", []):
+                if k["kernel"].split("<")[0] == kernel and "SQ_INSTS_VALU" in k and k.get("units_per_launch") and units:
+                    f = units / k["units_per_launch"]
+                    v = {c: k[c] * f for c in SQ_COUNTERS if c in k}
+                    current = j.get("build_id") == build_id
+                    src = "profiles/%s (collected on build %s = %s build), scaled by units per launch x %.4g" % (
+                        os.path.basename(PMC_FILE), j.get("build_id", "")[:16], "this" if current else "ANOTHER", f)
+        except Exception:
+            pass
+    if not v or not launch_s:
         return None
-    cyc = v["GRBM_GUI_ACTIVE"] / 8.0   # rocprofv3 sums the 8 XCDs
+    simd_cycles = N_CUS * 4 * launch_s * CLOCK_HZ
     out = {
-        "source": "this run: rocprofv3 --pmc %s child pass of bench.py, per-launch means" % " ".join(SQ_COUNTERS),
-        "kernel_cycles": cyc, "kernel_ms_under_profiler": cyc / CLOCK_HZ * 1e3,
+        "source": src, "counters_measured_in_this_run": src.startswith("this run"), "counters_current": current,
         "valu_wave_insts_per_launch": v["SQ_INSTS_VALU"], "lds_wave_insts_per_launch": v.get("SQ_INSTS_LDS"),
         "salu_wave_insts_per_launch": v.get("SQ_INSTS_SALU"),
-        "valu_issue_frac_at_2_cycles": v["SQ_INSTS_VALU"] * VALU_CYCLES / (N_CUS * 4 * cyc),
-        "valu_issue_frac_at_measured_int_rate": v["SQ_INSTS_VALU"] * VALU_INT_VOP3_CYCLES / (N_CUS * 4 * cyc),
-        "lds_pipe_frac": v.get("SQ_LDS_IDX_ACTIVE", 0.0) / (N_CUS * cyc),
+        "valu_G_wave_insts_per_s": v["SQ_INSTS_VALU"] / launch_s / 1e9,
+        "valu_issue_frac_at_2_cycles": v["SQ_INSTS_VALU"] * VALU_CYCLES / simd_cycles,
+        "valu_issue_frac_at_measured_int_rate": v["SQ_INSTS_VALU"] * VALU_INT_VOP3_CYCLES / simd_cycles,
+        "lds_pipe_frac": v.get("SQ_LDS_IDX_ACTIVE", 0.0) / (N_CUS * launch_s * CLOCK_HZ),
         "lds_bank_conflict_frac_of_lds_cycles": v.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(v.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0),
     }
-    if launch_s:
-        out["valu_G_wave_insts_per_s"] = v["SQ_INSTS_VALU"] / launch_s / 1e9
+    if "GRBM_GUI_ACTIVE" in v and src.startswith("this run"):
+        out["kernel_ms_under_profiler"] = v["GRBM_GUI_ACTIVE"] / 8.0 / CLOCK_HZ * 1e3   # rocprofv3 sums the 8 XCDs
     return out
 
 
@@ -214,6 +232,8 @@ def live_pmc(child_args, timeout=240):
     passes = [(["FETCH_SIZE"], child_args), (["WRITE_SIZE"], child_args), (SQ_COUNTERS, child_args + ["--pmc-child-vi"])]
     for counters, cargs in passes:
         d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        if counters is SQ_COUNTERS:
+            cargs = cargs + ["--pmc-child-out", os.path.join(d, "child.json")]
         cmd = [exe, "--pmc"] + counters + ["--kernel-trace", "-d", d, "--output-format", "csv", "--", sys.executable,
                os.path.abspath(__file__), "--pmc-child"] + cargs
         try:
@@ -221,10 +241,14 @@ def live_pmc(child_args, timeout=240):
                                stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
             files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
             if r.returncode != 0 or not files:
-                sys.stderr.write("bench.py: rocprofv3 --pmc %s child pass failed (rc %s): %s\n" % (" ".join(counters), r.returncode, r.stderr.decode(errors="replace")[-600:]))
+                err = r.stderr.decode(errors="replace")
+                sys.stderr.write("bench.py: rocprofv3 --pmc %s child pass failed (rc %s): %s\n" % (
+                    " ".join(counters), r.returncode, "\n".join(l for l in err.splitlines() if "rocprofv3" not in l and "output_stream" not in l)[-1500:]))
                 if counters is SQ_COUNTERS:
                     continue      # the traffic passes stand without the SQ pass
                 return None
+            if counters is SQ_COUNTERS and os.path.exists(os.path.join(d, "child.json")):
+                out["_child"] = json.load(open(os.path.join(d, "child.json")))
             acc = {}
             for row in csv.DictReader(open(files[0])):
                 name = row["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0]
@@ -242,7 +266,7 @@ def live_pmc(child_args, timeout=240):
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return {k: v for k, v in out.items() if ("read" in v and "write" in v) or "SQ_INSTS_VALU" in v}
+    return {k: v for k, v in out.items() if ("read" in v and "write" in v) or "SQ_INSTS_VALU" in v or k == "_child"}
 
 
 def pmc_entry(kernel_prefix, units_per_launch, build_id):
@@ -293,8 +317,11 @@ def main():
     ap.add_argument("--strong-share", type=int, default=8, help="rehearse one rank's share of a strong split over this many GPUs (0: skip)")
     ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from the committed PMC summary instead of "
                     "measuring it in child runs under rocprofv3 (about 40 s)")
+    ap.add_argument("--save-pmc", default="", help="write the counters measured by this run's child passes as the committed summary "
+                    "(profiles/r04_pmc.json): what runs without rocprofv3 -- N > 1, a profiled run -- scale their fractions from")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the child run live_pmc() profiles
     ap.add_argument("--pmc-child-vi", action="store_true", help=argparse.SUPPRESS)   # ... with the VI leg (the SQ pass)
+    ap.add_argument("--pmc-child-out", default="", help=argparse.SUPPRESS)           # ... which leaves its sweep count here
     ap.add_argument("--layout", default="csr", choices=["csr", "dense"],
                     help="layout of the HEADLINE leg: csr (default, fastest) or dense (then --launch-steps applies to K1D)")
     args = ap.parse_args()
@@ -302,8 +329,9 @@ def main():
     if args.pmc_child:   # a few launches of the headline and dense kernels, nothing else, nothing printed
         args.steps, args.warmup, args.dense_steps = 3, 1, 2
         args.no_cpu, args.no_live_pmc, args.sustained_seconds, args.strong_share = True, True, 0.0, 0
-        if not args.pmc_child_vi:
-            args.vi_instances = 0
+        # the VI leg of the SQ pass: a few instances built WITHOUT a process pool (the profiler's preload has initialised the GPU
+        # before main(): no fork() from here) -- instructions per sweep do not depend on how many instances are solved
+        args.vi_instances = min(256, args.vi_instances) if args.pmc_child_vi else 0
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
@@ -316,7 +344,7 @@ def main():
     # after the HIP runtime / RCCL have been initialised in this process.
     fl, fl_build_s = None, 0.0
     if args.vi_instances > 0:
-        workers = max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
+        workers = 1 if args.pmc_child else max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
         tb = time.time()
         fl = frozenlake_dp_tables(np.arange(rank * args.vi_instances, (rank + 1) * args.vi_instances), 20, workers)
         fl_build_s = time.time() - tb
@@ -459,6 +487,31 @@ def main():
                              "--dense-instances", str(args.dense_instances), "--dense-launch-steps", str(args.dense_launch_steps),
                              "--rollout-kernel", str(args.rollout_kernel), "--vi-instances", str(args.vi_instances)], timeout=240)
         t_pmc = time.time() - t_pmc
+        if LIVE_PMC and args.save_pmc:
+            ks = []
+            child_sweeps = (LIVE_PMC.get("_child") or {}).get("vi_sweeps_per_launch")
+            for k, v in LIVE_PMC.items():
+                if k == "_child":
+                    continue
+                e = {"kernel": k}
+                if "read" in v and "write" in v:
+                    e.update(hbm_read_bytes_per_launch=v["read"], hbm_write_bytes_per_launch=v["write"], hbm_bytes_per_launch=v["read"] + v["write"])
+                e.update({c: v[c] for c in SQ_COUNTERS if c in v})
+                if k in ("k_rollout_epi", "k_reward_scan", "k_epi_fold", "k_rollout_tmpl_stream", "k_trace_hist", "k_rollout_tmpl", "k_rollout_pipe", "k_rollout_lds"):
+                    e["units_per_launch"] = B * args.launch_steps
+                if k == "k_rollout_dense":
+                    e["units_per_launch"] = args.dense_instances * args.dense_launch_steps
+                if k.startswith("k_dp_reg") and child_sweeps and "SQ_INSTS_VALU" in v:
+                    e.update(sweeps_per_launch=child_sweeps, valu_insts_per_sweep=v["SQ_INSTS_VALU"] / child_sweeps,
+                             lds_insts_per_sweep=v.get("SQ_INSTS_LDS", 0.0) / child_sweeps,
+                             lds_bank_conflict_frac=v.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(v.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0))
+                ks.append(e)
+            json.dump({"build_id": build_id, "kernels": ks,
+                       "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced streaming reads -> x2 "
+                                     "(MI355X_MICROARCH.md, HBM section; calibrated with tools/calib/pmc_calib.hip); WRITE_SIZE exact",
+                       "source": "bench.py --save-pmc: per-launch means of its rocprofv3 child passes (--pmc FETCH_SIZE; --pmc WRITE_SIZE; "
+                                 "--pmc " + " ".join(SQ_COUNTERS) + "), --kernel-trace the only other option"},
+                      open(args.save_pmc, "w"), indent=1)
 
     units_per_launch = B * args.launch_steps
     total_steps = world * units_per_launch * args.steps
@@ -497,8 +550,8 @@ def main():
                       "k_rollout_epi", units_per_launch, avg_launch_s)
         k_ms = timed_kernel_ms.get("k_rollout_epi")
         dom_s = (k_ms or avg_launch_s * 1e3) * 1e-3
-        sq = sq_view("k_rollout_epi", dom_s)
-        sq2 = sq_view("k_reward_scan", (timed_kernel_ms.get("k_reward_scan") or 0.0) * 1e-3)
+        sq = sq_view("k_rollout_epi", dom_s, units_per_launch, build_id)
+        sq2 = sq_view("k_reward_scan", (timed_kernel_ms.get("k_reward_scan") or 0.0) * 1e-3, units_per_launch, build_id)
         episodes_pl = -(-args.launch_steps // int(env.H)) + 1
         own_bytes = B * S * 4 + 12 * B * episodes_pl + 16 * B * S        # table image in, code + count words out, departure image RMW
         scan_bytes = 12 * B * episodes_pl + 16 * B
@@ -696,6 +749,8 @@ def main():
         vi_V, vi_sweeps = np.array(V, copy=True), np.array(sw, copy=True)
         vi_s = max_over_ranks(time.perf_counter() - t1)
         my_sweeps = float(sw.sum())
+        if args.pmc_child and args.pmc_child_out:
+            json.dump({"vi_sweeps_per_launch": my_sweeps}, open(args.pmc_child_out, "w"))
         sweeps = sum_over_ranks(my_sweeps)
         kms, kid, kms_dev = C.c_double(), C.c_double(), C.c_double()
         L.check(lib.cmdp_stat(dp.handle, L.STAT_DP_KERNEL_MS, C.byref(kms)))
@@ -725,14 +780,16 @@ def main():
               "hbm": {"bytes_per_sweep_csr_figure": 8 * nnz + 4 * (nS * 4 + 1) + 4 * nS * 4 + 8 * nS,
                       "note": "SURVEY 8(d) CSR figure; read from HBM once per SOLVE, not per sweep -- not a roofline"}}
         live = (LIVE_PMC or {}).get(kname)
-        if live and "SQ_INSTS_VALU" in live and my_sweeps > 0:   # the SQ child pass of this run ran this very solve
-            per_sweep = live["SQ_INSTS_VALU"] / my_sweeps
-            vr["achieved"] = live["SQ_INSTS_VALU"] / (kms_dev.value * 1e-3) / 1e9
+        child_sweeps = ((LIVE_PMC or {}).get("_child") or {}).get("vi_sweeps_per_launch")
+        if live and "SQ_INSTS_VALU" in live and child_sweeps:   # the SQ child pass of this run solved a slice of this batch
+            per_sweep = live["SQ_INSTS_VALU"] / child_sweeps
+            vr["achieved"] = per_sweep * my_sweeps / (kms_dev.value * 1e-3) / 1e9
             vr["frac"] = vr["achieved"] / vr["peak"]
             vr["valu_wave_insts_per_workgroup_sweep"] = per_sweep
-            vr["lds_insts_per_sweep"] = live.get("SQ_INSTS_LDS", 0.0) / my_sweeps
+            vr["lds_insts_per_sweep"] = live.get("SQ_INSTS_LDS", 0.0) / child_sweeps
             vr["lds_bank_conflict_frac"] = live.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(live.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0)
-            vr["counter_source"] = "this run: rocprofv3 --pmc SQ child pass of bench.py (SQ_INSTS_VALU per launch / sweeps of the launch)"
+            vr["counter_source"] = ("this run: rocprofv3 --pmc SQ child pass of bench.py (SQ_INSTS_VALU per launch / sweeps of the launch, "
+                                    "the first 256 instances of this batch) x the sweeps of the timed solve")
             vr["counters_measured_in_this_run"] = True
         try:
             j = json.load(open(PMC_FILE)) if vr["achieved"] is None else {}

@@ -17,12 +17,13 @@ pytestmark = pytest.mark.gpu
 
 
 def test_c2_full_size_65536_deepsea30(need_gpu):
-    B, size, n = 65536, 30, 3000
+    B, size, n = 65536, 30, 30000   # SURVEY 8(d)'s C2 job itself: 1 000 episodes of every instance in one launch
     S = size * (size + 1) // 2
     seeds = np.arange(B, dtype=np.int64)
     tables = deepsea_episodic_tables(seeds, size, with_dp=False)
     keys = seeds.astype(np.uint64)
-    env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX, philox_keys=keys)   # automatic choice: LDS-resident kernel
+    env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX, philox_keys=keys)   # automatic choice: the episode-parallel kernel K1E
+    assert env.lds_plan()["kernel"] == "k_rollout_epi"
     env.reset()
     a = env.rollout(n)
     vs_a, vsa_a = env.visits()
@@ -30,7 +31,7 @@ def test_c2_full_size_65536_deepsea30(need_gpu):
     env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX, philox_keys=keys)
     env.set_rollout_kernel(L.ROLLOUT_GLOBAL)                                    # lane-per-instance HBM-table kernel
     env.reset()
-    b1 = env.rollout(1000)                                                      # launches compose: 1000 + 2000
+    b1 = env.rollout(1000)                                                      # launches compose: 1000 + 29000
     b2 = env.rollout(n - 1000)
     vs_b, vsa_b = env.visits()
     env.close()
@@ -38,12 +39,25 @@ def test_c2_full_size_65536_deepsea30(need_gpu):
     np.testing.assert_array_equal(vs_a, vs_b)
     np.testing.assert_array_equal(vsa_a, vsa_b)
     np.testing.assert_array_equal(a["last_obs"], b2["last_obs"])
-    # float64 reward sums: one launch adds 3000 terms in order, two launches add two partial sums -> rounding only
+    # float64 reward sums: one launch adds 30 000 terms in order, two launches add two partial sums -> rounding only
     np.testing.assert_allclose(a["reward_sum"], b1["reward_sum"] + b2["reward_sum"], rtol=1e-12, atol=0)
     # (ii) conservation: arrivals = transitions + resets, the same for every instance (fixed horizon)
     per_inst = vs_a.reshape(B, S).sum(1)
     assert (per_inst == n + 1 + n // size).all()
     assert (vsa_a.reshape(B, S * 2).sum(1) == n).all()
+    # (ii b) the chain kernels K1U and K1T on the same job: every counter again (the integer reward scan of K1E against their
+    # float64 adds: bit-equal sums)
+    for which in (L.ROLLOUT_LDS_TEMPLATE_STREAM, L.ROLLOUT_LDS_TEMPLATE):
+        env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX, philox_keys=keys)
+        env.set_rollout_kernel(which)
+        env.reset()
+        c = env.rollout(n)
+        vs_c, vsa_c = env.visits()
+        env.close()
+        np.testing.assert_array_equal(vs_a, vs_c)
+        np.testing.assert_array_equal(vsa_a, vsa_c)
+        np.testing.assert_array_equal(a["reward_sum"], c["reward_sum"])
+        np.testing.assert_array_equal(a["last_obs"], c["last_obs"])
     # (iii) the oracle on 64 instances taken from all over the batch
     for b0 in range(0, B, B // 4):
         last, rsum, cvs, _ = O.batch_rollout(tables, b0, b0 + 16, n, rng_mode=1, philox_keys=keys, want_visits=True)

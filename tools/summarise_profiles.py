@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copies what tools/collect_profiles.sh left under gpurun_out/TAG_* into profiles/ and writes profiles/r03_pmc.json,
+"""Copies what tools/collect_profiles.sh left under gpurun_out/TAG_* into profiles/ and writes profiles/r04_pmc.json,
 the summary bench.py reads for `roofline.traffic` (HBM bytes per launch: FETCH_SIZE x2 per the gfx950 correction for
 wide coalesced reads + WRITE_SIZE, separate --pmc passes) and for the VI leg's instruction counts (SQ_INSTS_VALU etc. per
 sweep).  The summary carries the build id of the library the passes ran on; bench.py reports whether that is the build
@@ -49,7 +49,9 @@ for leg, ks_ in legs.items():
             w.writerow([f"{tag}_{leg}", k, c, v, n])
 
 cfg = line["config"]
-units = {"k_rollout_pipe": cfg["instances_per_gpu"] * cfg["transitions_per_instance_per_step"],
+units = {"k_rollout_epi": cfg["instances_per_gpu"] * cfg["transitions_per_instance_per_step"],
+         "k_reward_scan": cfg["instances_per_gpu"] * cfg["transitions_per_instance_per_step"],
+         "k_rollout_pipe": cfg["instances_per_gpu"] * cfg["transitions_per_instance_per_step"],
          "k_rollout_tmpl_stream": cfg["instances_per_gpu"] * cfg["transitions_per_instance_per_step"],
          "k_trace_hist": cfg["instances_per_gpu"] * cfg["transitions_per_instance_per_step"],
          "k_rollout_tmpl": cfg["instances_per_gpu"] * cfg["transitions_per_instance_per_step"],
@@ -84,7 +86,7 @@ for k in sorted(names):
         e["kernel_cycles"] = cyc
         e["lds_idx_active_frac"] = e["SQ_LDS_IDX_ACTIVE"] / (256 * cyc)                     # LDS pipe busy, per CU
         e["valu_issue_frac_at_2_cycles"] = e["SQ_INSTS_VALU"] * 2 / (1024 * cyc)            # 1024 SIMDs, wave64 fp32 op = 2 cycles
-    if len(e) > 1 and ("rollout" in short or "dp_reg" in short or "trace_hist" in short):
+    if len(e) > 1 and ("rollout" in short or "dp_reg" in short or "trace_hist" in short or "reward_scan" in short or "epi_fold" in short):
         kernels.append(e)
 j = dict(build_id=None, tag=tag, kernels=kernels,
          correction="gfx950: FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced streaming reads -> x2 "
@@ -98,6 +100,6 @@ try:
     assert j["build_id"][:16] == under["build_id"], (j["build_id"][:16], under["build_id"])
 except ImportError:
     pass
-json.dump(j, open(f"{prof}/r03_pmc.json", "w"), indent=1)
+json.dump(j, open(f"{prof}/r04_pmc.json", "w"), indent=1)
 for e in kernels:
     print(e["kernel"], {k: (round(v, 3) if isinstance(v, float) else v) for k, v in e.items() if k != "kernel"})
