@@ -209,8 +209,12 @@ struct cmdp {
   K1ePlan k1e{};
   size_t k1e_lds = 0;
   DevBuf<uint32_t> d_etab;
-  DevBuf<uint2> d_k1e_codes;
-  DevBuf<uint32_t> d_k1e_cnts;
+  DevBuf<uint2> d_k1e_codes[2];    // two sets: the reward scan of one segment runs (second stream) under the walk of the next
+  DevBuf<uint32_t> d_k1e_cnts[2];
+  DevBuf<int32_t> d_k1e_h0b;       // second seg_h0 buffer
+  hipEvent_t ev_k1e_walk[2] = {nullptr, nullptr}, ev_k1e_scan[2] = {nullptr, nullptr};
+  bool ev_k1e_scan_used[2] = {false, false}, k1e_scan_pending = false;
+  int64_t k1e_seq = 0;
   DevBuf<int2> d_k1e_dep;          // departure counts of the K1E launches since the last fold (k_epi_fold)
   DevBuf<int32_t> d_k1e_dep_res, d_vis_ovf;
   bool k1e_pending = false;        // d_k1e_dep holds counts the visit counters do not have yet
@@ -284,10 +288,20 @@ int k1u_join(cmdp_t* h) {
   return CMDP_OK;
 }
 
+// ... the main stream waits for the reward scan K1E still owes on the second stream: before anything reads the reward sums
+int k1e_scan_join(cmdp_t* h) {
+  if (h->k1e_scan_pending) {
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_k1e_scan[(h->k1e_seq + 1) & 1], 0));
+    h->k1e_scan_pending = false;
+  }
+  return CMDP_OK;
+}
+
 // ... and the departure counts the episode-parallel rollout K1E has accumulated are turned into the visit counters
 int k1e_fold(cmdp_t* h);
 int visits_join(cmdp_t* h) {
   if (int rc = k1u_join(h)) return rc;
+  if (int rc = k1e_scan_join(h)) return rc;
   return k1e_fold(h);
 }
 
@@ -543,6 +557,10 @@ int cmdp_destroy(cmdp_t* h) {
   if (h->stream) {
     (void)hipStreamSynchronize(h->stream);
     (void)hipStreamDestroy(h->stream);
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (h->ev_k1e_walk[i]) (void)hipEventDestroy(h->ev_k1e_walk[i]);
+    if (h->ev_k1e_scan[i]) (void)hipEventDestroy(h->ev_k1e_scan[i]);
   }
   if (h->aux_stream) {
     (void)hipStreamSynchronize(h->aux_stream);
@@ -1405,29 +1423,59 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
     if (h->k1e_pending_steps + n_steps > 0x7fff0000LL) { if (int rc = k1e_fold(h)) return rc; }   // the departure image is int32
     e.dep = h->d_k1e_dep.p;
     e.dep_res = h->d_k1e_dep_res.p;
-    // segment length: the code words of a segment (8 bytes per episode chunk and instance) stay within ~1.5 GB
-    const int64_t budget_words = std::max<int64_t>(4, (int64_t)((1536ll << 20) / (12 * (int64_t)h->B * e.nch)));
+    // The reward scan of a segment runs on a second stream under the walk of the next segment / launch (two sets of code
+    // buffers): it is one wavefront per SIMD of sequential sums, the walk fills the rest of the chip (CMDP_K1E_OVERLAP=0: one
+    // stream).  cmdp_rollout / cmdp_synchronize / every call that reads the sums waits for it.
+    static const int ov_env = std::getenv("CMDP_K1E_OVERLAP") ? std::atoi(std::getenv("CMDP_K1E_OVERLAP")) : 1;
+    const bool ov = ov_env != 0;
+    if (ov && !h->aux_stream) HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+    if (ov && !h->ev_k1e_walk[0])
+      for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_k1e_walk[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_k1e_scan[i], hipEventDisableTiming));
+      }
+    if (!ov) { if (int rc = k1e_scan_join(h)) return rc; }
+    // segment length: the code words of a segment (12 bytes per episode chunk and instance, two sets) stay within ~1.5 GB
+    const int64_t budget_words = std::max<int64_t>(4, (int64_t)((768ll << 20) / (12 * (int64_t)h->B * e.nch)));
     const int64_t seg = std::max<int64_t>(e.H, std::min<int64_t>(K1E_SEG, (budget_words - 2) * e.H));
     const int64_t epi_cap = k1e_max_episodes(std::min<int64_t>(n_steps, seg), e.H);
     const size_t need = (size_t)epi_cap * (size_t)e.nch * (size_t)h->B;
-    if (h->d_k1e_codes.n < need) HIP_TRY(h->d_k1e_codes.alloc(need));
-    if (h->d_k1e_cnts.n < need) HIP_TRY(h->d_k1e_cnts.alloc(need));
     if (h->d_k1e_h0.n < (size_t)h->B) HIP_TRY(h->d_k1e_h0.alloc(h->B));
-    e.codes = h->d_k1e_codes.p;
-    e.cnts = h->d_k1e_cnts.p;
-    e.seg_h0 = h->d_k1e_h0.p;
+    if (h->d_k1e_h0b.n < (size_t)h->B) HIP_TRY(h->d_k1e_h0b.alloc(h->B));
     if (int rc = set_lds(k_rollout_epi, h->k1e_lds)) return rc;
     for (int64_t s0 = 0; s0 < n_steps; s0 += seg) {
       const int64_t n = std::min<int64_t>(seg, n_steps - s0);
+      const int i = ov ? (int)(h->k1e_seq & 1) : 0;
+      if (h->d_k1e_codes[i].n < need || h->d_k1e_cnts[i].n < need) {
+        if (h->aux_stream) HIP_TRY(hipStreamSynchronize(h->aux_stream));   // a scan may still read the buffers
+        HIP_TRY(h->d_k1e_codes[i].alloc(need));
+        HIP_TRY(h->d_k1e_cnts[i].alloc(need));
+      }
+      e.codes = h->d_k1e_codes[i].p;
+      e.cnts = h->d_k1e_cnts[i].p;
+      e.seg_h0 = i ? h->d_k1e_h0b.p : h->d_k1e_h0.p;
       e.n_pass = (int)((k1e_max_episodes(n, e.H) + K1E_EPP - 1) / K1E_EPP);
+      if (ov && h->ev_k1e_scan_used[i]) HIP_TRY(hipStreamWaitEvent(st, h->ev_k1e_scan[i], 0));   // its last scan has read this set
       const bool last = s0 + seg >= n_steps;
       if (last) HIP_TRY(hipEventRecord(h->ev_k1u[0], st));
       hipLaunchKernelGGL(k_rollout_epi, dim3(grid_for(h->B, K1E_NI)), dim3(K1E_THREADS), h->k1e_lds, st, t, e, (int)n, d_last);
       if (last) HIP_TRY(hipEventRecord(h->ev_k1u[1], st));
-      hipLaunchKernelGGL(k_reward_scan, dim3(grid_for(h->B, K1R_THREADS)), dim3(K1R_THREADS), 0, st, t, e, n, d_rsum, s0 > 0 ? 1 : 0);
-      if (last) HIP_TRY(hipEventRecord(h->ev_k1u[2], st));
+      if (ov) {
+        HIP_TRY(hipEventRecord(h->ev_k1e_walk[i], st));
+        HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_k1e_walk[i], 0));
+        if (last) HIP_TRY(hipEventRecord(h->ev_k1u[3], h->aux_stream));
+        hipLaunchKernelGGL(k_reward_scan, dim3(grid_for(h->B, K1R_THREADS)), dim3(K1R_THREADS), 0, h->aux_stream, t, e, n, d_rsum, s0 > 0 ? 1 : 0);
+        if (last) HIP_TRY(hipEventRecord(h->ev_k1u[4], h->aux_stream));
+        HIP_TRY(hipEventRecord(h->ev_k1e_scan[i], h->aux_stream));
+        h->ev_k1e_scan_used[i] = true;
+        h->k1e_scan_pending = true;
+        h->k1e_seq++;
+      } else {
+        hipLaunchKernelGGL(k_reward_scan, dim3(grid_for(h->B, K1R_THREADS)), dim3(K1R_THREADS), 0, st, t, e, n, d_rsum, s0 > 0 ? 1 : 0);
+        if (last) HIP_TRY(hipEventRecord(h->ev_k1u[2], st));
+      }
     }
-    h->k1u_last_overlap = false;
+    h->k1u_last_overlap = ov;
     h->k1e_pending = true;
     h->k1e_pending_steps += n_steps;
     HIP_TRY(hipGetLastError());
@@ -1602,6 +1650,7 @@ int cmdp_rollout(cmdp_t* h, int policy, const void* policy_arg, int64_t n_steps,
   };
   if (h->reward_cache) { if (int rc = rc_drive(h, launch)) return rc; }
   else if (int rc = launch(0)) return rc;
+  if (int rc = k1e_scan_join(h)) return rc;   // (K1E: the sums of the last segment come from the second stream)
   if (last_obs) HIP_TRY(hipMemcpyAsync(last_obs, h->d_last_obs.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
   if (reward_sum) HIP_TRY(hipMemcpyAsync(reward_sum, h->d_rsum.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
   if (trace_obs) HIP_TRY(hipMemcpyAsync(trace_obs, h->d_tr_obs.p, sizeof(int32_t) * NB, hipMemcpyDeviceToHost, st));
@@ -1688,7 +1737,9 @@ int cmdp_lds_plan(cmdp_t* h, int32_t plan[4]) {
 }
 
 int cmdp_synchronize(cmdp_t* h) {
-  if (int rc = bind(h)) return rc;
+  if (int rc = bind(h, false)) return rc;   // (the departure image of K1E stays as it is: nothing here reads the counters)
+  if (int rc = k1u_join(h)) return rc;
+  if (int rc = k1e_scan_join(h)) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
   return CMDP_OK;
 }

@@ -370,14 +370,24 @@ __global__ void __launch_bounds__(K1E_THREADS) k_epi_fold(EnvTables t, K1ePlan p
 // negative or a tie case -- the chunk is added step by step in float64, exactly as the oracle does, and (k, m, q) are
 // re-derived from the result.  An episode's code word holds the 2-bit reward codes of its steps, step j of a 32-step
 // chunk at bits 2 j of the 64-bit word (unused fields zero).
+// element `i` (run-time, per lane) of a register array of 16: a select tree instead of an LDS round trip -- the reward scan
+// keeps NO tile in LDS, so that its wavefronts fit beside k_rollout_epi's workgroups (whose tables take the CU's LDS)
+typedef uint32_t k1r_u32x16 __attribute__((ext_vector_type(16)));   // (a vector value, not an array: it cannot end up in scratch)
+__device__ __forceinline__ uint32_t k1r_sel16(const k1r_u32x16 a, int i) {
+  const bool i0 = (i & 1) != 0, i1 = (i & 2) != 0, i2 = (i & 4) != 0, i3 = (i & 8) != 0;
+  const uint32_t b0 = i0 ? a[1] : a[0], b1 = i0 ? a[3] : a[2], b2 = i0 ? a[5] : a[4], b3 = i0 ? a[7] : a[6];
+  const uint32_t b4 = i0 ? a[9] : a[8], b5 = i0 ? a[11] : a[10], b6 = i0 ? a[13] : a[12], b7 = i0 ? a[15] : a[14];
+  const uint32_t c0 = i1 ? b1 : b0, c1 = i1 ? b3 : b2, c2 = i1 ? b5 : b4, c3 = i1 ? b7 : b6;
+  const uint32_t d0 = i2 ? c1 : c0, d1 = i2 ? c3 : c2;
+  return i3 ? d1 : d0;
+}
+
 #define K1R_THREADS 64
 #define K1R_T 16   // code words per tile: the next tile's loads are in flight while a tile is summed
-__global__ void __launch_bounds__(K1R_THREADS) k_reward_scan(EnvTables t, K1ePlan p, int64_t n_steps,
+// (<= 128 VGPRs and 32 B of LDS: a wavefront of the scan fits on every SIMD beside k_rollout_epi's workgroup -- 4 x 96 VGPRs
+// per SIMD, 147 840 B of LDS per CU -- so that the scan of one segment runs under the walk of the next)
+__global__ void __launch_bounds__(K1R_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) k_reward_scan(EnvTables t, K1ePlan p, int64_t n_steps,
                                                             double* __restrict__ reward_sum, int accumulate) {
-  // a tile that does not advance in one piece: lane-private columns (lane i = bank i) of the prefix sums of its words' packed
-  // counts and steps and of its code words, read back with a run-time index by the search below
-  __shared__ uint32_t tile_P[K1R_T][K1R_THREADS], tile_S[K1R_T][K1R_THREADS];
-  __shared__ uint32_t tile_lo[K1R_T][K1R_THREADS], tile_hi[K1R_T][K1R_THREADS];
   __shared__ double rvt[4];
   const int lane = threadIdx.x;
   const int b = min(blockIdx.x * K1R_THREADS + lane, t.B - 1);   // (lanes past the batch repeat its last instance, unstored)
@@ -389,7 +399,7 @@ __global__ void __launch_bounds__(K1R_THREADS) k_reward_scan(EnvTables t, K1ePla
     rv[c] = c < p.n_codes ? p.rvals[c] * t.rscale - t.rmin : 0.0;
     bulk_allowed = bulk_allowed && rv[c] >= 0.0 && rv[c] < 1.0e300;
   }
-  if (lane < 4) rvt[lane] = rv[lane];
+  if (lane < 4) rvt[lane] = lane < p.n_codes ? p.rvals[lane] * t.rscale - t.rmin : 0.0;
   __syncthreads();
   // per code: mantissa with the hidden bit and biased exponent of the reward (zero / subnormal rewards: eb = 0)
   unsigned long long mv[4];
@@ -410,10 +420,10 @@ __global__ void __launch_bounds__(K1R_THREADS) k_reward_scan(EnvTables t, K1ePla
   const uint32_t* nsrc = p.cnts + b;
   // integer form of the sum, valid while `kvalid`: S = m * 2^(kb - 1075) with 2^52 <= m < 2^53 (kb = biased exponent);
   // q[c] = round(rv[c] / spacing) as (low, high) halves; `tie`: codes whose presence forces the float64 path (a tie case in
-  // this binade, a subnormal reward, a reward at or above 2^(k+1)); dmax >= the advance of m over one code word
+  // this binade, a subnormal reward, a reward at or above 2^(k+1))
   bool kvalid = false;
   int kb = 0;
-  unsigned long long m = 0ull, dmax = 0ull;
+  unsigned long long m = 0ull;
   uint32_t qlo[4] = {0u, 0u, 0u, 0u}, qhi[4] = {0u, 0u, 0u, 0u};
   uint32_t tie = 0u;
   auto rebase = [&]() {
@@ -423,7 +433,6 @@ __global__ void __launch_bounds__(K1R_THREADS) k_reward_scan(EnvTables t, K1ePla
     kb = (int)(sb >> 52);
     m = (sb & M52) | B52;
     tie = 0u;
-    unsigned long long qmax = 0ull;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       unsigned long long qq = 0ull;
@@ -439,15 +448,10 @@ __global__ void __launch_bounds__(K1R_THREADS) k_reward_scan(EnvTables t, K1ePla
       }
       qlo[c] = (uint32_t)qq;
       qhi[c] = (uint32_t)(qq >> 32);
-      qmax = qq > qmax ? qq : qmax;
     }
-    dmax = qmax * 32ull;   // q < 2^54
     kvalid = true;
   };
   rebase();
-  // Could a word among the next `words` leave the integer form?  Only then are its code words fetched as well (the counts
-  // always are): m advances by at most dmax per word, so below this bound every one of them is added in integers.
-  auto risky = [&](int words) -> bool { return !kvalid || tie != 0u || m + dmax * (unsigned long long)words >= (1ull << 53); };
   // m + the advance of `steps` (<= 512) transitions with packed counts nw; true = the whole of it stays in the integer form
   auto advance = [&](uint32_t nw, uint32_t steps, unsigned long long& m2) -> bool {
     const uint32_t n1 = nw & 0x7ffu, n2 = (nw >> 11) & 0x7ffu, n3 = nw >> 22, n0 = steps - n1 - n2 - n3;
@@ -468,18 +472,16 @@ __global__ void __launch_bounds__(K1R_THREADS) k_reward_scan(EnvTables t, K1ePla
   int ep_left = e_len;                                 // ... not yet covered by earlier chunks
   int64_t tot_left = n_steps;                          // steps from the current episode's first one on
 
-  uint32_t rn[K1R_T];
-  u32x2 rc[K1R_T];
-  bool have_next = risky(K1R_T);
+  // two tiles of count words in flight (rnA, rnB alternate): one tile's sums cover about a third of an HBM round trip
+  uint32_t rnA[K1R_T], rnB[K1R_T];
 #pragma unroll
   for (int k = 0; k < K1R_T; ++k) {
-    rn[k] = k < W ? __builtin_nontemporal_load(&nsrc[(size_t)k * t.B]) : 0u;
-    rc[k] = (have_next && k < W) ? __builtin_nontemporal_load(&csrc[(size_t)k * t.B]) : u32x2{0u, 0u};
+    rnA[k] = k < W ? __builtin_nontemporal_load(&nsrc[(size_t)k * t.B]) : 0u;
+    rnB[k] = K1R_T + k < W ? __builtin_nontemporal_load(&nsrc[(size_t)(K1R_T + k) * t.B]) : 0u;
   }
-  for (int w0 = 0; w0 < W; w0 += K1R_T) {
-    const bool have = have_next;
+  auto tile = [&](uint32_t (&rn)[K1R_T], const int w0) {
     // prefix sums of the tile's packed counts and steps (0 steps: a chunk a partial episode does not reach, or past the end)
-    uint32_t P[K1R_T], SP[K1R_T];
+    k1r_u32x16 P, SP;
     // interior tiles of single-chunk episodes (all lanes): every word holds H steps
     const bool interior = nch == 1 && __all(w0 >= 1 && w0 + K1R_T <= W - 1);
     if (interior) {
@@ -509,28 +511,14 @@ __global__ void __launch_bounds__(K1R_THREADS) k_reward_scan(EnvTables t, K1ePla
     const uint32_t Pt = P[K1R_T - 1], St = SP[K1R_T - 1];
     unsigned long long m2;
     const bool whole = advance(Pt, St, m2);
-    if (!__all(whole)) {   // some lane leaves the integer form inside this tile: lay the tile out for the search
-#pragma unroll
-      for (int k = 0; k < K1R_T; ++k) {
-        tile_P[k][lane] = P[k];
-        tile_S[k][lane] = SP[k];
-        tile_lo[k][lane] = rc[k].x;
-        tile_hi[k][lane] = rc[k].y;
-      }
-    }
-    // the next tile's loads: its words are at most 2 K1R_T words ahead of the state the bound is taken from
-    have_next = risky(2 * K1R_T);
+    // the count words of the tile after the next (the code words of a word are fetched only when that word has to be added
+    // step by step)
     {
-      const uint32_t* nn = nsrc + (size_t)(w0 + K1R_T) * t.B;
-      const u32x2* cn = csrc + (size_t)(w0 + K1R_T) * t.B;
+      const uint32_t* nn = nsrc + (size_t)(w0 + 2 * K1R_T) * t.B;
 #pragma unroll
-      for (int k = 0; k < K1R_T; ++k) {
-        const bool in = w0 + K1R_T + k < W;
-        rn[k] = in ? __builtin_nontemporal_load(&nn[(size_t)k * t.B]) : 0u;
-        rc[k] = (have_next && in) ? __builtin_nontemporal_load(&cn[(size_t)k * t.B]) : u32x2{0u, 0u};
-      }
+      for (int k = 0; k < K1R_T; ++k) rn[k] = (w0 + 2 * K1R_T + k < W) ? __builtin_nontemporal_load(&nn[(size_t)k * t.B]) : 0u;
     }
-    if (whole) { m = m2; continue; }
+    if (whole) { m = m2; return; }
     // ---- this lane: the first word that does not advance (binary search over the prefix sums: advancing is monotone --
     // q >= 0, and a forcing code stays present), everything before it in one piece, that word in float64 step by step
     // exactly as the oracle adds, then the rest of the tile again ----
@@ -542,17 +530,16 @@ __global__ void __launch_bounds__(K1R_THREADS) k_reward_scan(EnvTables t, K1ePla
 #pragma unroll
       for (int it = 0; it < 4; ++it) {   // 2^4 = K1R_T
         const int mid = (lo + hi) >> 1;
-        const bool ok = advance(tile_P[mid][lane] - base_n, tile_S[mid][lane] - base_s, m2);
+        const bool ok = advance(k1r_sel16(P, mid) - base_n, k1r_sel16(SP, mid) - base_s, m2);
         if (lo < hi) { if (ok) lo = mid + 1; else hi = mid; }
       }
       const int k = lo;
-      if (k > from && advance(tile_P[k - 1][lane] - base_n, tile_S[k - 1][lane] - base_s, m2)) m = m2;
-      const uint32_t Sk = tile_S[k][lane], Sk1 = k > 0 ? tile_S[k - 1][lane] : 0u;
+      const uint32_t Sk1 = k > 0 ? k1r_sel16(SP, k - 1) : 0u;
+      if (k > from && advance(k1r_sel16(P, k - 1) - base_n, Sk1 - base_s, m2)) m = m2;
+      const uint32_t Sk = k1r_sel16(SP, k);
       const uint32_t L = Sk - Sk1;
       if (L) {
-        u32x2 c;
-        if (have) { c.x = tile_lo[k][lane]; c.y = tile_hi[k][lane]; }
-        else c = csrc[(size_t)(w0 + k) * t.B];   // (never taken: `risky` is an upper bound; kept as the exact fallback)
+        const u32x2 c = csrc[(size_t)(w0 + k) * t.B];
         if (kvalid) S = compose();
         for (uint32_t j0 = 0; j0 < L; j0 += 8) {
           const uint32_t cw = (j0 < 16 ? c.x >> (2 * j0) : c.y >> (2 * (j0 - 16)));
@@ -564,10 +551,14 @@ __global__ void __launch_bounds__(K1R_THREADS) k_reward_scan(EnvTables t, K1ePla
         }
         rebase();
       }
-      base_n = tile_P[k][lane];
+      base_n = k1r_sel16(P, k);
       base_s = Sk;
       from = k + 1;
     }
+  };
+  for (int w0 = 0; w0 < W; w0 += 2 * K1R_T) {
+    tile(rnA, w0);
+    if (w0 + K1R_T < W) tile(rnB, w0 + K1R_T);
   }
   if (kvalid) S = compose();
   if (mine) reward_sum[b] = S;
