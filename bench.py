@@ -149,6 +149,8 @@ def sustained_leg(env, ev, launch_steps, seconds, B):
             env.rollout_async(launch_steps)
         n += 64
         env.synchronize()
+        if n % 1024 == 0:
+            env.reset_visits()   # (the device visit counters are int32: the library refuses launches that could wrap them)
     ev.record(b, stream)
     ms = ev.elapsed_ms(a, b)
     wall = time.perf_counter() - t0

@@ -8,8 +8,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcmdp.so")
 
-OK, ERR_INVALID, ERR_HIP, ERR_NEEDS_RESET, ERR_UNSUPPORTED, ERR_MAX_ITER, ERR_NO_DEVICE, ERR_MAX_VALUE = (
-    0, -1, -2, -3, -4, -5, -6, -7)
+OK, ERR_INVALID, ERR_HIP, ERR_NEEDS_RESET, ERR_UNSUPPORTED, ERR_MAX_ITER, ERR_NO_DEVICE, ERR_MAX_VALUE, ERR_OVERFLOW = (
+    0, -1, -2, -3, -4, -5, -6, -7, -8)
 RNG_MT_COMPAT, RNG_PHILOX = 0, 1
 POLICY_RANDOM, POLICY_HOST_ACTIONS, POLICY_GREEDY_Q = 0, 1, 2
 SCHEME_AUTO, SCHEME_JACOBI, SCHEME_GAUSS_SEIDEL = 0, 1, 2
@@ -41,7 +41,7 @@ ROLLOUT_EPISODE_PARALLEL = 6  # K1E: lane = (instance, episode): episodic batche
 EXPORTS = [
     "cmdp_version", "cmdp_build_id", "cmdp_last_error", "cmdp_device_count", "cmdp_set_device", "cmdp_create", "cmdp_destroy",
     "cmdp_stream", "cmdp_reset", "cmdp_step", "cmdp_rollout", "cmdp_rollout_async", "cmdp_synchronize", "cmdp_stat", "cmdp_calibrate", "cmdp_set_option", "cmdp_lds_plan",
-    "cmdp_visits", "cmdp_reset_visits", "cmdp_state", "cmdp_last_start", "cmdp_vi_discounted", "cmdp_pe_discounted",
+    "cmdp_visits", "cmdp_reset_visits", "cmdp_set_visits", "cmdp_state", "cmdp_last_start", "cmdp_vi_discounted", "cmdp_pe_discounted",
     "cmdp_vi_episodic", "cmdp_pe_episodic", "cmdp_diameter", "cmdp_diameter_episodic", "cmdp_value_norm", "cmdp_gth", "cmdp_qlearning_create", "cmdp_qlearning_destroy", "cmdp_qlearning_run",
     "cmdp_qlearning_tables", "cmdp_qlearning_evaluate", "cmdp_greedy_policy_episodic", "cmdp_qlearning_continuous_create",
     "cmdp_qlearning_policy", "cmdp_qlearning_average_reward", "cmdp_qlearning_run_logged", "cmdp_tracker_replay", "cmdp_average_reward", "cmdp_diameter_range", "cmdp_diameter_sparse_f64", "cmdp_mixing_time", "cmdp_set_observation_table", "cmdp_observe", "cmdp_observe_noise",
@@ -160,6 +160,7 @@ def load():
         L.cmdp_lds_plan.argtypes = [vp, vp]
         L.cmdp_visits.argtypes = [vp, vp, vp]
         L.cmdp_reset_visits.argtypes = [vp]
+        L.cmdp_set_visits.argtypes = [vp, vp, vp]
         L.cmdp_state.argtypes = [vp, vp, vp, vp]
         L.cmdp_last_start.argtypes = [vp, vp, vp]
         L.cmdp_vi_discounted.argtypes = [vp, f32, f64, i32, i64, f64, vp, vp, vp, vp]

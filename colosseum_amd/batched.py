@@ -238,6 +238,12 @@ class BatchedMDP:
     def reset_visits(self):
         L.check(self._lib.cmdp_reset_visits(self._h))
 
+    def set_visits(self, state_counts=None, sa_counts=None):
+        """Restores the visit counters (cmdp_set_visits): int64 arrays as `visits()` returns them; None leaves one as it is."""
+        vs = None if state_counts is None else np.ascontiguousarray(state_counts, np.int64)
+        vsa = None if sa_counts is None else np.ascontiguousarray(sa_counts, np.int64)
+        L.check(self._lib.cmdp_set_visits(self._h, L.ptr(vs) if vs is not None else None, L.ptr(vsa) if vsa is not None else None))
+
     def state(self):
         cur = np.zeros(self.B, np.int32)
         h = np.zeros(self.B, np.int32)

@@ -217,6 +217,7 @@ struct cmdp {
   int64_t k1e_seq = 0;
   DevBuf<int2> d_k1e_dep;          // departure counts of the K1E launches since the last fold (k_epi_fold)
   DevBuf<int32_t> d_k1e_dep_res, d_vis_ovf;
+  int64_t vis_bound = 0;           // upper bound of every device visit counter (int32): CMDP_ERR_OVERFLOW guard
   bool k1e_pending = false;        // d_k1e_dep holds counts the visit counters do not have yet
   int64_t k1e_pending_steps = 0;   // transitions per instance since the last fold (the departure image is int32)
   DevBuf<int32_t> d_k1e_h0;
@@ -303,6 +304,17 @@ int visits_join(cmdp_t* h) {
   if (int rc = k1u_join(h)) return rc;
   if (int rc = k1e_scan_join(h)) return rc;
   return k1e_fold(h);
+}
+
+// The device visit counters are int32.  No counter can grow by more than two per transition (the arrival and, when the
+// episode ends there, the reset), so `vis_bound` bounds all of them; a call that could carry one past 2^31 - 1 is refused.
+int visits_room(cmdp_t* h, int64_t n_transitions) {
+  if (h->vis_bound + 2 * n_transitions > 0x7fffffffLL)
+    return fail(CMDP_ERR_OVERFLOW, "a visit counter (int32 on the device) could wrap: up to %lld counted since the last "
+                "cmdp_reset_visits / cmdp_set_visits, %lld more transitions asked for -- read the counters (cmdp_visits) and reset them",
+                (long long)h->vis_bound, (long long)n_transitions);
+  h->vis_bound += 2 * n_transitions;
+  return CMDP_OK;
 }
 
 int bind(cmdp_t* h, bool join = true) {
@@ -1159,6 +1171,7 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
 int cmdp_reset(cmdp_t* h, const uint8_t* mask, int32_t* obs_out) {
   if (int rc = bind(h)) return rc;
   if (!h->has_env) return fail(CMDP_ERR_INVALID, "handle was created without the sampler half");
+  if (int rc = visits_room(h, 1)) return rc;
   hipStream_t st = h->stream;
   uint8_t* dmask = nullptr;
   if (mask) {
@@ -1184,6 +1197,9 @@ template <typename F>
 static int rc_drive(cmdp_t* h, F&& launch) {
   hipStream_t st = h->stream;
   const int B = h->B;
+  // refused before anything is stepped: a lane that parks has already committed its transition
+  if (!h->rc_streams_set)
+    return fail(CMDP_ERR_INVALID, "CMDP_FLAG_REWARD_CACHE: cmdp_set_reward_streams has not been called on this handle");
   HIP_TRY(h->d_rc_park_count.zero(st));
   if (int rc = launch(0)) return rc;
   for (;;) {
@@ -1260,6 +1276,21 @@ int cmdp_set_reward_streams(cmdp_t* h, const uint32_t* mt_key, const int32_t* mt
     rs.has_gauss = has_gauss ? has_gauss[b] : 0;
     rs.gauss = cached_gaussian ? cached_gaussian[b] : 0.0;
   }
+  if (h->rc_streams_set && h->reward_cache) {
+    // repositioned streams = a new run on a fresh copy of every MDP (BaseMDP.sample_reward starts with empty caches,
+    // colosseum/mdp/base.py:1187-1207): the blocks installed on the device, their positions and any parked step are dropped;
+    // the pool's chunks are handed out again from the start
+    if (int rc = bind(h)) return rc;
+    hipStream_t st = h->stream;
+    HIP_TRY(h->d_rc_blk.zero(st));
+    HIP_TRY(h->d_rc_pos.zero(st));
+    HIP_TRY(hipMemsetAsync(h->d_rc_pend_e.p, 0xff, sizeof(int32_t) * (size_t)B, st));
+    HIP_TRY(h->d_rc_left.zero(st));
+    HIP_TRY(h->d_rc_park_count.zero(st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::fill(h->rc_blk_h.begin(), h->rc_blk_h.end(), nullptr);
+    h->rc_next_block = 0;
+  }
   h->rc_streams_set = true;
   return CMDP_OK;
 }
@@ -1297,6 +1328,7 @@ int cmdp_step(cmdp_t* h, const int32_t* actions, int auto_reset, int32_t* obs, d
   if (!h->has_env) return fail(CMDP_ERR_INVALID, "handle was created without the sampler half");
   if (!actions || !obs || !reward || !step_type) return fail(CMDP_ERR_INVALID, "null argument");
   if (h->layout == CMDP_LAYOUT_DENSE) return fail(CMDP_ERR_UNSUPPORTED, "dense layout: use cmdp_rollout");
+  if (int rc = visits_room(h, 1)) return rc;
   hipStream_t st = h->stream;
   const int B = h->B;
   if (h->d_i32_scratch.n < (size_t)2 * B) HIP_TRY(h->d_i32_scratch.alloc((size_t)2 * B));
@@ -1619,6 +1651,7 @@ int cmdp_rollout(cmdp_t* h, int policy, const void* policy_arg, int64_t n_steps,
   if (policy != CMDP_POLICY_RANDOM && policy != CMDP_POLICY_HOST_ACTIONS && policy != CMDP_POLICY_GREEDY_Q)
     return fail(CMDP_ERR_INVALID, "policy");
   if (policy != CMDP_POLICY_RANDOM && !policy_arg && n_steps > 0) return fail(CMDP_ERR_INVALID, "policy_arg missing");
+  if (int rc = visits_room(h, n_steps)) return rc;
   bool any = false;
   if (int rc = any_needs_reset(h, &any)) return rc;
   if (any) return fail(CMDP_ERR_NEEDS_RESET, "rollout() on an instance that needs reset()");
@@ -1665,6 +1698,7 @@ int cmdp_rollout_async(cmdp_t* h, int policy, int64_t n_steps) {
   if (!h->has_env) return fail(CMDP_ERR_INVALID, "handle was created without the sampler half");
   if (policy != CMDP_POLICY_RANDOM) return fail(CMDP_ERR_INVALID, "rollout_async supports CMDP_POLICY_RANDOM only");
   if (n_steps < 0) return fail(CMDP_ERR_INVALID, "n_steps < 0");
+  if (int rc = visits_room(h, n_steps)) return rc;
   if (!h->known_reset) {  // one 4-byte read-back on the first call after create / cmdp_step, none afterwards
     bool any = false;
     if (int rc = any_needs_reset(h, &any)) return rc;
@@ -1852,6 +1886,31 @@ int cmdp_reset_visits(cmdp_t* h) {
   HIP_TRY(h->d_visits_s.zero(h->stream));
   HIP_TRY(h->d_visits_sa.zero(h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  h->vis_bound = 0;
+  return CMDP_OK;
+}
+
+int cmdp_set_visits(cmdp_t* h, const int64_t* state_counts, const int64_t* sa_counts) {
+  if (int rc = bind(h)) return rc;   // (folds what K1E still holds: the restored values replace everything)
+  if (!h->has_env) return fail(CMDP_ERR_INVALID, "handle was created without the sampler half");
+  hipStream_t st = h->stream;
+  int64_t top = 0;
+  std::vector<int32_t> tmp;
+  for (int which = 0; which < 2; ++which) {
+    const int64_t* src = which ? sa_counts : state_counts;
+    if (!src) continue;
+    const size_t n = (size_t)(which ? h->n_rows : h->n_states);
+    tmp.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+      if (src[i] < 0 || src[i] > 0x7fffffffLL) return fail(CMDP_ERR_INVALID, "visit count %lld at index %zu does not fit the device's int32 counters", (long long)src[i], i);
+      tmp[i] = (int32_t)src[i];
+      top = std::max(top, src[i]);
+    }
+    HIP_TRY(hipMemcpyAsync(which ? h->d_visits_sa.p : h->d_visits_s.p, tmp.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  // a counter left as it was keeps its old bound
+  h->vis_bound = (state_counts && sa_counts) ? top : std::max(h->vis_bound, top);
   return CMDP_OK;
 }
 
@@ -3622,6 +3681,7 @@ static int ql_launch(cmdp_agent_t* a, int64_t n_steps, const uint8_t* dmask, int
 // the kernel is relaunched); otherwise nothing is synchronised.
 // `cum_host` (nullable): page-locked host array that receives the running reward sums at the end of the launch.
 static int ql_enqueue_run(cmdp_agent_t* a, int64_t n_steps, const uint8_t* dmask, int8_t* d_actions, double* cum_host = nullptr) {
+  if (int rc = visits_room(a->env, n_steps)) return rc;
   if (a->env->reward_cache)
     return rc_drive(a->env, [&](int resume) -> int { return ql_launch(a, n_steps, dmask, d_actions, resume, cum_host); });
   return ql_launch(a, n_steps, dmask, d_actions, 0, cum_host);

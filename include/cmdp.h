@@ -38,8 +38,11 @@ enum {
   CMDP_ERR_MAX_ITER = -5,    /* DynamicProgrammingMaxIterationExceeded,
                                 colosseum/dynamic_programming/utils.py:8-9                          */
   CMDP_ERR_NO_DEVICE = -6,   /* no HIP device visible                                               */
-  CMDP_ERR_MAX_VALUE = -7    /* |V| exceeded max_abs_value: the reference returns None,
+  CMDP_ERR_MAX_VALUE = -7,   /* |V| exceeded max_abs_value: the reference returns None,
                                 colosseum/dynamic_programming/infinite_horizon.py:136-138           */
+  CMDP_ERR_OVERFLOW = -8     /* a device visit counter (int32) could wrap during this call: refused before anything is
+                                stepped -- read the counters out (cmdp_visits widens them to int64) and
+                                cmdp_reset_visits first; the reference's Python ints do not wrap      */
 };
 
 /* Random-number discipline of the transition sampler. */
@@ -306,6 +309,12 @@ int cmdp_lds_plan(cmdp_t* h, int32_t plan[4]);
    state_counts [state_off[B]], sa_counts [state_off[B]*A]; either may be NULL. */
 int cmdp_visits(cmdp_t* h, int64_t* state_counts, int64_t* sa_counts);
 int cmdp_reset_visits(cmdp_t* h);
+/* Restores the counters (e.g. of an earlier run that is being continued: the reference's MDPs are pickled with their
+   counts).  Either array may be NULL (left as it is); every value must fit the device's int32 counters.  The device
+   counters are int32: the library keeps an upper bound of what any of them can hold (largest restored value + two per
+   transition taken since -- an arrival and, at an episode end, the reset) and refuses a call that could carry one past
+   2^31 - 1 with CMDP_ERR_OVERFLOW, before anything is stepped. */
+int cmdp_set_visits(cmdp_t* h, const int64_t* state_counts, const int64_t* sa_counts);
 /* Current state index, in-episode step and needs-reset flag of every instance (BaseMDP.cur_node,
    .h, .necessary_reset); each may be NULL. */
 int cmdp_state(cmdp_t* h, int32_t* cur, int32_t* hstep, uint8_t* needs_reset);

@@ -102,3 +102,84 @@ def test_c4_at_its_real_length(need_gpu, tmp_path):
         assert lines[1].split(",")[lines[0].split(",").index("steps")] == "100"
         assert lines[5000].split(",")[lines[0].split(",").index("steps")] == "499999"
     print("C4 at full length: %.1f s wall, %.3g agent steps/s" % (s["wall_s"], s["agent_steps_per_s"]))
+
+
+def test_c4_at_its_real_length_reference_streams(need_gpu, tmp_path):
+    """Config C4 at full length in the mode whose rows ARE the reference's (the runner's default): MT19937 transition samplers
+    and the reference's per-triple caches of 5000 Beta samples filled from every MDP's own numpy stream
+    (colosseum/mdp/base.py:1187-1207; budget colosseum/benchmark/experiment_config.yml:1-4).  The summary is pinned, and five
+    instances -- spread over the suites, Beta-reward settings among them, every one crossing cache refills and MDPLoop's
+    training freeze where it happens -- are re-run alone through the per-instance path `GpuMDP` + `MDPLoop` + numpy agent
+    (bit-equal to the reference loop on the goldens G7 / G10 / G17) for ALL 500 000 steps: their 5 000 CSV rows must be the
+    batch's, column for column."""
+    import csv
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    suites = ["benchmark_episodic_ergodic", "benchmark_episodic_communicating", "benchmark_continuous_ergodic",
+              "benchmark_continuous_communicating"]
+    args = ["tools/run_benchmark.py", "--configs-json", os.path.join(GOLDEN, "G11_benchmark_configs.json")]
+    for b in suites:
+        args += ["--benchmark", b]
+    args += ["--out", str(tmp_path / "c4r"), "--beta-rewards", "reference"]
+    s = json.loads(_run([sys.executable] + args, timeout=600).strip().splitlines()[-1])
+    assert s["instances"] == s["run"] == 1000 and s["steps_each"] == 500000 and s["skipped_existing"] == 0
+    assert s["mean_normalized_cumulative_regret"] == pytest.approx(378726.1747486397, rel=1e-12)
+    print("C4 at full length, reference streams: %.1f s wall" % s["wall_s"])
+    # five instances alone (side by side, a process each), all 500 000 steps, against the files the batch run wrote
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+
+    from helpers_c4 import run_instance_alone
+
+    picks = [("benchmark_episodic_ergodic", 3), ("benchmark_episodic_communicating", 41), ("benchmark_continuous_ergodic", 7),
+             ("benchmark_continuous_communicating", 123), ("benchmark_episodic_ergodic", 200)]
+    with ProcessPoolExecutor(max_workers=5, mp_context=mp.get_context("spawn")) as pool:
+        alone = list(pool.map(run_instance_alone, [(su, i, 500000, 100, GOLDEN) for su, i in picks]))
+    for (suite, idx), res in zip(picks, alone):
+        path = tmp_path / "c4r" / "logs" / res["label"] / ("seed%d_logs.csv" % res["seed"])
+        assert path.exists(), (suite, idx, res["label"])
+        rows = list(csv.DictReader(open(path, newline="")))
+        assert len(rows) == len(res["rows"]) == 5000
+        for got, ref in zip(rows, res["rows"]):
+            for k in ref:
+                assert float(got[k]) == pytest.approx(ref[k], rel=1e-6, abs=1e-5), (suite, idx, k, got["steps"])
+    assert sum(r["beta"] for r in alone) >= 2
+
+
+def _n_devices():
+    """HIP devices visible, asked of a child process: this process must not touch the GPU before it spawns ranks."""
+    code = "import sys; sys.path.insert(0, %r); from colosseum_amd import _lib as L; print(L.load().cmdp_device_count())" % ROOT
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=ENV, capture_output=True, text=True, timeout=300)
+    return int(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 and p.stdout.strip() else 0
+
+
+def test_two_ranks_over_rccl_when_the_box_has_two_gpus(need_gpu, tmp_path):
+    """The "nccl" (= RCCL over xGMI) branches of bench.py, tools/run_benchmark.py and tools/run_c5.py -- one rank per GPU, the
+    driver's launcher -- on the first box that HAS two GPUs; on the one-GPU test boxes this skips itself (the same entry points
+    run there with gloo and a shared device, above).  Ranks are spawned before anything in this process touches HIP."""
+    if _n_devices() < 2:
+        pytest.skip("one HIP device visible: the RCCL branches need two (gloo + shared device covers the rest above)")
+    small = [a for a in SMALL if a not in ("--share-gpu", "--dist-backend", "gloo")]
+    line = json.loads(_run(_torchrun(2, 29741) + ["bench.py", "--gpus", "2"] + small).strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "gather_ms" in line and line["roofline"]["frac"] <= 1.0
+    args = ["tools/run_benchmark.py", "--configs-json", os.path.join(GOLDEN, "G11_benchmark_configs.json"), "--benchmark",
+            "benchmark_episodic_quick_test", "--steps", "1500", "--seeds", "3", "--log-every", "500"]
+    s1 = json.loads(_run([sys.executable] + args + ["--out", str(tmp_path / "one")]).strip().splitlines()[-1])
+    s2 = json.loads(_run(_torchrun(2, 29742) + args + ["--out", str(tmp_path / "two")]).strip().splitlines()[-1])
+    assert s1["mean_normalized_cumulative_regret"] == s2["mean_normalized_cumulative_regret"]
+    c5 = ["tools/run_c5.py", "--room-size", "6", "--n-rooms", "4"]
+    one = json.loads(_run([sys.executable] + c5).strip().splitlines()[-1])
+    two = json.loads(_run(_torchrun(2, 29743) + c5).strip().splitlines()[-1])
+    assert two["world"] == 2 and one["diameter"] == two["diameter"]
+
+
+def test_c5_at_its_real_size_diameter_and_mixing_time(need_gpu):
+    """Config C5 as BASELINE.json states it: MiniGridRoomsContinuous(room_size=28, n_rooms=16), S = 50 272 -- the diameter
+    over ALL targets (K5C; three targets re-solved by the CPU oracle, bit-equal) and the build-defined mixing time of the
+    uniform policy's chain (dense float64 matrix powers in HBM, 20 GB each), both pinned."""
+    out = json.loads(_run([sys.executable, "tools/run_c5.py", "--mixing", "--check", "3"], timeout=900).strip().splitlines()[-1])
+    assert out["n_states"] == 50272 and out["targets_this_rank"] == 50272
+    assert out["diameter"] == 259.99786376953125 and out["oracle_check"] is True
+    mx = out["mixing_time"]
+    assert mx["t_mix"] == 49391 and 0.0 < mx["tv_at_t_mix"] <= 0.25
+    print("C5 at full size: diameter %.2f s, mixing time %.1f s" % (out["solve_s"], mx["seconds"]))

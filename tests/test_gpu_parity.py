@@ -336,6 +336,47 @@ def test_lds_rollout_with_per_instance_episode_phase(need_gpu):
         np.testing.assert_array_equal(g[2][off[b]:off[b + 1]], e.visits()[0])
 
 
+def test_visit_counter_overflow_is_refused_not_wrapped(need_gpu):
+    """The device counters are int32 (cmdp_visits widens them); the reference's are Python ints.  A counter restored near
+    2^31 (cmdp_set_visits) must make a call that could carry it past 2^31 - 1 fail with CMDP_ERR_OVERFLOW BEFORE anything is
+    stepped -- for every rollout kernel, the per-step API and reset -- and the handle stays usable."""
+    from colosseum_amd.mdp.fast_batch import deepsea_episodic_tables
+
+    tables = deepsea_episodic_tables(np.arange(40), 6)
+    for which in (L.ROLLOUT_AUTO, L.ROLLOUT_GLOBAL, L.ROLLOUT_LDS_TEMPLATE_STREAM):
+        env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX, philox_keys=np.arange(40, dtype=np.uint64) + 5)
+        env.set_rollout_kernel(which)
+        env.reset()
+        env.rollout(600)
+        vs, vsa = env.visits()
+        start = int(tables["start_state"][0])
+        vs2 = vs.copy()
+        vs2[start] = 2**31 - 1 - 200            # instance 0's start state: 100 more transitions are the most that is safe
+        env.set_visits(vs2, vsa)
+        before = [a.copy() for a in env.state()]
+        with pytest.raises(L.CmdpError) as ei:
+            env.rollout(101)
+        assert ei.value.code == L.ERR_OVERFLOW
+        for a, b in zip(before, env.state()):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(env.visits()[0], vs2)        # nothing was counted
+        env.rollout(100)                                           # this much fits
+        vs3, _ = env.visits()
+        assert vs3[start] > vs2[start] and vs3.min() >= 0 and vs3[start] <= 2**31 - 1
+        with pytest.raises(L.CmdpError) as ei:
+            env.step(np.zeros(40, np.int32))
+        assert ei.value.code == L.ERR_OVERFLOW
+        env.reset_visits()
+        env.rollout(5000)                                          # counters cleared: room again
+        assert env.visits()[0].reshape(40, -1).sum(1).min() >= 5000
+        env.close()
+    with pytest.raises(L.CmdpError):                               # values beyond int32 cannot be restored
+        env = BatchedMDP(tables=tables, rng_mode=L.RNG_PHILOX)
+        bad = np.zeros(int(tables["state_off"][-1]), np.int64)
+        bad[3] = 2**31
+        env.set_visits(bad, None)
+
+
 def test_lds_kernel_refused_when_not_eligible(need_gpu):
     m = make_model("FrozenLakeContinuous", seed=0, size=5, p_frozen=0.9)
     env = BatchedMDP([m], rng_mode=L.RNG_PHILOX, with_dp=False)

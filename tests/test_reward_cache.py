@@ -87,6 +87,56 @@ def _kwargs(c):
 
 
 @pytest.mark.gpu
+def test_repositioned_reward_streams_start_from_empty_caches(need_gpu):
+    """cmdp_set_reward_streams called again = a new run on a fresh copy of every MDP: the blocks already installed on the device
+    (and their read positions) must not be served any more -- a fresh BaseMDP starts with empty caches
+    (colosseum/mdp/base.py:1187-1207).  Deterministic dynamics, Beta rewards: a first leg of whole episodes leaves the
+    instances in their reset state with half-used caches on the device; after repositioning the streams to their initial
+    states a second leg must equal what a handle that never ran gives, reward for reward.  A handle built from bare tables
+    with CMDP_FLAG_REWARD_CACHE and no streams refuses to step BEFORE anything is stepped."""
+    from colosseum_amd.batched import BatchedMDP, tables_from_models
+
+    ms = [make_model("DeepSeaEpisodic", seed=s, size=6, make_reward_stochastic=True) for s in (3, 4, 5)]
+    H = ms[0].H
+    rs = np.random.RandomState(11)
+    n1, n2 = 1000 * H, 777 * H + 3
+    a1 = rs.randint(0, 2, (n1, 3)).astype(np.int8)
+    a2 = rs.randint(0, 2, (n2, 3)).astype(np.int8)
+    states = [m.extra["rng_state"] for m in ms]
+    env = BatchedMDP(ms, rng_mode=L.RNG_MT_COMPAT, flags=L.FLAG_REWARD_CACHE, with_dp=False)
+    env.reset()
+    env.rollout(n1, a1)
+    assert env.reward_cache_stats()["fills"] > 0
+    cur, h, _ = env.state()
+    assert (h == 0).all() and (cur == ms[0].start_states[0]).all()   # whole episodes: back in the reset state
+    env.set_reward_streams(states)                                    # a new run: streams at their initial states, EMPTY caches
+    x = env.rollout(n2, a2, trace=True)
+    fresh = BatchedMDP(ms, rng_mode=L.RNG_MT_COMPAT, flags=L.FLAG_REWARD_CACHE, with_dp=False)
+    fresh.reset()
+    y = fresh.rollout(n2, a2, trace=True)
+    np.testing.assert_array_equal(x["obs"], y["obs"])
+    np.testing.assert_array_equal(x["rew"], y["rew"])
+    np.testing.assert_array_equal(x["reward_sum"], y["reward_sum"])
+    env.close()
+    fresh.close()
+    # no streams: refused before anything moves
+    t = tables_from_models(ms[:2], True, False)
+    env = BatchedMDP(tables=t, rng_mode=L.RNG_MT_COMPAT, flags=L.FLAG_REWARD_CACHE)
+    env.reset()
+    before = [a.copy() for a in env.state()]
+    with pytest.raises(L.CmdpError) as ei:
+        env.rollout(50, np.zeros((50, 2), np.int8))
+    assert ei.value.code == L.ERR_INVALID and "cmdp_set_reward_streams" in str(ei.value)
+    for a, b in zip(before, env.state()):
+        np.testing.assert_array_equal(a, b)
+    vs, vsa = env.visits()
+    assert vs.sum() == 2 and vsa.sum() == 0      # the two resets, no transition
+    env.set_reward_streams([m.extra["rng_state"] for m in ms[:2]])
+    env.rollout(50, np.zeros((50, 2), np.int8))   # and the handle is usable afterwards
+    env.close()
+
+
+@pytest.mark.gpu
 def test_g8_through_batched_rollout_and_step(need_gpu):
     """The reference's Beta-reward trajectories (7 000 steps, caches refilled) through the BATCHED path: every case three
     times in one batch (instances park and resume independently), observations / rewards / step types bit-equal."""

@@ -112,8 +112,9 @@ def check_one():
             assert np.array_equal(env.split_states(vs)[b], e.visits()[0]), tag
         env.close()
         # the other rollout kernels on the same streams: HBM tables (K1), the LDS kernels where the batch is eligible
-        # (K1L / K1P, the shared-table K1T, the stochastic-dynamics K1S)
-        for which in (L.ROLLOUT_GLOBAL, L.ROLLOUT_LDS, L.ROLLOUT_LDS_TEMPLATE, L.ROLLOUT_LDS_TEMPLATE_STREAM, L.ROLLOUT_LDS_STOCHASTIC):
+        # (K1L / K1P, the shared-table K1T / K1U, the stochastic-dynamics K1S, the episode-parallel K1E)
+        for which in (L.ROLLOUT_GLOBAL, L.ROLLOUT_LDS, L.ROLLOUT_LDS_TEMPLATE, L.ROLLOUT_LDS_TEMPLATE_STREAM, L.ROLLOUT_LDS_STOCHASTIC,
+                      L.ROLLOUT_EPISODE_PARALLEL):
             env = BatchedMDP([m] * 3, rng_mode=L.RNG_PHILOX, philox_keys=keys, with_dp=False)
             env.set_rollout_kernel(which)
             env.reset()

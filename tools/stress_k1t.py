@@ -15,21 +15,24 @@ from colosseum_amd.batched import BatchedMDP  # noqa: E402
 from colosseum_amd.mdp.fast_batch import deepsea_episodic_tables  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
-# second argument "k1u": the streamed-trace form K1U (k_rollout_tmpl_stream + k_trace_hist) instead of K1T
+# second argument "k1u": the streamed-trace form K1U (k_rollout_tmpl_stream + k_trace_hist) instead of K1T;
+# "k1e": the episode-parallel kernel K1E (k_rollout_epi + k_reward_scan; DeepSea-40 has too many states for it and is skipped;
+# CMDP_K1E_OVERLAP as in the environment: the reward scan on the second stream or not)
+K1E = len(sys.argv) > 2 and sys.argv[2] == "k1e"
 K1U = len(sys.argv) > 2 and sys.argv[2] == "k1u"
-WHICH = L.ROLLOUT_LDS_TEMPLATE_STREAM if K1U else L.ROLLOUT_LDS_TEMPLATE
+WHICH = L.ROLLOUT_EPISODE_PARALLEL if K1E else L.ROLLOUT_LDS_TEMPLATE_STREAM if K1U else L.ROLLOUT_LDS_TEMPLATE
 GENV = "CMDP_K1U_G" if K1U else "CMDP_K1T_G"
-KNAME = "k_rollout_tmpl_stream" if K1U else "k_rollout_tmpl"
+KNAME = "k_rollout_epi" if K1E else "k_rollout_tmpl_stream" if K1U else "k_rollout_tmpl"
 rng = np.random.default_rng(7)
 t_end = time.time() + budget
 cases = 0
 while time.time() < t_end:
-    size = int(rng.choice([3, 4, 5, 8, 13, 21, 30, 40]))
-    B = int(rng.choice([1, 63, 64, 65, 127, 128, 129, 1000, 128 * 256 - 1, 128 * 256 + 1, 40000, 65536]))
+    size = int(rng.choice([3, 4, 5, 8, 13, 21, 30, 31] if K1E else [3, 4, 5, 8, 13, 21, 30, 40]))
+    B = int(rng.choice([1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 1000, 128 * 256 - 1, 128 * 256 + 1, 40000, 65536]))
     if size >= 30 and B > 40000 and rng.integers(0, 3):
         B = 40000
     g = int(rng.choice([0, 0, 17, 64, 65, 100, 128] + ([129, 200, 255, 256] if K1U else [])))   # 0: the library's own choice
-    lens = [int(x) for x in rng.choice([1, 2, 3, 31, 32, 33, 63, 64, 65, 255, 257, 3551, 3553, 4097, 9001, 30001] + ([32767, 32769, 70001] if K1U else []),
+    lens = [int(x) for x in rng.choice([1, 2, 3, 31, 32, 33, 63, 64, 65, 255, 257, 3551, 3553, 4097, 9001, 30001] + ([32767, 32769, 70001] if K1U else []) + ([29, 30, 59, 60, 61, 3839, 3840, 3841, 30000, 61439, 61441, 70001] if K1E else []),
                                        size=int(rng.integers(1, 4)))]
     seeds = rng.integers(0, 1 << 30, B)
     tables = deepsea_episodic_tables(seeds, size)
@@ -67,4 +70,4 @@ while time.time() < t_end:
         assert np.array_equal(x, y), (size, B, g, lens)
     cases += 1
     print("stress_k1t: case %d ok (size %d, %d instances, G %s, launches %s)" % (cases, size, B, g or "auto", lens), flush=True)
-print("stress_k1t: %d cases, %s == K1 in every counter" % (cases, "K1U" if K1U else "K1T"))
+print("stress_k1t: %d cases, %s == K1 in every counter" % (cases, "K1E" if K1E else "K1U" if K1U else "K1T"))
