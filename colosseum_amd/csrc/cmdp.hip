@@ -238,6 +238,7 @@ struct cmdp {
   DevBuf<float> d_k5c_red;          // K5C: the clusters' partial reductions
   DevBuf<unsigned int> d_k5c_bar;   // K5C: barrier counters + error flag
   int64_t k5c_launches = 0, k5c_timeouts = 0;
+  int k5c_skip = 0, k5c_backoff = 0;   // after a give-up K5C is skipped for `k5c_backoff` calls (8, 16, ... 1024), then tried again
   bool k5c_agent_scope = false;     // K5C: a cluster was found spread over XCDs once -- agent-scope barriers from then on
   size_t dl_ws_bytes = (size_t)24 << 30;  // value arrays of the target groups in flight per launch
   // observation tables (k_emit)
@@ -1480,8 +1481,17 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
       const int i = ov ? (int)(h->k1e_seq & 1) : 0;
       if (h->d_k1e_codes[i].n < need || h->d_k1e_cnts[i].n < need) {
         if (h->aux_stream) HIP_TRY(hipStreamSynchronize(h->aux_stream));   // a scan may still read the buffers
-        HIP_TRY(h->d_k1e_codes[i].alloc(need));
-        HIP_TRY(h->d_k1e_cnts[i].alloc(need));
+        if (h->d_k1e_codes[i].alloc(need) != hipSuccess || h->d_k1e_cnts[i].alloc(need) != hipSuccess) {
+          // no room for the code words (12 bytes per episode and instance): the chain kernels need no workspace -- this
+          // handle takes them from now on (possible before the first segment only: the buffers never shrink)
+          (void)hipGetLastError();
+          if (s0 > 0) return fail(CMDP_ERR_HIP, "K1E: out of device memory for the code words of a later segment");
+          h->d_k1e_codes[i].release();
+          h->d_k1e_cnts[i].release();
+          h->k1e_ok = false;
+          if (h->rollout_kernel == 6) return fail(CMDP_ERR_HIP, "K1E: out of device memory for %zu code words", need);
+          return launch_rollout(h, policy, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype, d_q, resume);
+        }
       }
       e.codes = h->d_k1e_codes[i].p;
       e.cnts = h->d_k1e_cnts[i].p;
@@ -1549,7 +1559,16 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
       const int i = ov ? (int)(h->k1u_seq & 1) : 0;
       if (h->d_k1u_trace[i].n < need) {
         if (ov && h->aux_stream) HIP_TRY(hipStreamSynchronize(h->aux_stream));   // the buffer may still be read
-        HIP_TRY(h->d_k1u_trace[i].alloc(need));
+        if (h->d_k1u_trace[i].alloc(need) != hipSuccess) {
+          // no room for the trace (16 bytes per 8-12 transitions and instance): K1T counts in LDS and needs none -- this
+          // handle takes it from now on (possible before the first segment only: the buffer never shrinks)
+          (void)hipGetLastError();
+          if (s0 > 0) return fail(CMDP_ERR_HIP, "K1U: out of device memory for the trace of a later segment");
+          h->d_k1u_trace[i].release();
+          h->k1u_ok = false;
+          if (h->rollout_kernel == 5) return fail(CMDP_ERR_HIP, "K1U: out of device memory for a trace of %zu pieces", need);
+          return launch_rollout(h, policy, d_actions, n_steps, d_rsum, d_last, d_tobs, d_trew, d_ttype, d_q, resume);
+        }
       }
       if (h->d_k1u_resets[i].n < (size_t)h->B) HIP_TRY(h->d_k1u_resets[i].alloc(h->B));
       u.trace = h->d_k1u_trace[i].p;
@@ -2016,8 +2035,12 @@ int run_sweeps(cmdp_t* h, int mode, bool diam, int scheme, DpTables t, int64_t u
     if (mode == DP_VI) hipLaunchKernelGGL((k_dp_regw<DP_VI, AT, 5, 4, ST>), grid, dim3(64), ldsw, st, t);          \
     else hipLaunchKernelGGL((k_dp_regw<DP_PE, AT, 5, 4, ST>), grid, dim3(64), ldsw, st, t);                        \
   } else
+      // (only instantiations that keep their tables in registers: with four actions, seven states per lane -- and six under
+      // policy evaluation, which also holds the policy's rows -- spill to scratch; those batches take K2U below)
       REGW_CASE(2, 5) REGW_CASE(2, 6) REGW_CASE(2, 7) REGW_CASE(3, 5) REGW_CASE(3, 6) REGW_CASE(3, 7)
-      REGW_CASE(4, 5) REGW_CASE(4, 6) REGW_CASE(4, 7)
+      REGW_CASE(4, 5)
+      if (A == 4 && st_w == 6 && mode == DP_VI) hipLaunchKernelGGL((k_dp_regw<DP_VI, 4, 5, 4, 6>), grid, dim3(64), ldsw, st, t);
+      else
       { done = false; }
 #undef REGW_CASE
       if (done) {
@@ -2026,7 +2049,8 @@ int run_sweeps(cmdp_t* h, int mode, bool diam, int scheme, DpTables t, int64_t u
         h->zc_used = h->zc_V != nullptr;
         return CMDP_OK;
       }
-      if (h->dp_kernel == 7) return fail(CMDP_ERR_UNSUPPORTED, "no one-wavefront instantiation for A=%d", A);
+      if (h->dp_kernel == 7) return fail(CMDP_ERR_UNSUPPORTED, "no one-wavefront instantiation for A=%d, %d states per lane%s", A, st_w,
+                                         mode == DP_PE ? " (policy evaluation)" : "");
     }
     if (want_u) {
       bool done = true;
@@ -2546,7 +2570,11 @@ static int diameter_lanes(cmdp_t* h, DpTables t, int64_t unit_lo, int64_t unit_h
   // CMDP_K5C = 0 switches it off, = CL (8 | 16 | 32) chooses the cluster size (tuning aid)
   const int k5c_env = std::getenv("CMDP_K5C") ? std::atoi(std::getenv("CMDP_K5C")) : -1;   // read per call: the tests switch it
   const int CLs = k5c_env > 0 ? k5c_env : 16;
-  const bool use_cluster = ell_ok && k5c_env != 0 && h->cus % (8 * CLs) == 0 && h->max_S >= h->relabel_min_states;
+  // (a give-up costs every workgroup its 2-second spin: on a GPU that other streams / ranks keep busy the persistent launch is
+  // not tried again at once -- the back-off doubles with every consecutive give-up; CMDP_K5C > 0 overrides it)
+  const bool backing_off = h->k5c_skip > 0 && k5c_env <= 0;
+  if (backing_off) h->k5c_skip--;
+  const bool use_cluster = ell_ok && k5c_env != 0 && h->cus % (8 * CLs) == 0 && h->max_S >= h->relabel_min_states && !backing_off;
   const int64_t GW = 64;  // targets per group
   for (int b = 0; b < h->B; ++b) {
     const int64_t so = h->state_off[b], S = h->state_off[b + 1] - so;
@@ -2603,9 +2631,11 @@ static int diameter_lanes(cmdp_t* h, DpTables t, int64_t unit_lo, int64_t unit_h
       int err = 0;
       HIP_TRY(hipMemcpyAsync(&err, ca.err, sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
-      if (!err) { h->k5c_launches++; return CMDP_OK; }
+      if (!err) { h->k5c_launches++; h->k5c_backoff = 0; return CMDP_OK; }
       if (err == 2 && pass == 0) { h->k5c_agent_scope = true; continue; }   // this device does not deal workgroups as assumed
       h->k5c_timeouts++;   // a cluster's workgroups were not all resident: the groups are solved again, one workgroup each
+      h->k5c_backoff = std::min(1024, std::max(8, 2 * h->k5c_backoff));
+      h->k5c_skip = h->k5c_backoff;
       break;
     }
   }
@@ -3859,8 +3889,12 @@ int cmdp_qlearning_run_logged(cmdp_agent_t* a, const cmdp_loop_desc* d, int64_t 
     if (h->d_cur_snap.n < (size_t)B) HIP_TRY(h->d_cur_snap.alloc(B));
   }
   const double atol = episodic ? 1e-4 : 1e-5;
+  // rows within reach of the time limit run in order: "within reach" follows the longest row seen so far (a park round of
+  // the reward caches, a throttled host, sixteen batches sharing the GPU can make one row take seconds)
+  double longest_row = 0.0, last_row_done = elapsed();
+  bool limit_passed_while_ahead = false;
   auto mask_may_change = [&](const Row& r) -> bool {
-    if (d->max_time - elapsed() < 5.5) return true;
+    if (limit_passed_while_ahead || d->max_time - elapsed() < std::max(5.5, 3.0 * longest_row)) return true;
     for (int b = 0; b < B; ++b) {
       const Instance& x = tr.inst[(size_t)b];
       if (!episodic && !x.training && !x.cached) return true;   // the cached evaluation is taken at this row: `need` changes
@@ -3931,6 +3965,11 @@ int cmdp_qlearning_run_logged(cmdp_agent_t* a, const cmdp_loop_desc* d, int64_t 
     const auto c1 = now();
     HIP_TRY(hipEventSynchronize(h->ev_row[1]));
     const auto c2 = now();
+    {
+      const double e = elapsed();
+      longest_row = std::max(longest_row, e - last_row_done);
+      last_row_done = e;
+    }
     t_enq += secs(c0, c1);
     t_wait += secs(c1, c2);
     const double sps = (double)r.t / std::max(elapsed(), 1e-9);
@@ -3949,7 +3988,10 @@ int cmdp_qlearning_run_logged(cmdp_agent_t* a, const cmdp_loop_desc* d, int64_t 
     }
     if (!r.in_loop) { t_host += secs(c2, now()); break; }
     bool changed = false;
-    const bool out_of_time = d->max_time - elapsed() < 0.5;  // `_limit_exceeded` (agent_mdp_interaction.py:172-177) for the batch
+    // `_limit_exceeded` (agent_mdp_interaction.py:172-177) for the batch.  Should the limit pass on a row whose successor is
+    // already running (a row far longer than any before it), the freeze is recorded at the next row -- which then runs in order
+    bool out_of_time = d->max_time - elapsed() < 0.5;
+    if (out_of_time && ahead) { limit_passed_while_ahead = true; out_of_time = false; }
     for (int b = 0; b < B; ++b) {
       if (out_of_time && tr.inst[(size_t)b].training) {
         tr.inst[(size_t)b].training = false;

@@ -2593,7 +2593,10 @@ __device__ __forceinline__ bool cluster_barrier(unsigned int* bar, unsigned int&
 template <int CL, int A, int K, bool XCD>
 __global__ void __launch_bounds__(1024) k_diam_cluster(DpTables t, DiamLanesArgs g, DiamClusterArgs ca, const int32_t* __restrict__ ecol,
                                                       const float* __restrict__ eval_, const int32_t* __restrict__ new_of) {
-  constexpr int NW = 16, AK = A * K, U = 64 / AK, XCDS = 8;
+  // U states in flight per wavefront: the 64 / AK whose entries one 64-lane load fetches -- at most eight (A = K = 2 would
+  // hold sixteen states x four gathered rows in registers: 12 bytes of scratch under the 128-register cap of a 1024-thread
+  // workgroup)
+  constexpr int NW = 16, AK = A * K, U = (64 / AK > 10) ? 8 : 64 / AK, XCDS = 8;
   static_assert(U >= 1, "A*K must not exceed 64");
   __shared__ float red_d[NW][64];
   __shared__ float red_m[NW][64];

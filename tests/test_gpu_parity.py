@@ -459,14 +459,22 @@ def test_register_resident_sweeps_equal_workgroup_kernel_and_oracle(need_gpu):
             dp.set_dp_kernel(which)
             pis = [np.random.RandomState(5 + i).dirichlet(np.ones(A), m.n_states).astype(np.float32) for i, m in enumerate(models)]
             try:
-                outs[which] = (dp.value_iteration(0.99, 1e-5, L.SCHEME_JACOBI), dp.policy_evaluation(pis, 0.95, 1e-6, L.SCHEME_JACOBI))
+                vi = dp.value_iteration(0.99, 1e-5, L.SCHEME_JACOBI)
             except L.CmdpError as e:  # K2U exists for <= 8 distinct successors per state; it must say so otherwise
                 assert which in (L.DP_REGISTER_DISTINCT, L.DP_REGISTER_WAVEFRONT) and e.code == L.ERR_UNSUPPORTED
                 continue
+            try:
+                pe = dp.policy_evaluation(pis, 0.95, 1e-6, L.SCHEME_JACOBI)
+            except L.CmdpError as e:  # K2W under policy evaluation: four actions fit its registers at five states per lane only
+                assert which == L.DP_REGISTER_WAVEFRONT and A == 4 and e.code == L.ERR_UNSUPPORTED
+                pe = None
+            outs[which] = (vi, pe)
             n_distinct += which == L.DP_REGISTER_DISTINCT
             n_k2w += which == L.DP_REGISTER_WAVEFRONT
         for which in outs:
             for x, y in zip(outs[L.DP_WORKGROUP], outs[which]):
+                if y is None:
+                    continue
                 for u, v in zip(x, y):
                     np.testing.assert_array_equal(u, v)
         n_k2u = locals().get("n_k2u", 0) + n_distinct
