@@ -82,6 +82,12 @@ __host__ __device__ inline int64_t k1e_max_episodes(int64_t n_steps, int H) { re
 
 // steps of a code word (2-bit fields, unused fields zero) with code 1, 2, 3: n1 | n2 << 11 | n3 << 22 (11-bit fields: the
 // packed words of a 16-word tile add up without carries into the neighbouring field)
+// (at most three reward codes -- DeepSea: no field is 3, so the two bit planes ARE the counts of codes 1 and 2)
+__device__ __forceinline__ uint32_t k1e_code_counts3(uint32_t lo, uint32_t hi) {
+  const uint32_t n1 = __popc(lo & 0x55555555u) + __popc(hi & 0x55555555u);
+  const uint32_t n2 = __popc(lo & 0xaaaaaaaau) + __popc(hi & 0xaaaaaaaau);
+  return n1 | (n2 << 11);
+}
 __device__ __forceinline__ uint32_t k1e_code_counts(uint32_t lo, uint32_t hi) {
   const uint32_t l0 = lo & 0x55555555u, l1 = (lo >> 1) & 0x55555555u;
   const uint32_t h0 = hi & 0x55555555u, h1 = (hi >> 1) & 0x55555555u;
@@ -167,6 +173,7 @@ __global__ void __launch_bounds__(K1E_THREADS) k_rollout_epi(EnvTables t, K1ePla
 
   const int nch = p.nch;
   const uint32_t ash = (uint32_t)p.ash;
+  const bool few_codes = p.n_codes <= 3;
   for (int pass = 0; pass < p.n_pass; ++pass) {
     // the action bits of this pass (the ring holds ONE pass: fill, barrier, walk, barrier -- the fill is one Philox block
     // per thread, the same work for every wavefront)
@@ -233,7 +240,7 @@ __global__ void __launch_bounds__(K1E_THREADS) k_rollout_epi(EnvTables t, K1ePla
               u32x2 v;
               v.x = lo; v.y = hi;
               __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(p.codes) + wi);
-              __builtin_nontemporal_store(k1e_code_counts(lo, hi), p.cnts + wi);
+              __builtin_nontemporal_store(few_codes ? k1e_code_counts3(lo, hi) : k1e_code_counts(lo, hi), p.cnts + wi);
             }
             wi += (uint32_t)nch * (uint32_t)t.B;
           }
