@@ -99,7 +99,7 @@ __device__ __forceinline__ uint32_t k1e_code_counts(uint32_t lo, uint32_t hi) {
 
 typedef __attribute__((address_space(3))) uint32_t* k1e_lds_u32;
 
-__global__ void __launch_bounds__(K1E_THREADS) k_rollout_epi(EnvTables t, K1ePlan p, int n_steps,
+__global__ void __launch_bounds__(K1E_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) k_rollout_epi(EnvTables t, K1ePlan p, int n_steps,
                                                             int32_t* __restrict__ last_obs) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -123,10 +123,25 @@ __global__ void __launch_bounds__(K1E_THREADS) k_rollout_epi(EnvTables t, K1ePla
   // ---- stage: {count 0 | successor word}; the HBM image is interleaved like the LDS one: coalesced, conflict-free ----
   {
     const uint32_t* src = p.etab + (size_t)blockIdx.x * (size_t)S * K1E_NI;
-    for (int k = tid; k < S * K1E_NI; k += K1E_THREADS) {   // k = s * 32 + i
-      const uint32_t pair = src[k];
-      tab[k] = pair & 0xffffu;
-      tab[a_words + k] = pair >> 16;
+    // (k = s * 32 + i; S <= 512: at most 16 dwords per thread, all loads issued before the first store)
+    // (in two batches of eight: the walk's register budget -- 96 VGPRs, so that a wavefront of the reward scan fits beside four
+    // of this kernel's on a SIMD -- is not the staging's to break)
+#pragma unroll
+    for (int j0 = 0; j0 < 16; j0 += 8) {
+      uint32_t pair[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = tid + (j0 + j) * K1E_THREADS;
+        pair[j] = k < S * K1E_NI ? src[k] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = tid + (j0 + j) * K1E_THREADS;
+        if (k < S * K1E_NI) {
+          tab[k] = pair[j] & 0xffffu;
+          tab[a_words + k] = pair[j] >> 16;
+        }
+      }
     }
     if (tid < 32) tab[2 * a_words + tid] = 0u;
     if (tid < nb) {
@@ -295,13 +310,25 @@ __global__ void __launch_bounds__(K1E_THREADS) k_rollout_epi(EnvTables t, K1ePla
   // counts (base.py:1302-1303) are a linear function of them, formed by k_epi_fold when somebody needs the counters ----
   {
     int2* dep = p.dep + (size_t)blockIdx.x * (size_t)S * K1E_NI;
-    for (int k = tid; k < S * K1E_NI; k += K1E_THREADS) {
-      const uint32_t c0 = tab[k] >> 16, c1 = tab[a_words + k] >> 16;
-      if (c0 | c1) {
-        int2 v = dep[k];
-        v.x += (int32_t)c0;
-        v.y += (int32_t)c1;
-        dep[k] = v;
+    // (S <= 512: at most 16 entries per thread; all of a thread's loads are issued before the first is used -- one HBM round
+    // trip per workgroup instead of one per entry)
+    constexpr int FL = 8;   // (two batches of eight, as the staging)
+#pragma unroll
+    for (int j0 = 0; j0 < 16; j0 += FL) {
+      int2 v[FL];
+      uint32_t c0[FL], c1[FL];
+#pragma unroll
+      for (int j = 0; j < FL; ++j) {
+        const int k = tid + (j0 + j) * K1E_THREADS;
+        const bool in = k < S * K1E_NI;
+        c0[j] = in ? tab[k] >> 16 : 0u;
+        c1[j] = in ? tab[a_words + k] >> 16 : 0u;
+        v[j] = (c0[j] | c1[j]) ? dep[k] : make_int2(0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < FL; ++j) {
+        const int k = tid + (j0 + j) * K1E_THREADS;
+        if (c0[j] | c1[j]) dep[k] = make_int2(v[j].x + (int32_t)c0[j], v[j].y + (int32_t)c1[j]);
       }
     }
     if (tid < nb) p.dep_res[g0 + tid] += meta[tid];
