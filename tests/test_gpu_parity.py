@@ -336,6 +336,86 @@ def test_lds_rollout_with_per_instance_episode_phase(need_gpu):
         np.testing.assert_array_equal(g[2][off[b]:off[b + 1]], e.visits()[0])
 
 
+def test_episode_parallel_rollout_interleaved_with_everything_else(need_gpu):
+    """K1E keeps DEPARTURE counts in an image of its own and folds them into the visit counters lazily, and its reward scan
+    runs on a second stream: every other entry point must see the counters and sums as if each launch had finished on the spot.
+    One handle, one oracle environment per instance, the same sequence on both: asynchronous K1E launches, per-step calls,
+    masked resets, a launch of the HBM-table kernel, counter read-outs and resets in between -- visit counts (both arrays),
+    states, in-episode times, reward sums compared with the oracle after every leg."""
+    B, size = 37, 7
+    models = [make_model("DeepSeaEpisodic", seed=50 + i, size=size) for i in range(B)]
+    keys = (np.arange(B) * 2654435761 + 99).astype(np.uint64)
+    env = BatchedMDP(models, rng_mode=L.RNG_PHILOX, philox_keys=keys, with_dp=False)
+    assert env.lds_plan()["kernel"] == "k_rollout_epi"
+    oes = [O.OracleEnv(m, rng_mode=1, philox_key=int(keys[b])) for b, m in enumerate(models)]
+    env.reset()
+    for e in oes:
+        e.reset()
+    off = np.concatenate([[0], np.cumsum([m.n_states for m in models])])
+
+    def check(tag, sums=None, osums=None):
+        vs, vsa = env.visits()
+        cur, h, _ = env.state()
+        for b, e in enumerate(oes):
+            rvs, rvsa = e.visits()
+            np.testing.assert_array_equal(vs[off[b]:off[b + 1]], rvs, err_msg=tag)
+            np.testing.assert_array_equal(vsa[2 * off[b]:2 * off[b + 1]].reshape(-1, 2), rvsa, err_msg=tag)
+            oc, oh, _ = e.state()
+            assert (cur[b], h[b]) == (oc, oh), (tag, b)
+        if sums is not None:
+            np.testing.assert_array_equal(sums, osums, err_msg=tag)
+
+    def oracle_rollout(n):
+        return np.array([e.rollout(n, trace=False)["reward_sum"] for e in oes])
+
+    # two asynchronous K1E launches back to back (the second starts mid-episode), then a read-out
+    env.rollout_async(333)
+    env.rollout_async(1001)
+    oracle_rollout(333)
+    oracle_rollout(1001)
+    check("after two async launches")
+    # a synchronous launch right behind an asynchronous one: its sums come from the second stream
+    env.rollout_async(70)
+    out = env.rollout(4321)
+    oracle_rollout(70)
+    check("sync after async", out["reward_sum"], oracle_rollout(4321))
+    # per-step calls (lane-per-instance kernel), with a masked reset in the middle
+    for t in range(5):
+        acts = (np.arange(B) + t) % 2
+        env.step(acts.astype(np.int32), auto_reset=True)
+        for b, e in enumerate(oes):
+            if e.state()[2]:
+                e.reset()
+            else:
+                e.step(int(acts[b]))
+    mask = ((np.arange(B) % 4 == 1) | env.state()[2]).astype(np.uint8)   # every fourth instance + those a step left terminated
+    env.reset(mask)
+    for b, e in enumerate(oes):
+        if mask[b]:
+            e.reset()
+    check("after steps and a masked reset")
+    # K1E from per-lane episode phases, then the HBM-table kernel, then K1E again
+    a = env.rollout(777)
+    oa = oracle_rollout(777)
+    env.set_rollout_kernel(L.ROLLOUT_GLOBAL)
+    b_ = env.rollout(500)
+    ob = oracle_rollout(500)
+    env.set_rollout_kernel(L.ROLLOUT_AUTO)
+    env.rollout_async(64)
+    oracle_rollout(64)
+    check("K1E / K1 / K1E", a["reward_sum"] + b_["reward_sum"], oa + ob)
+    # counters reset while K1E's image holds counts: they must not come back
+    env.rollout_async(3000)
+    oracle_rollout(3000)
+    env.reset_visits()
+    for e in oes:
+        e.reset_visits()
+    env.rollout_async(129)
+    oracle_rollout(129)
+    check("after reset_visits")
+    env.close()
+
+
 def test_visit_counter_overflow_is_refused_not_wrapped(need_gpu):
     """The device counters are int32 (cmdp_visits widens them); the reference's are Python ints.  A counter restored near
     2^31 (cmdp_set_visits) must make a call that could carry it past 2^31 - 1 fail with CMDP_ERR_OVERFLOW BEFORE anything is
