@@ -574,7 +574,10 @@ def main():
             "transitions_per_s_in_kernel": units_per_launch / dom_s,
             "valu_wave_insts_per_transition": sq["valu_wave_insts_per_launch"] * 64 / units_per_launch if sq else None,
             "sq": sq, "lds_pipe_frac": sq["lds_pipe_frac"] if sq else None,
-            "kernel_ms": timed_kernel_ms, "kernel_ms_note": "of the last timed step, back to back with its neighbours: parts of ms_per_step",
+            "kernel_ms": timed_kernel_ms,
+            "kernel_ms_note": "of the last timed step, back to back with its neighbours (HIP events inside the library).  k_reward_scan runs on the "
+                              "handle's SECOND stream under the k_rollout_epi of the next step (CMDP_K1E_OVERLAP=0: one stream): the two durations "
+                              "overlap in time, ms_per_step ~ k_rollout_epi's; each of them is <= ms_per_step",
             "lds_plan": plan, "traffic": hv["traffic"],
             "hbm": dict(hv, own_algorithmic_bytes_per_launch=own_bytes,
                         own_accounting="k_rollout_epi itself: table image read once per workgroup (4 B per state), 12 B of reward-code + count words "
