@@ -174,6 +174,12 @@ SQ_COUNTERS = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "S
 # cycles a wave64 instruction of K1E's step (v_bfe_u32, v_lshl_or_b32, v_and_or_b32, v_alignbit_b32) occupies a SIMD at 4-8
 # wavefronts per SIMD: measured, tools/calib/valu_int_rate.hip -> profiles/r04_valu_int_rate.txt (float32 v_fma: 2.7-3.0)
 VALU_INT_VOP3_CYCLES = 4.4
+# cycles a wave64 ds_add_rtn_u32 (bank-conflict-free) occupies a CU's LDS pipe, and cycles per wave-transition per SIMD of the
+# walk's step alone -- v_bfe_u32 . v_lshl_or_b32 . v_and_or_b32 . ds_add_rtn_u32 . v_alignbit_b32, four chains per lane, 16
+# wavefronts per CU, nothing else in the loop: measured, tools/calib/lds_atomic_rate.hip -> profiles/r04_lds_atomic_rate.txt
+# (a ds_read_b32 takes 1.1 cycles; SQ_LDS_IDX_ACTIVE counts ~2 per LDS instruction whatever it is, so it UNDERSTATES atomics)
+LDS_ATOMIC_RTN_CYCLES = 4.31
+WALK_STEP_CYCLES_PER_SIMD = 22.4
 
 
 def sq_view(kernel, launch_s, units=None, build_id=None):
@@ -571,6 +577,16 @@ def main():
             "int_rate_note": "the step's instructions (v_bfe_u32, v_lshl_or_b32, v_and_or_b32, v_alignbit_b32) occupy a SIMD for %.1f cycles "
                              "per wavefront at 4-8 wavefronts per SIMD, not 2 (tools/calib/valu_int_rate.hip, profiles/r04_valu_int_rate.txt): "
                              "against THAT issue rate the kernel is at frac_at_measured_int_rate" % VALU_INT_VOP3_CYCLES,
+            "lds_atomic_pipe_frac": (units_per_launch / 64.0) * LDS_ATOMIC_RTN_CYCLES / (N_CUS * dom_s * CLOCK_HZ),
+            "lds_atomic_note": "one returning LDS atomic per transition (it is the table read and the visit count): units / 64 wave-atomics x %.2f "
+                               "cycles of a CU's LDS pipe each (measured: tools/calib/lds_atomic_rate.hip, profiles/r04_lds_atomic_rate.txt; a "
+                               "ds_read_b32 takes 1.1) over the kernel's CU-cycles.  SQ_LDS_IDX_ACTIVE (`lds_pipe_frac`) counts ~2 cycles per LDS "
+                               "instruction of any kind and understates it" % LDS_ATOMIC_RTN_CYCLES,
+            "step_loop_frac": (units_per_launch / 64.0) * WALK_STEP_CYCLES_PER_SIMD / (N_CUS * 4 * dom_s * CLOCK_HZ),
+            "step_loop_note": "the walk's step ALONE (4 VALU + 1 returning LDS atomic, four chains per lane, 16 wavefronts per CU, nothing else "
+                              "in the loop) runs at %.1f cycles per wave-transition per SIMD on this chip -- both pipes nearly full (VALU 4 x 4.6 = "
+                              "18.4, LDS 4 x 4.31 = 17.2): step_loop_frac = that floor / the kernel's duration, i.e. how much of the kernel is "
+                              "the irreducible step; the rest is Philox, code / count words, staging, flush" % WALK_STEP_CYCLES_PER_SIMD,
             "transitions_per_s_in_kernel": units_per_launch / dom_s,
             "valu_wave_insts_per_transition": sq["valu_wave_insts_per_launch"] * 64 / units_per_launch if sq else None,
             "sq": sq, "lds_pipe_frac": sq["lds_pipe_frac"] if sq else None,
@@ -580,8 +596,9 @@ def main():
                               "overlap in time, ms_per_step ~ k_rollout_epi's; each of them is <= ms_per_step",
             "lds_plan": plan, "traffic": hv["traffic"],
             "hbm": dict(hv, own_algorithmic_bytes_per_launch=own_bytes,
-                        own_accounting="k_rollout_epi itself: table image read once per workgroup (4 B per state), 12 B of reward-code + count words "
-                                       "written per episode, 16 B read-modify-write per state of the departure-count image",
+                        own_accounting="k_rollout_epi itself: table image read once per group of 32 instances (4 B per state), 12 B of reward-code + count "
+                                       "words written per episode, 16 B per state of the departure-count image (a returnless 64-bit atomic add: "
+                                       "line in, line out)",
                         own_algorithmic_GBps=own_bytes / dom_s / 1e9,
                         own_traffic_over_algorithmic=(pm_e["bytes"] / own_bytes) if pm_e else None),
             "step": {

@@ -1021,32 +1021,39 @@ int cmdp_create(cmdp_t** out, const cmdp_desc* d) {
         // parallel (private {successor word | count} tables of 32 instances per workgroup): throughput- instead of
         // latency-bound, and the tables need not be action-permuted copies of one MDP.
         static const int k1e_env = std::getenv("CMDP_K1E") ? std::atoi(std::getenv("CMDP_K1E")) : -1;   // tuning aid: 0 off
-        if (A == 2 && h->H > 0 && vals.size() <= 4 && k1e_env != 0) {
+        if (A == 2 && h->H > 0 && h->H < (1 << 14) && vals.size() <= 4 && k1e_env != 0) {
           K1ePlan e{};
           e.S = max_S;
           e.H = h->H;
           e.n_codes = (int)vals.size();
           e.nch = (h->H + 31) / 32;
-          const int64_t pass_bits = (int64_t)K1E_EPP * h->H;
-          int rb = 4;
-          while (rb < (pass_bits + 127) / 128 + 1) rb <<= 1;
+          // a wavefront's ring: the blocks the eight episodes of a round can touch (cmdp_k1e.h)
+          const int64_t round_bits = (int64_t)2 * K1E_EPL * h->H;
+          int rb = 2;
+          while (rb < (round_bits + 126) / 128 + 1) rb <<= 1;
           e.ring_blocks = rb;
-          e.ash = 7;
+          e.ash = 12;   // (at least 32 padded states: an action's image then holds whole rounds of the workgroup's 1024 lanes)
           while ((1 << (e.ash - 7)) < max_S) ++e.ash;   // action stride: states padded to a power of two, 128 B per state
           if (const char* de = std::getenv("CMDP_K1E_DEBUG")) {   // timing experiments: phases switched off
             e.debug = std::atoi(de);
             if (e.debug) std::fprintf(stderr, "libcmdp: CMDP_K1E_DEBUG=%d switches phases of k_rollout_epi off -- results are INVALID (timing experiments only)\n", e.debug);
           }
-          if (max_S <= 512 && k1e_lds_bytes(e) <= (size_t)kLdsBudget) {
+          e.gdw = (int32_t)((((int64_t)max_S * K1E_NI + K1E_THREADS - 1) / K1E_THREADS) * K1E_THREADS);   // a group's image: whole rounds of the workgroup's loads
+          const size_t k1e_behind = k1e_lds_bytes(e);
+          const bool k1e_fits = k1e_behind <= (size_t)kLdsBudget;
+          if (std::getenv("CMDP_K1E_VERBOSE"))
+            std::fprintf(stderr, "libcmdp: K1E plan S %d H %d codes %d ash %d ring_blocks %d gdw %d tables+rings %zu B fits %d\n", e.S, e.H, e.n_codes,
+                         e.ash, e.ring_blocks, e.gdw, k1e_behind, (int)k1e_fits);
+          if (max_S <= 512 && k1e_fits) {
             // interleaved by instance like the LDS image: [group of 32][state][instance in group]
             const int64_t groups = ((int64_t)B + K1E_NI - 1) / K1E_NI;
-            std::vector<uint32_t> et((size_t)groups * max_S * K1E_NI, 0u);
+            std::vector<uint32_t> et((size_t)groups * (size_t)e.gdw, 0u);
             for (int64_t b2 = 0; b2 < B; ++b2)
               for (int s2 = 0; s2 < max_S; ++s2) {
                 const int64_t sidx = b2 * max_S + s2;
                 const uint32_t w0 = ((uint32_t)rows[(size_t)(2 * sidx)].next_if_det << 7) | codes[(size_t)(2 * sidx)];
                 const uint32_t w1 = ((uint32_t)rows[(size_t)(2 * sidx + 1)].next_if_det << 7) | codes[(size_t)(2 * sidx + 1)];
-                et[(size_t)((b2 / K1E_NI) * max_S + s2) * K1E_NI + (size_t)(b2 % K1E_NI)] = w0 | (w1 << 16);
+                et[(size_t)(b2 / K1E_NI) * (size_t)e.gdw + (size_t)s2 * K1E_NI + (size_t)(b2 % K1E_NI)] = w0 | (w1 << 16);
               }
             HIP_TRY(h->d_etab.upload(et.data(), et.size(), st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -1445,7 +1452,7 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
       for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&h->ev_k1u[i]));
     K1ePlan e = h->k1e;
     if (!h->d_k1e_dep.p) {
-      const size_t nd = (size_t)grid_for(h->B, K1E_NI) * (size_t)e.S * K1E_NI;
+      const size_t nd = (size_t)grid_for(h->B, K1E_NI) * (size_t)e.gdw;
       HIP_TRY(h->d_k1e_dep.alloc(nd));
       HIP_TRY(h->d_k1e_dep.zero(st));
       HIP_TRY(h->d_k1e_dep_res.alloc(h->B));
@@ -1464,8 +1471,8 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
     if (ov && !h->aux_stream) HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
     if (ov && !h->ev_k1e_walk[0])
       for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipEventCreateWithFlags(&h->ev_k1e_walk[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&h->ev_k1e_scan[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_k1e_walk[i], hipEventDisableTiming | hipEventDisableSystemFence));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_k1e_scan[i], hipEventDisableTiming | hipEventDisableSystemFence));
       }
     if (!ov) { if (int rc = k1e_scan_join(h)) return rc; }
     // segment length: the code words of a segment (12 bytes per episode chunk and instance, two sets) stay within ~1.5 GB
@@ -1475,7 +1482,8 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
     const size_t need = (size_t)epi_cap * (size_t)e.nch * (size_t)h->B;
     if (h->d_k1e_h0.n < (size_t)h->B) HIP_TRY(h->d_k1e_h0.alloc(h->B));
     if (h->d_k1e_h0b.n < (size_t)h->B) HIP_TRY(h->d_k1e_h0b.alloc(h->B));
-    if (int rc = set_lds(k_rollout_epi, h->k1e_lds)) return rc;
+    if (int rc = set_lds(k_rollout_epi<true>, h->k1e_lds)) return rc;
+    if (int rc = set_lds(k_rollout_epi<false>, h->k1e_lds)) return rc;
     for (int64_t s0 = 0; s0 < n_steps; s0 += seg) {
       const int64_t n = std::min<int64_t>(seg, n_steps - s0);
       const int i = ov ? (int)(h->k1e_seq & 1) : 0;
@@ -1500,7 +1508,12 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
       if (ov && h->ev_k1e_scan_used[i]) HIP_TRY(hipStreamWaitEvent(st, h->ev_k1e_scan[i], 0));   // its last scan has read this set
       const bool last = s0 + seg >= n_steps;
       if (last) HIP_TRY(hipEventRecord(h->ev_k1u[0], st));
-      hipLaunchKernelGGL(k_rollout_epi, dim3(grid_for(h->B, K1E_NI)), dim3(K1E_THREADS), h->k1e_lds, st, t, e, (int)n, d_last);
+      // one workgroup per CU (the tables take the CU's LDS), each walking its groups one after the other with the next
+      // group's table image in flight under the walk; CMDP_K1E_GRID = workgroups (timing experiments; any value is correct)
+      int k1e_grid = std::min(grid_for(h->B, K1E_NI), h->cus);
+      if (const char* gs = std::getenv("CMDP_K1E_GRID")) k1e_grid = std::max(1, std::min(grid_for(h->B, K1E_NI), std::atoi(gs)));
+      if (e.n_codes <= 3) hipLaunchKernelGGL(k_rollout_epi<true>, dim3(k1e_grid), dim3(K1E_THREADS), h->k1e_lds, st, t, e, (int)n, d_last);
+      else hipLaunchKernelGGL(k_rollout_epi<false>, dim3(k1e_grid), dim3(K1E_THREADS), h->k1e_lds, st, t, e, (int)n, d_last);
       if (last) HIP_TRY(hipEventRecord(h->ev_k1u[1], st));
       if (ov) {
         HIP_TRY(hipEventRecord(h->ev_k1e_walk[i], st));
