@@ -1449,7 +1449,7 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
     // the reward scan over the code words it left in HBM
     if (int rc = k1u_join(h)) return rc;
     if (!h->ev_k1u[0])
-      for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&h->ev_k1u[i]));
+      for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreateWithFlags(&h->ev_k1u[i], hipEventDisableSystemFence));   // (timestamps only: no host-visibility cache flush per launch)
     K1ePlan e = h->k1e;
     if (!h->d_k1e_dep.p) {
       const size_t nd = (size_t)grid_for(h->B, K1E_NI) * (size_t)e.gdw;
@@ -1545,12 +1545,12 @@ static int launch_rollout(cmdp_t* h, int policy, const int8_t* d_actions, int64_
     static const int ov_env = std::getenv("CMDP_K1U_OVERLAP") ? std::atoi(std::getenv("CMDP_K1U_OVERLAP")) : -1;
     const bool ov = (ov_env < 0 ? h->k1u_overlap : ov_env != 0) && h->k1u_overlap_fits;
     if (!h->ev_k1u[0])
-      for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&h->ev_k1u[i]));
+      for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreateWithFlags(&h->ev_k1u[i], hipEventDisableSystemFence));   // (timestamps only: no host-visibility cache flush per launch)
     if (ov && !h->aux_stream) {
       HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
       for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipEventCreateWithFlags(&h->ev_trace[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&h->ev_hist[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_trace[i], hipEventDisableTiming | hipEventDisableSystemFence));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_hist[i], hipEventDisableTiming | hipEventDisableSystemFence));
       }
     }
     if (!ov) { if (int rc = k1u_join(h)) return rc; }

@@ -627,15 +627,31 @@ __global__ void __launch_bounds__(K1R_THREADS) __attribute__((amdgpu_waves_per_e
       if (L) {
         const u32x2 c = csrc[(size_t)(w0 + k) * t.B];
         if (kvalid) S = compose();
-        // (step by step exactly as the oracle adds; the reward of a code by a select on four registers -- the scan owns no LDS
-        // at all, k_rollout_epi may hold every byte of the CU's; the path is rare)
-        uint32_t cw = c.x;
-        for (uint32_t j = 0; j < L; ++j) {
-          if (j == 16) cw = c.y;
-          const bool b0 = (cw & 1u) != 0u, b1 = (cw & 2u) != 0u;
-          const double lo2 = b0 ? rv1 : rv0, hi2 = b0 ? rv3 : rv2;
-          S += b1 ? hi2 : lo2;
-          cw >>= 2;
+        // (step by step exactly as the oracle adds, but for the steps whose reward is +0.0 -- x + 0.0 == x, the sum is never
+        // -0.0 -- which are skipped: the scaled minimum reward is 0, half of DeepSea's steps.  The reward of a code by a
+        // select on four registers: the scan owns no LDS at all, k_rollout_epi may hold every byte of the CU's.  One wavefront
+        // per SIMD issues an instruction every ~8 cycles, so this path is priced by its instruction count)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const uint32_t cw = half ? c.y : c.x;
+          const int Lh = (int)L - 16 * half;
+          if (Lh > 0) {
+            const uint32_t vm = Lh >= 16 ? 0x55555555u : ((1u << (2 * Lh)) - 1u) & 0x55555555u;
+            const uint32_t b0 = cw & vm, b1 = (cw >> 1) & vm;
+            uint32_t nz = 0u;
+            if (rv0 != 0.0) nz |= vm & ~(b0 | b1);
+            if (rv1 != 0.0) nz |= b0 & ~b1;
+            if (rv2 != 0.0) nz |= b1 & ~b0;
+            if (rv3 != 0.0) nz |= b0 & b1;
+            while (nz) {
+              const uint32_t pos = (uint32_t)__builtin_ctz(nz);
+              nz &= nz - 1u;
+              const uint32_t cd = cw >> pos;
+              const bool c0 = (cd & 1u) != 0u, c1 = (cd & 2u) != 0u;
+              const double lo2 = c0 ? rv1 : rv0, hi2 = c0 ? rv3 : rv2;
+              S += c1 ? hi2 : lo2;
+            }
+          }
         }
         rebase();
       }
