@@ -177,11 +177,11 @@ SQ_COUNTERS = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "S
 # wavefronts per SIMD: measured, tools/calib/valu_int_rate.hip -> profiles/r04_valu_int_rate.txt (float32 v_fma: 2.7-3.0)
 VALU_INT_VOP3_CYCLES = 4.4
 # cycles a wave64 ds_add_rtn_u32 (bank-conflict-free) occupies a CU's LDS pipe, and cycles per wave-transition per SIMD of the
-# walk's step alone -- v_bfe_u32 . v_lshl_or_b32 . v_and_or_b32 . ds_add_rtn_u32 . v_alignbit_b32, four chains per lane, 16
+# walk's step alone -- v_add_co_u32 . v_cndmask_b32 . v_and_or_b32 . ds_add_rtn_u32 . v_alignbit_b32, four chains per lane, 16
 # wavefronts per CU, nothing else in the loop: measured, tools/calib/lds_atomic_rate.hip -> profiles/r04_lds_atomic_rate.txt
 # (a ds_read_b32 takes 1.1 cycles; SQ_LDS_IDX_ACTIVE counts ~2 per LDS instruction whatever it is, so it UNDERSTATES atomics)
 LDS_ATOMIC_RTN_CYCLES = 4.31
-WALK_STEP_CYCLES_PER_SIMD = 22.4
+WALK_STEP_CYCLES_PER_SIMD = 20.9
 
 
 def sq_view(kernel, launch_s, units=None, build_id=None):
@@ -585,7 +585,7 @@ def main():
                      "inside the library); peak = %d CUs x 4 SIMDs x %.1f GHz / %d cycles per wave64 VALU instruction (MI355X_MICROARCH.md: "
                      "the float32 figure)" % (N_CUS, CLOCK_HZ / 1e9, VALU_CYCLES),
             "frac_at_measured_int_rate": sq["valu_G_wave_insts_per_s"] / (N_CUS * 4 * CLOCK_HZ / VALU_INT_VOP3_CYCLES / 1e9) if sq else None,
-            "int_rate_note": "the step's instructions (v_bfe_u32, v_lshl_or_b32, v_and_or_b32, v_alignbit_b32) occupy a SIMD for %.1f cycles "
+            "int_rate_note": "the step's VOP3 instructions (v_and_or_b32, v_alignbit_b32; v_bfe_u32, v_lshl_or_b32) occupy a SIMD for %.1f cycles "
                              "per wavefront at 4-8 wavefronts per SIMD, not 2 (tools/calib/valu_int_rate.hip, profiles/r04_valu_int_rate.txt): "
                              "against THAT issue rate the kernel is at frac_at_measured_int_rate" % VALU_INT_VOP3_CYCLES,
             "lds_atomic_pipe_frac": (units_per_launch / 64.0) * LDS_ATOMIC_RTN_CYCLES / (N_CUS * dom_s * CLOCK_HZ),
@@ -595,8 +595,8 @@ def main():
                                "instruction of any kind and understates it" % LDS_ATOMIC_RTN_CYCLES,
             "step_loop_frac": (units_per_launch / 64.0) * WALK_STEP_CYCLES_PER_SIMD / (N_CUS * 4 * dom_s * CLOCK_HZ),
             "step_loop_note": "the walk's step ALONE (4 VALU + 1 returning LDS atomic, four chains per lane, 16 wavefronts per CU, nothing else "
-                              "in the loop) runs at %.1f cycles per wave-transition per SIMD on this chip -- both pipes nearly full (VALU 4 x 4.6 = "
-                              "18.4, LDS 4 x 4.31 = 17.2): step_loop_frac = that floor / the kernel's duration, i.e. how much of the kernel is "
+                              "in the loop) runs at %.1f cycles per wave-transition per SIMD on this chip -- both pipes nearly full (VALU ~17, LDS "
+                              "4 x 4.31 = 17.2): step_loop_frac = that floor / the kernel's duration, i.e. how much of the kernel is "
                               "the irreducible step; the rest is Philox, code / count words, staging, flush" % WALK_STEP_CYCLES_PER_SIMD,
             "transitions_per_s_in_kernel": units_per_launch / dom_s,
             "valu_wave_insts_per_transition": sq["valu_wave_insts_per_launch"] * 64 / units_per_launch if sq else None,

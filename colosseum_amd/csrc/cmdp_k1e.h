@@ -23,11 +23,13 @@
 //         bank-conflict-free whatever the states are (a slot per instance measured 76 % of the LDS cycles as conflicts: 32
 //         random dwords over 32 banks collide 3.5-fold), and no two lanes ever add to the same dword.  The successor word
 //         is s' << 7 | reward code: the address of the next row is ONE v_and_or_b32, (word & 0xff80) | (action << ASH | 4 i).
-//   step  v_bfe (action bit) . v_lshl_or (| lane base) . v_and_or (address) . ds_add_rtn_u32 . v_alignbit (reward code into
-//         the episode's code word): the returning atomic IS the table read -- it counts the row the chain LEAVES and hands
-//         back its successor word: 4 VALU + 1 LDS instruction per transition (spelled out in inline asm: left alone the
-//         compiler sometimes picks a five-instruction form).  An idle chain (no episode left for it) walks from state 0 under
-//         action 0 and adds ZERO.
+//   step  v_add_co (next action bit -> VCC) . v_cndmask (the lane's base in that action's image) . v_and_or (address) .
+//         ds_add_rtn_u32 . v_alignbit (reward code into the episode's code word): the returning atomic IS the table read -- it
+//         counts the row the chain LEAVES and hands back its successor word: 4 VALU + 1 LDS instruction per transition,
+//         spelled out in inline asm (left alone the compiler picks v_bfe . v_and . v_lshlrev . v_or3, five with the
+//         v_alignbit; v_bfe . v_lshl_or . v_and_or is four but two of them VOP3 where v_add_co . v_cndmask are VOP2: 25.2 /
+//         22.4 / 20.9 cycles per wave-transition per SIMD in isolation).  An idle chain (no episode left for it) walks from
+//         state 0 under action 0 and adds ZERO.
 //   lanes lane = (instance l & 31, half l >> 5).  Wavefront w owns a CONTIGUOUS range of the segment's episodes and walks it
 //         eight at a time (a round): half s, chain c in {0 .. 3} walks episode 8 (R w + r) + 4 s + c -- four independent
 //         chains per lane, their atomics issued together.
@@ -137,6 +139,7 @@ __global__ void __launch_bounds__(K1E_THREADS) __attribute__((amdgpu_waves_per_e
   const uint32_t RD = (uint32_t)p.ring_blocks * 4u;      // ring dwords per instance
   uint32_t* ring = reinterpret_cast<uint32_t*>(smem + tab_bytes) + (size_t)wave * RD * K1E_NI;   // this wavefront's ring
   const uint32_t lbase = lds0 + 4u * (uint32_t)inst;     // the lane's bank
+  const uint32_t lbase1 = lbase | (1u << p.ash);         // ... in the image of action 1
   const int nch = p.nch;
   const uint32_t ash = (uint32_t)p.ash;
   const int nj = p.gdw / K1E_THREADS;                     // rounds of the workgroup over a group's image (<= 16)
@@ -263,19 +266,22 @@ __global__ void __launch_bounds__(K1E_THREADS) __attribute__((amdgpu_waves_per_e
 #pragma unroll
           for (int c = 0; c < K1E_EPL; ++c) {
             const uint32_t fb = fetch_bits(first_of(c) + 32 * ch);
-            bits[c] = full_of(c) ? fb : 0u;
+            bits[c] = full_of(c) ? __builtin_bitreverse32(fb) : 0u;
             clo[c] = 0u; chi[c] = 0u;
           }
           // one step of all the lane's chains: the atomics of all chains are issued before the first is waited for
-          auto steps = [&](int j, uint32_t (&cw)[K1E_EPL]) {
+          auto steps = [&](uint32_t (&cw)[K1E_EPL]) {
             uint32_t ra[K1E_EPL];
 #pragma unroll
             for (int c = 0; c < K1E_EPL; ++c) {
               // (spelled out: left to itself the compiler may pick v_bfe . v_and (literal) . v_lshlrev . v_or3 -- five VALU
               // instructions per transition with the code word's v_alignbit instead of four)
-              uint32_t a, ax;
-              asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(a) : "v"(bits[c]), "s"(j));
-              asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(ax) : "v"(a), "s"(ash), "v"(lbase));
+              // (the action bits are consumed from the TOP of the bit-reversed window: v_add_co_u32 shifts the next one into VCC,
+              // v_cndmask_b32 picks the lane's base in that action's image -- two VOP2 instructions where v_bfe_u32 .
+              // v_lshl_or_b32 are two VOP3 ones: 20.9 instead of 22.4 cycles per wave-transition in isolation,
+              // tools/calib/lds_atomic_rate.hip)
+              uint32_t ax;
+              asm("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, %2, %3, vcc" : "+v"(bits[c]), "=v"(ax) : "v"(lbase), "v"(lbase1) : "vcc");
               asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ra[c]) : "v"(w[c]), "s"(K1E_SMASK), "v"(ax));
             }
 #pragma unroll
@@ -287,11 +293,11 @@ __global__ void __launch_bounds__(K1E_THREADS) __attribute__((amdgpu_waves_per_e
           const int L0 = __builtin_amdgcn_readfirstlane(min(L, 16));   // (wave-uniform by construction: keep the loop control scalar)
           {
             int j = 0;
-            for (; j + 1 < L0; j += 2) { steps(j, clo); steps(j + 1, clo); }
-            if (j < L0) steps(j, clo);
+            for (; j + 1 < L0; j += 2) { steps(clo); steps(clo); }
+            if (j < L0) steps(clo);
             j = 16;
-            for (; j + 1 < L; j += 2) { steps(j, chi); steps(j + 1, chi); }
-            if (j < L) steps(j, chi);
+            for (; j + 1 < L; j += 2) { steps(chi); steps(chi); }
+            if (j < L) steps(chi);
           }
           if (!(p.debug & 8)) {
             uint32_t wi = ((uint32_t)e0 * (uint32_t)nch + (uint32_t)ch) * (uint32_t)t.B + (uint32_t)b;

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(1024) k_walk(uint32_t* out, int iters, uint32_
   extern __shared__ uint32_t tab[];
   for (int k = threadIdx.x; k < 32768; k += 1024) tab[k] = ((uint32_t)(k * 2654435761u) >> 9) & 0xff83u;   // successor word | code
   __syncthreads();
-  const uint32_t x0 = 4u * (threadIdx.x & 31u);
+  const uint32_t x0 = 4u * (threadIdx.x & 31u), x1 = x0 | (1u << ash);
   uint32_t w[EPL], bits[EPL], cw[EPL];
 #pragma unroll
   for (int c = 0; c < EPL; ++c) { w[c] = (threadIdx.x * 640u + c * 4736u) & 0xff80u; bits[c] = threadIdx.x * 2654435761u + c; cw[c] = 0; }
@@ -54,6 +54,11 @@ __global__ void __launch_bounds__(1024) k_walk(uint32_t* out, int iters, uint32_
             uint32_t a, t;
             asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(a) : "v"(bits[c]), "s"(j + u));
             asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(t) : "v"(a), "s"(ash), "v"(x0));
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ra[c]) : "v"(w[c]), "s"(0xff80u), "v"(t));
+          } else if (FORM == 2) {   // v_add_co_u32 (shifts the next action bit into VCC) . v_cndmask_b32 (lane base of that action) . v_and_or_b32:
+                                    // two VOP2 instructions instead of two VOP3 ones (bits consumed from the top: bit-reversed words)
+            uint32_t t;
+            asm volatile("v_add_co_u32 %0, vcc, %0, %0\n\tv_cndmask_b32 %1, %2, %3, vcc" : "+v"(bits[c]), "=v"(t) : "v"(x0), "v"(x1) : "vcc");
             asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ra[c]) : "v"(w[c]), "s"(0xff80u), "v"(t));
           } else {           // what the compiler may also pick: bfe . and (literal) . lshl . or3
             const uint32_t a = (bits[c] >> (j + u)) & 1u;
@@ -94,6 +99,7 @@ int main() {
   hipFuncSetAttribute((const void*)k_lds<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipFuncSetAttribute((const void*)k_walk<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipFuncSetAttribute((const void*)k_walk<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipFuncSetAttribute((const void*)k_walk<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipFuncSetAttribute((const void*)k_walk<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipFuncSetAttribute((const void*)k_walk<6, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipFuncSetAttribute((const void*)k_walk<8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -115,6 +121,7 @@ int main() {
   };
   report("walk step, 4 chains, bfe.lshl_or.and_or", timed([&] { hipLaunchKernelGGL((k_walk<4, 0>), dim3(cus), dim3(1024), lds, 0, out, it2, 16u); }), 4);
   report("walk step, 4 chains, compiler's choice", timed([&] { hipLaunchKernelGGL((k_walk<4, 1>), dim3(cus), dim3(1024), lds, 0, out, it2, 16u); }), 4);
+  report("walk step, 4 chains, add_co.cndmask.and_or", timed([&] { hipLaunchKernelGGL((k_walk<4, 2>), dim3(cus), dim3(1024), lds, 0, out, it2, 16u); }), 4);
   report("walk step, 2 chains, bfe.lshl_or.and_or", timed([&] { hipLaunchKernelGGL((k_walk<2, 0>), dim3(cus), dim3(1024), lds, 0, out, it2, 16u); }), 2);
   report("walk step, 6 chains, bfe.lshl_or.and_or", timed([&] { hipLaunchKernelGGL((k_walk<6, 0>), dim3(cus), dim3(1024), lds, 0, out, it2, 16u); }), 6);
   report("walk step, 8 chains, bfe.lshl_or.and_or", timed([&] { hipLaunchKernelGGL((k_walk<8, 0>), dim3(cus), dim3(1024), lds, 0, out, it2, 16u); }), 8);
