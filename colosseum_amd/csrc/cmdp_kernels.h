@@ -1811,6 +1811,8 @@ k_dp_regu(DpTables t) {
 // The price is registers: SPT (A U + U + A) resident table entries per lane (C3: 6 x 29 = 174 of 253 VGPRs), i.e. two
 // wavefronts per SIMD.  Same arithmetic in the same order per row: bit-equal to K2U, K2R, K2 and the oracle.
 // C3 (4 096 x FrozenLake 20x20): 2.00 ms against K2U's 2.43 ms; 322 VALU wave-instructions per instance-sweep against 419.
+// (Round 4: two actions per v_pk_mul_f32 / v_pk_add_f32 -- bit-equal, 144 fewer instructions per sweep -- changed nothing,
+// 2.09 ms: the sweep is a latency chain -- 36 gathers -> sums -> DPP reduction -> branch -- at two wavefronts per SIMD.)
 template <int MODE, int A_T, int U_T, int KMAX, int SPT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_dp_regw(DpTables t) {
