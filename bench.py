@@ -181,6 +181,7 @@ VALU_INT_VOP3_CYCLES = 4.4
 # wavefronts per CU, nothing else in the loop: measured, tools/calib/lds_atomic_rate.hip -> profiles/r04_lds_atomic_rate.txt
 # (a ds_read_b32 takes 1.1 cycles; SQ_LDS_IDX_ACTIVE counts ~2 per LDS instruction whatever it is, so it UNDERSTATES atomics)
 LDS_ATOMIC_RTN_CYCLES = 4.31
+VALU_FP32_CYCLES_2_WAVES = 4.22   # v_fma_f32 at two wavefronts per SIMD (profiles/r04_valu_int_rate.txt)
 WALK_STEP_CYCLES_PER_SIMD = 20.9
 
 
@@ -843,6 +844,17 @@ def main():
                             vr[extra] = k[extra]
         except Exception:
             pass
+        if vr["frac"] is not None and kname == "k_dp_regw":
+            # k_dp_regw keeps an instance's whole CSR in registers (174 of 253 VGPRs at C3): TWO wavefronts per SIMD, and at two
+            # wavefronts per SIMD a float32 VALU instruction issues every 4.22 cycles on this chip, not every 2 (measured:
+            # tools/calib/valu_int_rate.hip, profiles/r04_valu_int_rate.txt, v_fma_f32 at waves/SIMD 2)
+            vr["frac_at_measured_rate_two_waves_per_simd"] = vr["frac"] * VALU_FP32_CYCLES_2_WAVES / VALU_CYCLES
+            vr["measured_rate_note"] = ("the kernel runs at two wavefronts per SIMD (its tables fill the register file); there a wave64 float32 VALU "
+                                        "instruction issues every %.2f cycles, not every %d (tools/calib/valu_int_rate.hip, profiles/r04_valu_int_rate.txt): "
+                                        "against THAT rate the sweep is at frac_at_measured_rate_two_waves_per_simd -- the SIMDs issue back to back; "
+                                        "fewer instructions (packed float32: bit-equal, 144 fewer per sweep) did not shorten the sweep, more wavefronts "
+                                        "per SIMD would (K2U, the instance over four wavefronts, pays a barrier per sweep for them: 2.4 ms)"
+                                        % (VALU_FP32_CYCLES_2_WAVES, VALU_CYCLES))
         line["vi"]["roofline"] = vr
         dp.close()
 
