@@ -852,7 +852,8 @@ def main():
             vr["measured_rate_note"] = ("the kernel runs at two wavefronts per SIMD (its tables fill the register file); there a wave64 float32 VALU "
                                         "instruction issues every %.2f cycles, not every %d (tools/calib/valu_int_rate.hip, profiles/r04_valu_int_rate.txt): "
                                         "against THAT rate the sweep is at frac_at_measured_rate_two_waves_per_simd -- the SIMDs issue back to back; "
-                                        "fewer instructions (packed float32: bit-equal, 144 fewer per sweep) did not shorten the sweep, more wavefronts "
+                                        "packed float32 (bit-equal, 144 fewer instructions per sweep) did not shorten the sweep -- a v_pk_mul_f32 / v_pk_add_f32 issues "
+                                        "every 6.1 cycles there, two plain ones every 8.4, and the pairs cost register moves; more wavefronts "
                                         "per SIMD would (K2U, the instance over four wavefronts, pays a barrier per sweep for them: 2.4 ms)"
                                         % (VALU_FP32_CYCLES_2_WAVES, VALU_CYCLES))
         line["vi"]["roofline"] = vr

@@ -1812,7 +1812,8 @@ k_dp_regu(DpTables t) {
 // wavefronts per SIMD.  Same arithmetic in the same order per row: bit-equal to K2U, K2R, K2 and the oracle.
 // C3 (4 096 x FrozenLake 20x20): 2.00 ms against K2U's 2.43 ms; 322 VALU wave-instructions per instance-sweep against 419.
 // (Round 4: two actions per v_pk_mul_f32 / v_pk_add_f32 -- bit-equal, 144 fewer instructions per sweep -- changed nothing,
-// 2.09 ms: the sweep is a latency chain -- 36 gathers -> sums -> DPP reduction -> branch -- at two wavefronts per SIMD.)
+// 2.09 ms: at two wavefronts per SIMD a packed instruction issues every 6.1 cycles, a plain float32 one every 4.2
+// (tools/calib/valu_int_rate.hip), and the pairs cost register moves.  The SIMDs issue back to back at that rate.)
 template <int MODE, int A_T, int U_T, int KMAX, int SPT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_dp_regw(DpTables t) {

@@ -9,8 +9,11 @@
 template <int OP, int ILP>
 __global__ void k(uint32_t* out, int iters, uint32_t a, uint32_t b) {
   uint32_t x[ILP];
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 y[ILP];
+  const f2 yb = {__uint_as_float(a), __uint_as_float(b)};
 #pragma unroll
-  for (int i = 0; i < ILP; ++i) x[i] = threadIdx.x * 2654435761u + i;
+  for (int i = 0; i < ILP; ++i) { x[i] = threadIdx.x * 2654435761u + i; y[i] = (f2){(float)i, (float)threadIdx.x}; }
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < ILP; ++i) {
@@ -22,11 +25,13 @@ __global__ void k(uint32_t* out, int iters, uint32_t a, uint32_t b) {
       if (OP == 5) asm volatile("v_add_u32 %0, %1, %0" : "+v"(x[i]) : "v"(a));
       if (OP == 6) { float f = __uint_as_float(x[i]); asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f) : "v"(__uint_as_float(a)), "v"(__uint_as_float(b))); x[i] = __float_as_uint(f); }
       if (OP == 7) asm volatile("v_or_b32 %0, %1, %0" : "+v"(x[i]) : "v"(a));
+      if (OP == 8) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(y[i]) : "v"(yb));   // two float32 per lane and instruction
+      if (OP == 9) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(y[i]) : "v"(yb));
     }
   }
   uint32_t s = 0;
 #pragma unroll
-  for (int i = 0; i < ILP; ++i) s += x[i];
+  for (int i = 0; i < ILP; ++i) s += x[i] + __float_as_uint(y[i].x) + __float_as_uint(y[i].y);
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -69,5 +74,7 @@ int main() {
   run<2>("v_bfe_u32", out, cus, khz);
   run<3>("v_alignbit_b32", out, cus, khz);
   run<4>("v_and_or_b32", out, cus, khz);
+  run<8>("v_pk_mul_f32", out, cus, khz);
+  run<9>("v_pk_add_f32", out, cus, khz);
   return 0;
 }
