@@ -360,11 +360,15 @@ __global__ void __launch_bounds__(K1T_THREADS) k_rollout_tmpl(EnvTables t, TmplP
   }
   if (wave < 2 && owner) {
     cur /= 2 * A;
-    t.cur[b] = cur;
-    t.hstep[b] = h;
-    t.n_trans[b] = my_ntr + (unsigned long long)n_steps;
-    t.n_reset[b] += (unsigned long long)n_resets_total;
-    if (last_obs) last_obs[b] = cur;  // the state after the last transition (the start state after a termination)
+    // (the addresses of the instance's scalars are formed HERE, from an index the optimiser cannot trace back to the loads at
+    // the top: kept from there they were three register pairs spilled across the whole walk)
+    int bo = b;
+    asm volatile("" : "+v"(bo));
+    t.cur[bo] = cur;
+    t.hstep[bo] = h;
+    t.n_trans[bo] = my_ntr + (unsigned long long)n_steps;
+    t.n_reset[bo] += (unsigned long long)n_resets_total;
+    if (last_obs) last_obs[bo] = cur;  // the state after the last transition (the start state after a termination)
   }
   if (wave >= 4 && wave < 6 && owner && reward_sum) reward_sum[b] = sum;
 }
