@@ -128,8 +128,9 @@ __global__ void __launch_bounds__(K1E_THREADS) __attribute__((amdgpu_waves_per_e
                                                             int32_t* __restrict__ last_obs) {
   extern __shared__ __align__(16) unsigned char smem[];
   // (the reward scan of the previous launch shares the SIMDs with this kernel: the walk takes the issue slots first, the scan
-  // -- one latency-bound wavefront per SIMD with a whole launch to finish in -- what is left)
-  __builtin_amdgcn_s_setprio(3);
+  // -- one latency-bound wavefront per SIMD with a whole launch to finish in -- what is left.  Not when a workgroup has a
+  // single group to walk: the launch is then shorter than the scan, and the scan is what the step waits for)
+  if ((t.B + K1E_NI - 1) / K1E_NI > (int)gridDim.x) __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int inst = lane & (K1E_NI - 1), sub = lane >> 5;
