@@ -36,6 +36,13 @@ SMALL = ["--instances", "2048", "--launch-steps", "600", "--steps", "3", "--warm
 def test_bench_two_ranks_without_and_with_a_launcher(need_gpu):
     one = json.loads(_run([sys.executable, "bench.py", "--gpus", "1"] + SMALL).strip().splitlines()[-1])
     assert one["n_gpus"] == 1 and one["scaling"] == "weak"
+    # the bench contract's objects, and the hardware-anchored fields of the episode-parallel kernel's roofline
+    r = one["roofline"]
+    assert r["kernel"] == "k_rollout_epi" and r["bound"] == "valu_issue" and one["config"]["settle_launches"] == 80
+    for k in ("achieved", "peak", "frac", "traffic", "frac_at_measured_int_rate", "lds_atomic_pipe_frac", "step_loop_frac", "kernel_ms"):
+        assert k in r, k
+    assert 0.0 < r["lds_atomic_pipe_frac"] < 1.0 and 0.0 < r["step_loop_frac"] < 1.0
+    assert set(r["kernel_ms"]) == {"k_rollout_epi", "k_reward_scan"} and max(r["kernel_ms"].values()) <= one["ms_per_step"] * 1.5
     # no WORLD_SIZE in the environment: bench.py starts its two ranks itself
     two = json.loads(_run([sys.executable, "bench.py", "--gpus", "2"] + SMALL).strip().splitlines()[-1])
     # the driver's form
