@@ -733,6 +733,9 @@ def main():
         senv.reset()
         if args.rollout_kernel:
             senv.set_rollout_kernel(args.rollout_kernel)
+        for _ in range(settle):   # the same settling launches as the headline handle got
+            senv.rollout_async(args.launch_steps)
+        senv.synchronize()
         s_wall, s_ms = timed_launches(senv, args.steps, args.launch_steps, args.warmup)
         s_launch = float(np.mean(s_ms)) * 1e-3
         line["strong"] = {
