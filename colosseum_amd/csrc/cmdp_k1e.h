@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(K1E_THREADS) __attribute__((amdgpu_waves_per_e
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int inst = lane & (K1E_NI - 1), sub = lane >> 5;
-  const int S = p.S, H = p.H;
+  const int H = p.H;
   const int n_groups = (t.B + K1E_NI - 1) / K1E_NI;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;   // 0: no static LDS here
   const uint32_t tab_bytes = 2u << p.ash;
